@@ -1,0 +1,280 @@
+"""Restatement (torch-CPU) of the UniRes y-update path, composed exactly as the
+reference composes it (dense affine grid rebuilt per call, unfused pull / conv /
+push, stacked gradient, unpreconditioned CG) - deliberately slow.
+
+ORACLE - test infrastructure only (see oracle/__init__.py); PARITY UNPINNED at
+the nitorch boundary (oracle/nitorch_restated.py).  Each function cites the
+reference lines it follows.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+from torch.nn import functional as F
+
+from .nitorch_restated import (affine_grid, grid_pull, grid_push, im_gradient,
+                               im_divergence, cg, smooth, voxel_size)
+
+
+# --------------------------------------------------------------------------
+# unires/struct.py:4-54  (only the fields the hot path reads)
+# --------------------------------------------------------------------------
+def make_input(dat, mat, tau, po=None):
+    return SimpleNamespace(dat=dat, dim=tuple(dat.shape), mat=mat, tau=tau, po=po, ct=False)
+
+
+def make_output(dat, mat, lam):
+    return SimpleNamespace(dat=dat, dim=tuple(dat.shape), mat=mat, lam=lam, lam0=lam)
+
+
+# --------------------------------------------------------------------------
+# unires/_project.py:9-24
+# --------------------------------------------------------------------------
+def apply_scaling(dat, scl, dim):
+    """Even/odd slice scaling along ``dim``: even *= exp(scl), odd *= exp(-scl)."""
+    scl = torch.as_tensor(scl, dtype=dat.dtype)
+    out = torch.zeros_like(dat)
+    sl_e = [Ellipsis, slice(None), slice(None), slice(None)]
+    sl_o = [Ellipsis, slice(None), slice(None), slice(None)]
+    sl_e[1 + dim] = slice(0, None, 2)
+    sl_o[1 + dim] = slice(1, None, 2)
+    out[tuple(sl_e)] = torch.exp(scl) * dat[tuple(sl_e)]
+    out[tuple(sl_o)] = torch.exp(-scl) * dat[tuple(sl_o)]
+    return out
+
+
+# --------------------------------------------------------------------------
+# unires/_project.py:193-297
+# --------------------------------------------------------------------------
+def proj_info(dim_y, mat_y, dim_x, mat_x, rigid=None, prof_ip=0, prof_tp=0, gap=0.0,
+              scl=0.0, gauss_lim=None):
+    """Projection-operator descriptor (the ``samp>0`` branch, :245-264, is only
+    used by the rigid Gauss-Newton and is out of scope)."""
+    dt = torch.float64
+    po = SimpleNamespace()
+    mat_y = torch.as_tensor(mat_y, dtype=dt)
+    mat_x = torch.as_tensor(mat_x, dtype=dt)
+    dim_y_t = torch.tensor(tuple(dim_y), dtype=dt)
+    dim_x_t = torch.tensor(tuple(dim_x), dtype=dt)
+    po.mat_y, po.vx_y = mat_y, voxel_size(mat_y)              # :223-224
+    po.mat_x, po.vx_x = mat_x, voxel_size(mat_x)              # :229-230
+    ndim = 3
+    po.rigid = torch.eye(4, dtype=dt) if rigid is None else torch.as_tensor(rigid).to(dt)  # :234-237
+    gap_cn = torch.zeros(ndim, dtype=dt)                       # :239
+    profile = torch.tensor((prof_ip,) * ndim, dtype=dt)        # :240
+    dim_thick = int(torch.max(po.vx_x, dim=0)[1])              # :241
+    gap_cn[dim_thick] = gap                                    # :242
+    profile[dim_thick] = prof_tp                               # :243
+    po.dim_thick = dim_thick
+    ratio = torch.linalg.solve(mat_y, mat_x)                   # :266
+    ratio = (ratio[:ndim, :ndim] ** 2).sum(0).sqrt()           # :267
+    ratio = ratio.ceil().clamp(1)                              # :268
+    mat_yx = torch.cat((ratio, torch.ones(1, dtype=dt))).diag()  # :269
+    po.mat_yx = mat_x.matmul(mat_yx.inverse())                 # :270
+    dim_yx = (dim_x_t - 1) * ratio + 1                         # :271
+    profile[ratio == 1] = -1                                   # :273
+    profile = profile.int().tolist()                           # :274
+    fwhm = (1.0 - gap_cn) * ratio                              # :276
+    po.smo_ker = smooth(profile, fwhm.tolist(), sep=False, dtype=torch.float32,
+                        gauss_lim=gauss_lim)                   # :277
+    po.smo_ker_1d = smooth(profile, fwhm.tolist(), sep=True, dtype=torch.float32,
+                           gauss_lim=gauss_lim)
+    off = torch.tensor(po.smo_ker.shape[-ndim:], dtype=dt)     # :280
+    off = torch.div(-(off - 1), 2, rounding_mode='floor')      # :281
+    mat_off = torch.eye(ndim + 1, dtype=dt)                    # :282
+    mat_off[:ndim, -1] = off                                   # :283
+    dim_yx = dim_yx + 2 * torch.abs(off)                       # :284
+    po.mat_yx = torch.matmul(po.mat_yx, mat_off)               # :285
+    po.scl = torch.as_tensor(scl, dtype=torch.float32)         # :287-290
+    po.dim_y = tuple(dim_y_t.int().tolist())                   # :292
+    po.dim_yx = tuple(dim_yx.int().tolist())                   # :293
+    po.dim_x = tuple(dim_x_t.int().tolist())                   # :294
+    po.ratio = tuple(ratio.int().tolist())                     # :295
+    return po
+
+
+def proj_matrix(po, method):
+    """mat_y \\ (rigid @ mat_yx|mat_x), float64  (unires/_project.py:145-150)."""
+    if method == 'super-resolution':
+        return torch.linalg.solve(po.mat_y, po.rigid.mm(po.mat_yx)), po.dim_yx
+    if method == 'denoising':
+        return torch.linalg.solve(po.mat_y, po.rigid.mm(po.mat_x)), po.dim_x
+    raise ValueError('Undefined method')
+
+
+# --------------------------------------------------------------------------
+# unires/_project.py:99-190
+# --------------------------------------------------------------------------
+def proj_apply(operator, dat, po, method='super-resolution', bound='zero',
+               interpolation='linear'):
+    """A, At, AtA or 'none' on (1,1,X,Y,Z) data."""
+    if operator not in ['A', 'At', 'AtA', 'none']:
+        raise ValueError('Undefined operator')
+    if method not in ['denoising', 'super-resolution']:
+        raise ValueError('Undefined method')
+    if operator == 'none':
+        return dat
+    mat, dim = proj_matrix(po, method)
+    ratio, smo_ker, scl, dim_thick = po.ratio, po.smo_ker.to(dat.dtype), po.scl, po.dim_thick
+    conv = lambda x: F.conv3d(x, smo_ker, stride=ratio)                 # :153
+    conv_t = lambda x: F.conv_transpose3d(x, smo_ker, stride=ratio)     # :154
+    grid = affine_grid(mat.type(dat.dtype), dim)[None]                  # :159
+    kw = dict(bound=bound, extrapolate=False, interpolation=interpolation)
+    if method == 'super-resolution':
+        if operator == 'A':                                             # :163-167
+            dat = conv(grid_pull(dat, grid, **kw))
+            if scl != 0:
+                dat = apply_scaling(dat, scl, dim_thick)
+        elif operator == 'At':                                          # :168-172
+            if scl != 0:
+                dat = apply_scaling(dat, scl, dim_thick)
+            dat = grid_push(conv_t(dat), grid, shape=po.dim_y, **kw)
+        else:                                                           # :173-179
+            dat = conv(grid_pull(dat, grid, **kw))
+            if scl != 0:
+                dat = apply_scaling(dat, 2 * scl, dim_thick)
+            dat = grid_push(conv_t(dat), grid, shape=po.dim_y, **kw)
+    else:                                                               # :180-188
+        if operator == 'A':
+            dat = grid_pull(dat, grid, **kw)
+        elif operator == 'At':
+            dat = grid_push(dat, grid, shape=po.dim_y, **kw)
+        else:
+            dat = grid_push(grid_pull(dat, grid, **kw), grid, shape=po.dim_y, **kw)
+    return dat
+
+
+# --------------------------------------------------------------------------
+# unires/_project.py:300-317
+# --------------------------------------------------------------------------
+def DtD(dat, vx_y, bound='zero', diff='forward'):
+    return im_divergence(im_gradient(dat, vx=vx_y, bound=bound, which=diff),
+                         vx=vx_y, bound=bound, which=diff)
+
+
+# --------------------------------------------------------------------------
+# unires/_project.py:54-96
+# --------------------------------------------------------------------------
+def proj(operator, dat, x, y, method='super-resolution', do=True, rho=1, n=0, vx_y=None,
+         interpolation='linear', bound='zero', diff='forward'):
+    """x is the list of repeats of ONE channel; y the channel's output struct."""
+    if operator == 'AtA':
+        if not do:
+            operator = 'none'
+        dat = dat[None, None]
+        dat_p = x[n].tau * proj_apply(operator, dat, x[n].po, method, bound, interpolation)
+        for n1 in range(1, len(x)):
+            dat_p = dat_p + x[n1].tau * proj_apply(operator, dat, x[n1].po, method, bound,
+                                                   interpolation)
+        dat_p = dat_p[0, 0]
+        dat_p = dat_p + rho * y.lam ** 2 * DtD(dat[0, 0], vx_y=vx_y, bound=bound, diff=diff)
+    else:
+        if not do:
+            operator = 'none'
+        dat_p = proj_apply(operator, dat[None, None], x[n].po, method, bound, interpolation)[0, 0]
+    return dat_p
+
+
+# --------------------------------------------------------------------------
+# unires/_project.py:27-51
+# --------------------------------------------------------------------------
+def check_adjoint(po, method, dtype=torch.float64):
+    """<Ay,x> - <Atx,y> with seed-0 uniform inputs (returned, not printed)."""
+    torch.manual_seed(0)
+    x = torch.rand((1, 1) + tuple(po.dim_x), dtype=dtype)
+    y = torch.rand((1, 1) + tuple(po.dim_y), dtype=dtype)
+    Ay = proj_apply('A', y, po, method=method)
+    Atx = proj_apply('At', x, po, method=method)
+    return (torch.sum(Ay * x, dtype=torch.float64) - torch.sum(Atx * y, dtype=torch.float64)).item()
+
+
+# --------------------------------------------------------------------------
+# unires/_update.py:35-64
+# --------------------------------------------------------------------------
+def step_size(x, y, rho=None, rho_scl=1.0):
+    if rho is not None:
+        return torch.tensor(rho, dtype=torch.float32)
+    all_lam = torch.tensor([float(yc.lam) for yc in y], dtype=torch.float32)
+    all_tau = torch.tensor([float(xn.tau) for xc in x for xn in xc], dtype=torch.float32)
+    return rho_scl * torch.sqrt(torch.mean(all_tau)) / torch.mean(all_lam)
+
+
+# --------------------------------------------------------------------------
+# unires/_update.py:118-152  (the y-update block of _update_admm)
+# --------------------------------------------------------------------------
+def y_rhs(xc, yc, zc, wc, rho, vx_y, method, do_proj):
+    """b = sum_n tau_n At x_n - lam * Dt(w - rho z)   (:124-133)."""
+    tmp = torch.zeros_like(yc.dat)
+    for n in range(len(xc)):
+        tmp += xc[n].tau * proj('At', xc[n].dat, xc, yc, method=method, do=do_proj, n=n)
+    div = wc - rho * zc
+    div = im_divergence(div, vx=vx_y)
+    tmp -= yc.lam * div
+    return tmp
+
+
+def update_y(x, y, z, w, rho, method, do_proj, cgs_max_iter=20, cgs_tol=1e-3,
+             return_info=False):
+    """In-place CG update of every y[c].dat; identity preconditioner (:136-137),
+    stop='max_gain' (:145)."""
+    vx_y = voxel_size(y[0].mat).float()                                   # :111
+    info = []
+    for c in range(len(x)):
+        tmp = y_rhs(x[c], y[c], z[c], w[c], rho, vx_y, method, do_proj)
+        lhs = lambda dat, c=c: proj('AtA', dat, x[c], y[c], method=method, do=do_proj,
+                                    rho=rho, vx_y=vx_y)                   # :140-141
+        _, n_it, obj = cg(A=lhs, b=tmp, x=y[c].dat, max_iter=cgs_max_iter, stop='max_gain',
+                          inplace=True, precond=lambda r: r, tolerance=cgs_tol,
+                          return_info=True)                               # :142-148
+        info.append((n_it, obj))
+    return (y, info) if return_info else y
+
+
+# --------------------------------------------------------------------------
+# unires/_update.py:160-193  (z- and w-updates)
+# --------------------------------------------------------------------------
+def update_zw(y, z, w, rho, alpha=1.0):
+    vx_y = voxel_size(y[0].mat).float()
+    tiny = torch.tensor(1e-7, dtype=torch.float32)
+    one = torch.tensor(1.0, dtype=torch.float32)
+    rho = torch.as_tensor(rho, dtype=torch.float32)
+    z_old = z.clone() if alpha != 1 else None
+    C = len(y)
+
+    def _Dy(c):
+        Dy = y[c].lam * im_gradient(y[c].dat, vx=vx_y)
+        if alpha != 1:
+            Dy = alpha * Dy + (one - alpha) * z_old[c]
+        return Dy
+
+    tmp = torch.zeros_like(y[0].dat)
+    for c in range(C):
+        tmp += torch.sum((w[c] / rho + _Dy(c)) ** 2, dim=0)
+    tmp.sqrt_()
+    tmp = ((tmp - one / rho).clamp_min(0)) / (tmp + tiny)
+    for c in range(C):
+        Dy = _Dy(c)
+        for d in range(3):
+            z[c, d] = tmp * (w[c, d] / rho + Dy[d])
+    for c in range(C):
+        w[c] += rho * (_Dy(c) - z[c])
+    return z, w, tmp
+
+
+# --------------------------------------------------------------------------
+# unires/_update.py:396-427  (objective)
+# --------------------------------------------------------------------------
+def compute_nll(x, y, method, do_proj, sum_dtype=torch.float64):
+    vx_y = voxel_size(y[0].mat).float()
+    nll_xy = torch.tensor(0, dtype=torch.float64)
+    nll_y = None
+    for c in range(len(x)):
+        for n in range(len(x[c])):
+            msk = x[c][n].dat != 0
+            Ay = proj('A', y[c].dat, x[c], y[c], n=n, method=method, do=do_proj)
+            nll_xy = nll_xy + 0.5 * x[c][n].tau * torch.sum(
+                (x[c][n].dat[msk] - Ay[msk]) ** 2, dtype=sum_dtype)
+        Dy = y[c].lam * im_gradient(y[c].dat, vx=vx_y)
+        nll_y = torch.sum(Dy ** 2, dim=0) if nll_y is None else nll_y + torch.sum(Dy ** 2, dim=0)
+    nll_y = torch.sum(torch.sqrt(nll_y), dtype=sum_dtype)
+    return nll_xy + nll_y, nll_xy, nll_y
