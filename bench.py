@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""bench.py - the UniRes y-update hot path on N MI355X GPUs (one process per GPU).
+
+A "step" is one full y-update of one synthetic subject (BASELINE.json configs[2]:
+256^3, 3 channels, 6 mm thick slices along z, small random rigid per channel):
+for every channel assemble b = tau At x - lam Dt(w - rho z) and run 20 CG
+iterations of (tau AtA + rho lam^2 DtD) y = b in fixed-iteration mode
+(tolerance 0 - no early stop, so the work per step is constant).
+
+metric  = per-channel CG iterations per second, whole job (all ranks).
+roofline = the CG matvec (AtA + rho lam^2 DtD) for one channel, algorithmic
+           bytes B_mv = 4*(2 N_y + 2 N_x) / measured duration.
+cpu_baseline = the CPU oracle (torch-CPU restatement of the reference path)
+           timed on a bounded sample of the same workload on this box's cores.
+
+Multi-GPU: subjects are independent: rank g reconstructs its own
+subject, no data-path collective; RCCL is used for the start/end barrier and
+the max-over-ranks of the elapsed time only.  scaling = "weak".
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy
+
+WORKLOADS = {
+    # name: dim_y, channels, thick ratio, thick axis per channel
+    'cfg3_256c3_thick6z': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 2, 2)),
+    'cfg4_384c4_iso2': dict(dim_y=(384, 384, 384), C=4, thick=2, axes=None),
+    'small_96c3_thick3': dict(dim_y=(96, 96, 96), C=3, thick=3, axes=(2, 2, 2)),
+}
+
+
+def rigid_matrix(t, r):
+    cx, sx, cy, sy, cz, sz = (math.cos(r[0]), math.sin(r[0]), math.cos(r[1]), math.sin(r[1]),
+                              math.cos(r[2]), math.sin(r[2]))
+    Rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=torch.float64)
+    Ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=torch.float64)
+    Rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=torch.float64)
+    M = torch.eye(4, dtype=torch.float64)
+    M[:3, :3] = Rz @ Ry @ Rx
+    M[:3, 3] = torch.tensor(t, dtype=torch.float64)
+    return M
+
+
+def phantom(dim, gen, device):
+    """Sum of random ellipsoids on a zero background, built on device."""
+    ax = [torch.linspace(-1, 1, d, device=device) for d in dim]
+    X, Y, Z = torch.meshgrid(*ax, indexing='ij')
+    vol = torch.zeros(dim, device=device)
+    for _ in range(8):
+        c = (torch.rand(3, generator=gen) - 0.5).tolist()
+        r = (0.2 + 0.5 * torch.rand(3, generator=gen)).tolist()
+        a = float(torch.rand(1, generator=gen))
+        vol += a * (((X - c[0]) / r[0]) ** 2 + ((Y - c[1]) / r[1]) ** 2
+                    + ((Z - c[2]) / r[2]) ** 2 < 1).float()
+    return vol
+
+
+def build_subject(wl, device, seed):
+    """Synthetic subject: ground truth -> x = A y* + N(0, 75^2) via the HIP A
+    (the demos' recipe, demos/demo_multi_channel.ipynb:173,193-202); fixed
+    hyper-parameters tau = 1/75^2, lam = 4 sqrt(1/C)/mu_c, rho = sqrt(mean tau)/mean lam."""
+    import unires_amd as U
+    gen = torch.Generator().manual_seed(seed)
+    dim_y, C, thick = wl['dim_y'], wl['C'], wl['thick']
+    mat_y = torch.eye(4, dtype=torch.float64)
+    if wl['axes'] is None:  # config 4: 0.5 mm recon of 1 mm isotropic inputs
+        mat_y = torch.diag(torch.tensor([0.5, 0.5, 0.5, 1.0], dtype=torch.float64))
+    mus = (400.0, 2000.0, 4300.0, 1000.0)
+    sd = 75.0
+    x, y = [], []
+    for c in range(C):
+        truth = phantom(dim_y, gen, device) * mus[c]
+        scale = [1.0, 1.0, 1.0]
+        if wl['axes'] is None:
+            scale = [float(thick)] * 3
+        else:
+            scale[wl['axes'][c]] = float(thick)
+        mat_x = mat_y @ torch.diag(torch.tensor(scale + [1.0], dtype=torch.float64))
+        dim_x = tuple(int(math.floor(d / s)) for d, s in zip(dim_y, scale))
+        u = torch.rand(6, generator=gen) * 2 - 1
+        rigid = rigid_matrix((u[:3] * 5.0).tolist(), (u[3:] * 0.1).tolist())
+        po = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=0, prof_tp=0,
+                          device=device)
+        clean = U._proj_apply('A', truth[None, None], po)[0, 0]
+        noise = torch.randn(clean.shape, generator=gen).to(device) * sd
+        x.append([U._input(clean + noise, mat_x, 1.0 / sd ** 2, po)])
+        lam = 4.0 * math.sqrt(1.0 / C) / mus[c]
+        y.append(U._output(torch.zeros(dim_y, device=device), mat_y, lam))
+        del truth
+    sett = U.settings()
+    sett.device, sett.method, sett.do_proj = device, 'super-resolution', True
+    sett.cgs_max_iter, sett.cgs_tol = 20, 0.0  # fixed-iteration mode
+    rho = float(U._step_size(x, y, sett))
+    z, w = U._admm_aux(y, sett)
+    return x, y, z, w, rho, sett
+
+
+def alg_bytes_matvec(x_c, dim_y):
+    n_y = dim_y[0] * dim_y[1] * dim_y[2]
+    n_x = sum(xn.po.dim_x[0] * xn.po.dim_x[1] * xn.po.dim_x[2] for xn in x_c)
+    return 4 * (2 * n_y + 2 * n_x)
+
+
+def time_matvec(x, y, rho, sett, reps=50):
+    """Average duration of one channel's CG matvec, HIP events on the launch stream."""
+    from unires_amd._project import _channel_plan
+    plan = _channel_plan(x[0], y[0], sett.method, sett.do_proj)
+    p = torch.rand(y[0].dim, device=y[0].dat.device)
+    q = torch.empty_like(p)
+    for _ in range(5):
+        plan.matvec(p, rho, y[0].lam, out=q)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        plan.matvec(p, rho, y[0].lam, out=q)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def cpu_baseline(wl, seconds_budget=25.0):
+    """CPU oracle ("port" of the reference composition) on one channel of the same
+    workload: fixed-iteration CG, as many iterations as fit the budget (>= 1)."""
+    from oracle import nitorch_restated as N
+    from oracle import unires_restated as O
+    dim_y, thick = wl['dim_y'], wl['thick']
+    gen = torch.Generator().manual_seed(0)
+    mat_y = torch.eye(4, dtype=torch.float64)
+    scale = [1.0, 1.0, float(thick)] if wl['axes'] is not None else [float(thick)] * 3
+    if wl['axes'] is None:
+        mat_y = torch.diag(torch.tensor([0.5, 0.5, 0.5, 1.0], dtype=torch.float64))
+    mat_x = mat_y @ torch.diag(torch.tensor(scale + [1.0], dtype=torch.float64))
+    dim_x = tuple(int(math.floor(d / s)) for d, s in zip(dim_y, scale))
+    u = torch.rand(6, generator=gen) * 2 - 1
+    po = O.proj_info(dim_y, mat_y, dim_x, mat_x,
+                     rigid=rigid_matrix((u[:3] * 5.0).tolist(), (u[3:] * 0.1).tolist()))
+    xc = [O.make_input(torch.rand(dim_x, generator=gen) * 400, mat_x, torch.tensor(1 / 75.0 ** 2), po)]
+    yc = O.make_output(torch.zeros(dim_y), mat_y, torch.tensor(4.0 * math.sqrt(1 / 3.0) / 400.0))
+    vx = N.voxel_size(mat_y).float()
+    rho = torch.tensor(0.9)
+    lhs = lambda d: O.proj('AtA', d, xc, yc, method='super-resolution', rho=rho, vx_y=vx)
+    b = torch.rand(dim_y, generator=gen)
+    t0 = time.perf_counter()
+    lhs(b)  # one matvec to size the sample
+    t_mv = time.perf_counter() - t0
+    n_it = max(1, min(20, int(seconds_budget / max(t_mv, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    N.cg(lhs, b, yc.dat, max_iter=n_it, tolerance=0, stop='max_gain')
+    dt = time.perf_counter() - t0
+    # cg(tolerance=0) does n_it + 1 matvecs for n_it iterations; report iterations/s
+    return dict(value=n_it / dt, unit='cg_iters/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d CG iterations (tol=0) of one %dx%dx%d channel, oracle/unires_restated '
+                       '(torch-CPU, unfused as the reference composes it); matvec %.2f s'
+                       % (n_it, dim_y[0], dim_y[1], dim_y[2], t_mv))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='cfg3_256c3_thick6z', choices=list(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=25.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if dist:
+        import torch.distributed as td
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        td.init_process_group('nccl', device_id=device)
+
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build()
+    if dist:
+        td.barrier()
+    import unires_amd as U
+
+    wl = WORKLOADS[args.workload]
+    x, y, z, w, rho, sett = build_subject(wl, device, seed=1234 + rank)
+    tmp = torch.zeros_like(y[0].dat)
+
+    def step():
+        for yc in y:  # same start every step -> identical work
+            yc.dat.zero_()
+        U._update_admm(x, y, z, w, rho, tmp, None, 0, sett)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    C = wl['C']
+    iters_per_step = C * sett.cgs_max_iter
+    total_iters = world * args.steps * iters_per_step
+    out = None
+    if rank == 0:
+        t_mv = time_matvec(x, y, rho, sett)
+        b_mv = alg_bytes_matvec(x[0], wl['dim_y'])
+        achieved = b_mv / t_mv / 1e9
+        out = {
+            'metric': 'cg_iters_per_sec', 'value': total_iters / elapsed, 'unit': 'cg_iters/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'dim_y': list(wl['dim_y']), 'channels': C,
+                       'thick_ratio': wl['thick'], 'cg_iters_per_channel': sett.cgs_max_iter,
+                       'cg_mode': 'fixed-iteration (tol=0), identity preconditioner',
+                       'step': 'one y-update of one subject: C x (RHS + 20 CG iterations)',
+                       'parallelism': 'one subject per GPU, no data-path collective'},
+            'subjects_per_sec': world * args.steps / elapsed / 50.0,
+            'subjects_per_sec_note': 'y-update only, subject = 50 ADMM iterations x C x 20 CG',
+            'roofline': {'bound': 'hbm', 'kernel': 'ata_matvec (one channel)',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'alg_bytes_per_launch': b_mv, 'us_per_launch': t_mv * 1e6},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(wl, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

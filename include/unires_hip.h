@@ -1,0 +1,176 @@
+/*
+ * unires_hip.h - C ABI of libunires_hip.so: the MI355X (gfx950) implementation of
+ * the UniRes ADMM y-update hot path.
+ *
+ * All volumes are float32, C-contiguous (X,Y,Z) with Z fastest, resident in
+ * device memory; all `dim`/`M`/`taps`/descriptor arguments are HOST pointers
+ * read during the call (never retained).  Every entry point returns an int
+ * status (0 = OK) and never throws; unires_last_error() gives the message of
+ * the calling thread's last failure.  Kernels are launched on the caller's
+ * stream (`stream` is a hipStream_t passed as void*; NULL = default stream).
+ * No entry point synchronises, except unires_cg_solve when the caller asks for
+ * the realised iteration count / objective trace on the host.
+ *
+ * The reference (brudfors/UniRes) has no FFI layer: its seam is Python calls
+ * into nitorch + torch.  Each entry point below cites the
+ * reference call it replaces (paths relative to the reference tree).
+ */
+#ifndef UNIRES_HIP_H
+#define UNIRES_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNIRES_HIP_ABI_VERSION 1
+#define UNIRES_MAX_TAPS 32 /* per axis */
+
+enum unires_status {
+  UNIRES_OK = 0,
+  UNIRES_ERR_NULL = 1,        /* null pointer argument                         */
+  UNIRES_ERR_DIM = 2,         /* inconsistent / non-positive dimensions        */
+  UNIRES_ERR_ARG = 3,         /* bad enum / value ("Undefined operator" ...)   */
+  UNIRES_ERR_HIP = 4,         /* HIP runtime error (message has hipGetErrorString) */
+  UNIRES_ERR_ALLOC = 5,       /* device allocation failed                      */
+  UNIRES_ERR_UNSUPPORTED = 6  /* valid request this build cannot serve         */
+};
+
+/* unires/_project.py:122-126: 'A' | 'At' | 'AtA' ('none' is regime 0) */
+enum unires_operator { UNIRES_OP_A = 0, UNIRES_OP_AT = 1, UNIRES_OP_ATA = 2 };
+
+/* unires/_core.py:209-260 selects one of three operator regimes */
+enum unires_regime {
+  UNIRES_REGIME_IDENTITY = 0, /* sett.do_proj == False: A = I   (_project.py:76-77,91-92) */
+  UNIRES_REGIME_DENOISE = 1,  /* method 'denoising': A = pull   (_project.py:180-188)     */
+  UNIRES_REGIME_SUPERRES = 2  /* method 'super-resolution': A = S conv_down pull (:161-179) */
+};
+
+/* nitorch cg(stop=...) objective branch */
+enum unires_cg_stop {
+  UNIRES_STOP_RESIDUAL = 0,       /* 'e': obj = sqrt(r.z)                                  */
+  UNIRES_STOP_MAXGAIN = 1,        /* anything else, e.g. 'max_gain' as UniRes passes
+                                     (_update.py:145): obj = 0.5*sum(x*(A(x)-2b)),
+                                     one extra A(x) per iteration (reference-faithful)     */
+  UNIRES_STOP_MAXGAIN_RECURRED = 2 /* same objective from the recurred residual,
+                                     obj = -0.5*sum(x*(b+r)): no extra A(x) (build-side)   */
+};
+
+enum unires_precond {
+  UNIRES_PRECOND_IDENTITY = 0 /* the reference's only live mode (_update.py:136-137) */
+};
+
+const char *unires_last_error(void);
+int unires_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Op level - one call per nitorch / torch function on the path
+ * ---------------------------------------------------------------------- */
+
+/* nitorch grid_pull(src, affine_grid(M, gdim), 'linear', bound='zero',
+ * extrapolate=False)  (_project.py:159,164,174,183,187).  M is the row-major
+ * 3x4 float32 affine mapping a grid voxel (i,j,k) to src voxel coordinates.
+ * dst[gdim] is overwritten. fov_tol = nitorch's in-FOV tolerance (5e-2). */
+int unires_pull3d_affine(const float *src, const int32_t sdim[3], const float M[12], float *dst,
+                         const int32_t gdim[3], float fov_tol, void *stream);
+
+/* nitorch grid_push(src, affine_grid(M, gdim), shape=ddim, ...)
+ * (_project.py:172,179,185,188): dst (+)= alpha * push(src).
+ * accumulate == 0 overwrites dst. */
+int unires_push3d_affine(const float *src, const int32_t gdim[3], const float M[12], float *dst,
+                         const int32_t ddim[3], float alpha, float fov_tol, int accumulate,
+                         void *stream);
+
+/* F.conv3d(src, smo_ker, stride)  (_project.py:153) with a separable kernel
+ * smo_ker = taps[0] (x) taps[1] (x) taps[2] (cross-correlation, no padding), followed
+ * by the optional even/odd slice scaling of _apply_scaling (_project.py:9-24):
+ * slices with even index along scl_dim are multiplied by exp(scl), odd by
+ * exp(-scl); scl == 0 skips it.  Requires sdim = (ddim-1)*stride + ntaps. */
+int unires_conv_down3d(const float *src, const int32_t sdim[3], const float *const taps[3],
+                       const int32_t ntaps[3], const int32_t stride[3], float *dst,
+                       const int32_t ddim[3], float scl, int32_t scl_dim, void *stream);
+
+/* F.conv_transpose3d(S(scl) src, smo_ker, stride)  (_project.py:154,168-171): exact
+ * adjoint of unires_conv_down3d, scaling applied to the INPUT.  src has sdim
+ * (low-res), dst has ddim = (sdim-1)*stride + ntaps and is overwritten. */
+int unires_conv_up3d(const float *src, const int32_t sdim[3], const float *const taps[3],
+                     const int32_t ntaps[3], const int32_t stride[3], float *dst,
+                     const int32_t ddim[3], float scl, int32_t scl_dim, void *stream);
+
+/* nitorch im_gradient(src, vx, bound='zero', which='forward')
+ * (_project.py:314; _update.py:168,176,188,419): dst is (3,X,Y,Z). */
+int unires_grad_fwd_zero(const float *src, const int32_t dim[3], const float vx[3], float *dst3,
+                         void *stream);
+
+/* nitorch im_divergence(src3, vx, bound='zero', which='forward') - the POSITIVE
+ * adjoint of the gradient (_project.py:315; _update.py:132). */
+int unires_div_fwd_zero(const float *src3, const int32_t dim[3], const float vx[3], float *dst,
+                        void *stream);
+
+/* dst = a*src + c*DtD(src): _DtD (_project.py:300-317) fused with the scalar
+ * multiply-add of _proj (_project.py:87). */
+int unires_dtd(const float *src, const int32_t dim[3], const float vx[3], float a, float c,
+               float *dst, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Fused level - plan + matvec + RHS + CG  (unires/_update.py:118-152)
+ * ---------------------------------------------------------------------- */
+
+/* One observation ("repeat") of a channel: the fields of _proj_op
+ * (struct.py:36-54) that the operators read, flattened. */
+typedef struct unires_repeat {
+  int32_t dim_x[3];  /* observed image dims                                             */
+  int32_t dim_g[3];  /* grid dims: dim_yx (super-resolution) or dim_x (denoising)       */
+  float M[12];       /* float32(mat_y \ (rigid*mat_yx|mat_x)), row-major 3x4 (:147,150,159) */
+  int32_t ratio[3];  /* conv stride (:153)                                              */
+  int32_t ntaps[3];  /* separable factors of smo_ker (:277)                             */
+  const float *taps[3]; /* HOST pointers, ntaps[d] floats each                          */
+  float scl;         /* even/odd slice scaling parameter po.scl (:287-290); 0 = off     */
+  int32_t dim_thick; /* axis the scaling runs along (:241)                              */
+  float tau;         /* noise precision x[c][n].tau (_core.py:134-136)                  */
+} unires_repeat_t;
+
+typedef struct unires_plan unires_plan_t;
+
+/* Builds the per-channel operator  sum_n tau_n A_n^T A_n + rho lam^2 D^T D  and
+ * allocates every workspace it will ever need (r, p, Ap, one grid-space and one
+ * x-space intermediate, reduction partials).  Nothing is allocated afterwards. */
+int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3], const float vx_y[3],
+                       int32_t regime, int32_t n_repeats, const unires_repeat_t *repeats,
+                       float fov_tol);
+int unires_plan_destroy(unires_plan_t *plan);
+/* Replace repeat n's descriptor (after a rigid / scaling update; _update.py:576). */
+int unires_plan_set_repeat(unires_plan_t *plan, int32_t n, const unires_repeat_t *repeat);
+/* Bytes of device workspace the plan owns. */
+int64_t unires_plan_workspace_bytes(const unires_plan_t *plan);
+
+/* _proj_apply(operator, ., po_n)  (_project.py:99-190) for repeat n, WITHOUT tau.
+ * in/out sizes follow the operator (A: dim_y -> dim_x; At: dim_x -> dim_y; AtA: dim_y -> dim_y). */
+int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, const float *in, float *out,
+                      void *stream);
+
+/* q = sum_n tau_n AtA_n p + rho*lam^2 DtD p   (_proj('AtA'), _project.py:73-87).
+ * If dot_dev != NULL the float64 sum(p*q) is written there (device pointer). */
+int unires_ata_matvec(unires_plan_t *plan, float rho, float lam, const float *p, float *q,
+                      double *dot_dev, void *stream);
+
+/* b = sum_n tau_n At_n x_n - lam * Dt(w_c - rho z_c)   (_update.py:124-133).
+ * x_ptrs: HOST array of n_repeats device pointers; w_c,z_c: (3,X,Y,Z) device. */
+int unires_rhs_assemble(unires_plan_t *plan, const float *const *x_ptrs, const float *w_c,
+                        const float *z_c, float rho, float lam, float *b, void *stream);
+
+/* nitorch cg(A=lhs, b, x, precond=identity, max_iter, tolerance, stop,
+ * inplace=True, sum_dtype=float64)  (_update.py:142-148): x is updated in place.
+ * tol == 0 runs exactly max_iter iterations with no objective evaluation.
+ * If iters_out != NULL the call synchronises the stream and returns the realised
+ * iteration count; obj_trace (HOST, max_iter+1 doubles, may be NULL) then
+ * receives the objective values obj[0..iters]. */
+int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const float *b, float *x,
+                    int32_t max_iter, double tol, int32_t stop_mode, int32_t precond_mode,
+                    int32_t *iters_out, double *obj_trace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIRES_HIP_H */

@@ -1,0 +1,150 @@
+"""Shared test scaffolding: seeded synthetic y-update problems, built once and
+fed to both the CPU oracle (oracle/) and the HIP path (unires_amd/)."""
+import math
+
+import torch
+
+from oracle import unires_restated as O
+
+
+def rigid_matrix(t, r):
+    """4x4 float64 rigid: translation t (mm), rotations r (rad) about x, y, z."""
+    cx, sx = math.cos(r[0]), math.sin(r[0])
+    cy, sy = math.cos(r[1]), math.sin(r[1])
+    cz, sz = math.cos(r[2]), math.sin(r[2])
+    Rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=torch.float64)
+    Ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=torch.float64)
+    Rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=torch.float64)
+    M = torch.eye(4, dtype=torch.float64)
+    M[:3, :3] = Rz @ Ry @ Rx
+    M[:3, 3] = torch.tensor(t, dtype=torch.float64)
+    return M
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def smooth_volume(dim, gen, scale):
+    """Smooth random phantom: low-pass filtered noise, non-negative."""
+    v = torch.rand(dim, generator=gen)
+    k = torch.ones(1, 1, 3, 3, 3) / 27.0
+    v = torch.nn.functional.conv3d(v[None, None], k, padding=1)[0, 0]
+    return (v * scale).float()
+
+
+def make_problem(dim_y=(16, 14, 12), n_channels=1, thick=3, seed=0, scl=0.0, regime='sr',
+                 n_repeats=1, vx_y=1.0, rot=0.05, trans=0.7, noise_sd=20.0, prof_tp=0,
+                 prof_ip=0, thick_axes=None, aniso=None):
+    """A synthetic multi-channel y-update problem.
+
+    regime 'sr': thick-slice observations (ratio ``thick`` along a per-channel axis),
+    'dn': same-resolution observations with a rigid misalignment (pull/push only),
+    'id': do_proj False (A = I).
+    """
+    gen = torch.Generator().manual_seed(seed)
+    mat_y = torch.diag(torch.tensor([vx_y, vx_y, vx_y, 1.0], dtype=torch.float64))
+    if aniso is not None:
+        mat_y = torch.diag(torch.tensor(list(aniso) + [1.0], dtype=torch.float64))
+    C = n_channels
+    truth = [smooth_volume(dim_y, gen, 400.0 * (c + 1)) for c in range(C)]
+    chans = []
+    for c in range(C):
+        reps = []
+        for n in range(n_repeats):
+            u = torch.rand(6, generator=gen) * 2 - 1
+            rigid = rigid_matrix((u[:3] * trans).tolist(), (u[3:] * rot).tolist())
+            if regime == 'sr':
+                ax = (thick_axes[c] if thick_axes is not None else (2 - c - n) % 3)
+                scale = [1.0, 1.0, 1.0]
+                scale[ax] = float(thick)
+                D = torch.diag(torch.tensor(scale + [1.0], dtype=torch.float64))
+                mat_x = mat_y @ D
+                dim_x = tuple(int(math.floor(d / s)) for d, s in zip(dim_y, scale))
+                po = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=prof_ip,
+                                 prof_tp=prof_tp, scl=scl)
+                method = 'super-resolution'
+            elif regime == 'dn':
+                mat_x, dim_x = mat_y.clone(), tuple(dim_y)
+                po = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid)
+                method = 'denoising'
+            else:
+                mat_x, dim_x, rigid = mat_y.clone(), tuple(dim_y), torch.eye(4, dtype=torch.float64)
+                po = O.proj_info(dim_y, mat_y, dim_x, mat_x)
+                method = 'denoising'
+            do_proj = regime != 'id'
+            clean = O.proj_apply('A' if do_proj else 'none', truth[c][None, None], po,
+                                 method=method)[0, 0]
+            dat = clean + noise_sd * torch.randn(clean.shape, generator=gen)
+            reps.append(dict(dim_x=dim_x, mat_x=mat_x, rigid=rigid, scl=scl if regime == 'sr' else 0.0,
+                             tau=1.0 / (noise_sd * (1.0 + 0.3 * n)) ** 2, dat=dat.float(),
+                             prof_ip=prof_ip, prof_tp=prof_tp))
+        mu = float(truth[c].mean())
+        chans.append(dict(reps=reps, lam=4.0 * math.sqrt(1.0 / C) / mu))
+    all_tau = torch.tensor([r['tau'] for ch in chans for r in ch['reps']], dtype=torch.float32)
+    all_lam = torch.tensor([ch['lam'] for ch in chans], dtype=torch.float32)
+    rho = float(torch.sqrt(all_tau.mean()) / all_lam.mean())
+    y0 = [(truth[c] * 0.8 + 20.0 * torch.rand(dim_y, generator=gen)).float() for c in range(C)]
+    z = 0.05 * torch.randn((C, 3) + tuple(dim_y), generator=gen)
+    w = 0.05 * torch.randn((C, 3) + tuple(dim_y), generator=gen)
+    return dict(dim_y=tuple(dim_y), mat_y=mat_y, chans=chans, rho=rho, y0=y0, z=z.float(),
+                w=w.float(), method=method, do_proj=do_proj, truth=truth)
+
+
+# ---------------------------------------------------------------------------
+# oracle side
+# ---------------------------------------------------------------------------
+def oracle_structs(prob):
+    x, y = [], []
+    for c, ch in enumerate(prob['chans']):
+        xc = []
+        for r in ch['reps']:
+            po = O.proj_info(prob['dim_y'], prob['mat_y'], r['dim_x'], r['mat_x'], rigid=r['rigid'],
+                             prof_ip=r['prof_ip'], prof_tp=r['prof_tp'], scl=r['scl'])
+            xc.append(O.make_input(r['dat'].clone(), r['mat_x'], torch.tensor(r['tau']), po))
+        x.append(xc)
+        y.append(O.make_output(prob['y0'][c].clone(), prob['mat_y'], torch.tensor(ch['lam'])))
+    return x, y
+
+
+def run_oracle_update_y(prob, max_iter=20, tol=1e-3):
+    x, y = oracle_structs(prob)
+    rho = torch.tensor(prob['rho'])
+    y, info = O.update_y(x, y, prob['z'].clone(), prob['w'].clone(), rho, prob['method'],
+                         prob['do_proj'], cgs_max_iter=max_iter, cgs_tol=tol, return_info=True)
+    return [yc.dat for yc in y], info
+
+
+# ---------------------------------------------------------------------------
+# HIP side
+# ---------------------------------------------------------------------------
+def gpu_structs(prob, device):
+    import unires_amd as U
+    x, y = [], []
+    for c, ch in enumerate(prob['chans']):
+        xc = []
+        for r in ch['reps']:
+            po = U._proj_info(prob['dim_y'], prob['mat_y'], r['dim_x'], r['mat_x'],
+                              rigid=r['rigid'], prof_ip=r['prof_ip'], prof_tp=r['prof_tp'],
+                              scl=r['scl'], device=device)
+            xc.append(U._input(r['dat'].to(device), r['mat_x'], r['tau'], po))
+        x.append(xc)
+        y.append(U._output(prob['y0'][c].clone().to(device), prob['mat_y'], ch['lam']))
+    sett = U.settings()
+    sett.device = device
+    sett.method = prob['method']
+    sett.do_proj = prob['do_proj']
+    return x, y, sett
+
+
+def run_gpu_update_y(prob, device='cuda:0', max_iter=20, tol=1e-3, stop='max_gain'):
+    import unires_amd as U
+    x, y, sett = gpu_structs(prob, device)
+    sett.cgs_max_iter, sett.cgs_tol, sett.cgs_stop = max_iter, tol, stop
+    z, w = prob['z'].to(device), prob['w'].to(device)
+    tmp = torch.zeros_like(y[0].dat)
+    info = []
+    U._update_admm(x, y, z, w, prob['rho'], tmp, None, 0, sett, info=info)
+    torch.cuda.synchronize()
+    return [yc.dat for yc in y], info

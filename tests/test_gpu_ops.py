@@ -1,0 +1,145 @@
+"""GPU parity of every op-level entry point of the C ABI against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import nitorch_restated as N
+from oracle import unires_restated as O
+from tests.helpers import rel_err, rigid_matrix
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # float32 op-level agreement (relative L2); the path-level gate is 1e-4
+
+
+def _affines():
+    eye = torch.eye(4, dtype=torch.float64)
+    shift = eye.clone()
+    shift[:3, 3] = torch.tensor([1.0, -2.0, 3.0])
+    scale = torch.diag(torch.tensor([1.0, 1.0, 3.0, 1.0], dtype=torch.float64))
+    scale[2, 3] = -1.0
+    return {'identity': eye, 'int_shift': shift, 'thick': scale,
+            'small_rigid': rigid_matrix([0.4, -0.3, 0.2], [0.03, -0.02, 0.05]),
+            'big_rigid': rigid_matrix([3.0, -4.0, 2.5], [0.4, -0.3, 0.6]),
+            'far_outside': rigid_matrix([100.0, 0, 0], [0, 0, 0])}
+
+
+@pytest.mark.parametrize('name', list(_affines()))
+@pytest.mark.parametrize('sdim,gdim', [((12, 10, 9), (11, 12, 10)), ((5, 70, 131), (6, 66, 140)),
+                                        ((1, 1, 1), (2, 3, 4))])
+def test_pull_and_push(dev, name, sdim, gdim):
+    from unires_amd import spatial
+    torch.manual_seed(0)
+    M = _affines()[name]
+    src = torch.rand((1, 1) + sdim)
+    g = N.affine_grid(M.float(), gdim)[None]
+    ref = N.grid_pull(src, g)
+    out = spatial.grid_pull(src.to(dev), M, gdim).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
+    val = torch.rand((1, 1) + gdim)
+    refp = N.grid_push(val, g, sdim)
+    outp = spatial.grid_push(val.to(dev), M, sdim).cpu()
+    assert outp.shape == refp.shape
+    assert (outp - refp).abs().max() <= 2e-5 * max(1.0, refp.abs().max().item())
+
+
+def test_push_accumulates_with_alpha(dev):
+    from unires_amd import _ops, spatial
+    torch.manual_seed(1)
+    M = _affines()['small_rigid']
+    val = torch.rand(9, 8, 7)
+    base = torch.rand(10, 9, 8)
+    ref = base + 0.37 * N.grid_push(val[None, None], N.affine_grid(M.float(), (9, 8, 7))[None],
+                                    (10, 9, 8))[0, 0]
+    out = base.to(dev)
+    _ops.push_affine(val.to(dev), spatial._m12(M), (10, 9, 8), alpha=0.37, out=out)
+    assert rel_err(out.cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize('stride,kinds,w', [((1, 1, 3), (-1, -1, 0), 3.0), ((4, 1, 1), (0, -1, -1), 4.0),
+                                             ((1, 6, 1), (-1, 0, -1), 6.0), ((2, 2, 2), (0, 2, 2), 2.0),
+                                             ((1, 1, 1), (-1, -1, -1), 1.0), ((2, 1, 3), (1, -1, 0), 2.5)])
+@pytest.mark.parametrize('scl', [0.0, 0.1])
+def test_conv_down_up_match_torch(dev, stride, kinds, w, scl):
+    from unires_amd import _ops
+    torch.manual_seed(2)
+    taps = [np.array(N.smooth1d(k, w * (s if k != -1 else 1) / max(stride)), dtype=np.float32)
+            for k, s in zip(kinds, stride)]
+    lo = (5, 6, 7)
+    hi = tuple((l - 1) * s + len(t) for l, s, t in zip(lo, stride, taps))
+    ker = torch.from_numpy(taps[0][:, None, None] * taps[1][None, :, None] * taps[2][None, None, :])
+    ker = ker[None, None]
+    dim_thick = int(np.argmax(stride))
+    src = torch.rand((1, 1) + hi)
+    ref = F.conv3d(src, ker, stride=stride)
+    if scl:
+        ref = O.apply_scaling(ref, scl, dim_thick)
+    out = _ops.conv_down(src.to(dev), taps, stride, scl, dim_thick).cpu()
+    assert out.shape == ref.shape and rel_err(out, ref) < TOL
+    low = torch.rand((1, 1) + lo)
+    ref = F.conv_transpose3d(O.apply_scaling(low, scl, dim_thick) if scl else low, ker, stride=stride)
+    out = _ops.conv_up(low.to(dev), taps, stride, scl, dim_thick).cpu()
+    assert out.shape == ref.shape and rel_err(out, ref) < TOL
+
+
+def test_conv_dim_mismatch_is_an_error(dev):
+    from unires_amd import _ops
+    with pytest.raises(ValueError):
+        _ops.conv_down(torch.zeros(10, 10, 10, device=dev), [np.ones(1, np.float32)] * 2 + [np.ones(3, np.float32) / 3],
+                       (1, 1, 3))
+
+
+@pytest.mark.parametrize('dim', [(9, 8, 7), (3, 65, 129), (1, 1, 5), (2, 1, 1)])
+@pytest.mark.parametrize('vx', [(1.0, 1.0, 1.0), (0.8, 1.25, 2.0)])
+def test_gradient_divergence_dtd(dev, dim, vx):
+    from unires_amd import _ops, spatial
+    import unires_amd as U
+    torch.manual_seed(3)
+    y = torch.rand(dim) * 100
+    g = torch.rand((3,) + dim) * 100
+    vxt = torch.tensor(vx)
+    a = spatial.im_gradient(y.to(dev), vxt).cpu()
+    assert rel_err(a, N.im_gradient(y, vxt)) < TOL
+    a = spatial.im_divergence(g.to(dev), vxt).cpu()
+    assert rel_err(a, N.im_divergence(g, vxt)) < TOL
+    a = U._DtD(y.to(dev), vxt).cpu()
+    assert rel_err(a, O.DtD(y, vxt)) < TOL
+    a = _ops.dtd(y.to(dev), vxt, a=0.7, c=0.3).cpu()
+    assert rel_err(a, 0.7 * y + 0.3 * O.DtD(y, vxt)) < TOL
+
+
+def test_apply_scaling(dev):
+    import unires_amd as U
+    torch.manual_seed(4)
+    dat = torch.rand(1, 1, 6, 7, 9)
+    for dim in (0, 1, 2):
+        ref = O.apply_scaling(dat, torch.tensor(0.2), dim)
+        out = U._apply_scaling(dat.to(dev), torch.tensor(0.2), dim).cpu()
+        assert rel_err(out, ref) < 1e-6
+
+
+def test_abi_status_codes(dev, lib):
+    """Errors come back as status codes + message, never as a crash."""
+    import ctypes as C
+    from unires_amd import _lib
+    t = torch.zeros(4, 4, 4, device=dev)
+    bad = _lib.i3((0, 4, 4))
+    ok = _lib.i3((4, 4, 4))
+    M = _lib.f12([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0])
+    p = C.c_void_p(t.data_ptr())
+    assert lib.unires_pull3d_affine(None, ok, M, p, ok, 0.05, None) == 1
+    assert lib.unires_pull3d_affine(p, bad, M, p, ok, 0.05, None) == 2
+    assert b'dimension' in lib.unires_last_error()
+    assert lib.unires_dtd(p, ok, _lib.f3((1, 1, 0)), 0.0, 1.0, p, None) == 3
+    h = C.c_void_p()
+    r = (_lib.Repeat * 1)()
+    r[0].tau = 1.0
+    assert lib.unires_plan_create(C.byref(h), ok, _lib.f3((1, 1, 1)), 7, 1, r, 0.05) == 3
+    assert b'Undefined method' in lib.unires_last_error()
+    assert lib.unires_plan_create(C.byref(h), ok, _lib.f3((1, 1, 1)), 0, 1, r, 0.05) == 0
+    assert lib.unires_proj_apply(h, 0, 9, p, p, None) == 3
+    assert b'Undefined operator' in lib.unires_last_error()
+    assert lib.unires_cg_solve(h, 1.0, 1.0, p, p, 5, 0.0, 1, 0, None, None, None) == 3
+    assert lib.unires_plan_destroy(h) == 0

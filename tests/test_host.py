@@ -1,0 +1,120 @@
+"""CPU-only checks of the host logic and of the C-ABI surface (no compute
+calls: there is no GPU in the build container)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nitorch_restated as N
+from oracle import unires_restated as O
+from tests.helpers import rigid_matrix
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'unires_hip.h')).read()
+    declared = set(re.findall(r'\b(unires_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 17
+    from unires_amd import _lib
+    assert declared == set(_lib.SIGNATURES), 'ctypes table and header disagree'
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r' T (unires_[a-z0-9_]+)', out))
+    assert declared <= exported
+    assert lib.unires_abi_version() == 1
+
+
+def test_library_has_gfx950_code_object(lib):
+    from unires_amd import _lib
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    assert b'gfx950' in blob
+
+
+def test_missing_library_fails_loudly(monkeypatch, lib):
+    from unires_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libunires_hip.so')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        _lib.load()
+
+
+def test_cpu_tensors_are_rejected(lib):
+    import unires_amd as U
+    from unires_amd import spatial
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        U._DtD(torch.zeros(4, 4, 4), (1, 1, 1))
+    with pytest.raises(RuntimeError):
+        spatial.im_gradient(torch.zeros(4, 4, 4))
+
+
+def test_undefined_operator_and_method_raise_like_the_reference(lib):
+    import unires_amd as U
+    eye = torch.eye(4, dtype=torch.float64)
+    po = U._proj_info((8, 8, 8), eye, (8, 8, 4), eye @ torch.diag(torch.tensor([1, 1, 2, 1.], dtype=torch.float64)),
+                      device='cpu')
+    dat = torch.zeros(1, 1, 8, 8, 8)
+    with pytest.raises(ValueError, match='Undefined operator'):
+        U._proj_apply('B', dat, po)
+    with pytest.raises(ValueError, match='Undefined method'):
+        U._proj_apply('A', dat, po, method='sharpening')
+    assert U._proj_apply('none', dat, po) is dat
+
+
+@pytest.mark.parametrize('kind,w', [(-1, 1), (0, 2), (0, 3), (0, 4), (0, 6), (0, 2.5), (1, 2), (1, 3.5),
+                                    (2, 2), (2, 3)])
+def test_profile_closed_forms_match_oracle_quadrature(kind, w):
+    from unires_amd import _kernels
+    a = _kernels.smooth1d(kind, w)
+    b = np.array(N.smooth1d(kind, w))
+    assert a.shape == b.shape and np.abs(a - b).max() < 1e-12
+
+
+def test_factorise_roundtrip_and_rejects_non_separable():
+    from unires_amd import _kernels
+    k = [np.array(N.smooth1d(0, 3.0)), np.array(N.smooth1d(2, 2.0)), np.array(N.smooth1d(1, 2.0))]
+    dense = k[0][:, None, None] * k[1][None, :, None] * k[2][None, None, :]
+    f = _kernels.factorise(dense[None, None])
+    rec = f[0][:, None, None] * f[1][None, :, None] * f[2][None, None, :]
+    assert np.abs(rec - dense).max() < 1e-7
+    bad = dense.copy()
+    bad[0, 0, 0] += 0.1
+    with pytest.raises(NotImplementedError):
+        _kernels.factorise(bad)
+
+
+@pytest.mark.parametrize('scale,dim_x', [((1, 1, 4), (181, 217, 45)), ((4, 1, 1), (45, 217, 181)),
+                                         ((1, 3, 1), (20, 7, 20)), ((2, 2, 2), (10, 10, 10))])
+def test_proj_info_matches_oracle(scale, dim_x, lib):
+    import unires_amd as U
+    dim_y = tuple(int(d * s) if d < 100 else d for d, s in zip(dim_x, scale))
+    dim_y = (181, 217, 181) if dim_x[0] in (181, 45) else dim_y
+    mat_y = torch.diag(torch.tensor([0.9, 0.9, 0.9, 1.0], dtype=torch.float64))
+    mat_x = mat_y @ torch.diag(torch.tensor(list(scale) + [1.0], dtype=torch.float64))
+    rigid = rigid_matrix([1.0, -2.0, 0.5], [0.02, 0.03, -0.01])
+    a = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=2, prof_tp=0, scl=0.1,
+                     device='cpu')
+    b = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=2, prof_tp=0, scl=0.1)
+    assert a.dim_yx == b.dim_yx and a.ratio == b.ratio and a.dim_thick == b.dim_thick
+    assert a.dim_x == b.dim_x and a.dim_y == b.dim_y
+    assert torch.allclose(a.mat_yx, b.mat_yx, atol=1e-12)
+    assert torch.allclose(a.smo_ker.cpu(), b.smo_ker, atol=1e-7)
+    from unires_amd._plan import proj_matrix
+    for method in ('super-resolution', 'denoising'):
+        ma, da = proj_matrix(a, method)
+        mb, db = O.proj_matrix(b, method)
+        assert da == tuple(db) and torch.allclose(ma, mb, atol=1e-12)
+
+
+def test_step_size_matches_oracle(lib):
+    import unires_amd as U
+    x = [[U._input(None, None, 4.2e-4)], [U._input(None, None, 2.5e-4), U._input(None, None, 1.6e-4)]]
+    y = [U._output(None, None, 0.0057), U._output(None, None, 0.0012)]
+    s = U.settings()
+    a = U._step_size(x, y, s)
+    ox = [[O.make_input(torch.zeros(1, 1, 1), None, xn.tau) for xn in xc] for xc in x]
+    oy = [O.make_output(torch.zeros(1, 1, 1), None, yc.lam) for yc in y]
+    b = O.step_size(ox, oy)
+    assert abs(float(a) - float(b)) < 1e-6 * float(b)

@@ -1,0 +1,14 @@
+"""unires_amd - MI355X-native (gfx950) implementation of the UniRes ADMM y-update.
+
+Host-side mirror of the reference's operator interface for this path
+(``unires/_project.py`` + the y-block of ``unires/_update.py``), backed by the
+hand-written HIP library ``libunires_hip.so`` (C ABI: ``include/unires_hip.h``).
+"""
+from . import _lib  # noqa: F401
+from .struct import _input, _output, _proj_op, settings  # noqa: F401
+from ._project import (_apply_scaling, _check_adjoint, _DtD, _proj, _proj_apply,  # noqa: F401
+                       _proj_info)
+from ._update import _admm_aux, _step_size, _update_admm  # noqa: F401
+
+__all__ = ['_input', '_output', '_proj_op', 'settings', '_proj_info', '_proj_apply', '_proj',
+           '_DtD', '_apply_scaling', '_check_adjoint', '_update_admm', '_step_size', '_admm_aux']

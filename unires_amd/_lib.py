@@ -1,0 +1,105 @@
+"""ctypes binding of ``libunires_hip.so`` (C ABI in ``include/unires_hip.h``).
+
+The library is the product: if it is missing this module raises - there is no
+CPU / eager fallback anywhere in ``unires_amd``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libunires_hip.so')
+
+UNIRES_MAX_TAPS = 32
+OP = {'A': 0, 'At': 1, 'AtA': 2}
+REGIME_IDENTITY, REGIME_DENOISE, REGIME_SUPERRES = 0, 1, 2
+STOP = {'e': 0, 'max_gain': 1, 'max_gain_recurred': 2}
+
+c_i32x3 = C.c_int32 * 3
+c_f32x3 = C.c_float * 3
+c_f32x12 = C.c_float * 12
+c_fptrx3 = C.POINTER(C.c_float) * 3
+
+
+class Repeat(C.Structure):
+    """``unires_repeat_t``."""
+    _fields_ = [('dim_x', c_i32x3), ('dim_g', c_i32x3), ('M', c_f32x12), ('ratio', c_i32x3),
+                ('ntaps', c_i32x3), ('taps', c_fptrx3), ('scl', C.c_float),
+                ('dim_thick', C.c_int32), ('tau', C.c_float)]
+
+
+# name -> (restype, argtypes); must list every symbol include/unires_hip.h declares
+SIGNATURES = {
+    'unires_last_error': (C.c_char_p, []),
+    'unires_abi_version': (C.c_int, []),
+    'unires_pull3d_affine': (C.c_int, [C.c_void_p, c_i32x3, c_f32x12, C.c_void_p, c_i32x3,
+                                       C.c_float, C.c_void_p]),
+    'unires_push3d_affine': (C.c_int, [C.c_void_p, c_i32x3, c_f32x12, C.c_void_p, c_i32x3,
+                                       C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    'unires_conv_down3d': (C.c_int, [C.c_void_p, c_i32x3, c_fptrx3, c_i32x3, c_i32x3, C.c_void_p,
+                                     c_i32x3, C.c_float, C.c_int32, C.c_void_p]),
+    'unires_conv_up3d': (C.c_int, [C.c_void_p, c_i32x3, c_fptrx3, c_i32x3, c_i32x3, C.c_void_p,
+                                   c_i32x3, C.c_float, C.c_int32, C.c_void_p]),
+    'unires_grad_fwd_zero': (C.c_int, [C.c_void_p, c_i32x3, c_f32x3, C.c_void_p, C.c_void_p]),
+    'unires_div_fwd_zero': (C.c_int, [C.c_void_p, c_i32x3, c_f32x3, C.c_void_p, C.c_void_p]),
+    'unires_dtd': (C.c_int, [C.c_void_p, c_i32x3, c_f32x3, C.c_float, C.c_float, C.c_void_p,
+                             C.c_void_p]),
+    'unires_plan_create': (C.c_int, [C.POINTER(C.c_void_p), c_i32x3, c_f32x3, C.c_int32,
+                                     C.c_int32, C.POINTER(Repeat), C.c_float]),
+    'unires_plan_destroy': (C.c_int, [C.c_void_p]),
+    'unires_plan_set_repeat': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Repeat)]),
+    'unires_plan_workspace_bytes': (C.c_int64, [C.c_void_p]),
+    'unires_proj_apply': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    'unires_ata_matvec': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    'unires_rhs_assemble': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'unires_cg_solve': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                  C.c_int32, C.c_double, C.c_int32, C.c_int32,
+                                  C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p]),
+}
+
+_lib = None
+
+# status code -> exception type, mirroring the reference's Python errors
+# (ValueError('Undefined operator'/'Undefined method'), unires/_project.py:123-126)
+_EXC = {1: ValueError, 2: ValueError, 3: ValueError, 4: RuntimeError, 5: MemoryError,
+        6: NotImplementedError}
+
+
+def load():
+    """Load (once) and return the bound library; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'unires_amd: %s is missing. Build it with `python -c "import __graft_entry__ as g; '
+            'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.unires_abi_version() != 1:
+        raise RuntimeError('unires_amd: ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().unires_last_error().decode()
+        raise _EXC.get(status, RuntimeError)(msg)
+
+
+def i3(v):
+    return c_i32x3(*[int(t) for t in v])
+
+
+def f3(v):
+    return c_f32x3(*[float(t) for t in v])
+
+
+def f12(v):
+    return c_f32x12(*[float(t) for t in v])

@@ -1,0 +1,159 @@
+"""ChannelPlan - Python handle of ``unires_plan_t``: the per-channel operator
+``sum_n tau_n A_n^T A_n + rho lam^2 D^T D`` with all its device workspace."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (REGIME_DENOISE, REGIME_IDENTITY, REGIME_SUPERRES, Repeat, check, f3, i3)
+from ._ops import FOV_TOL, _ptr, _stream, _vol
+from .spatial import _m12, voxel_size
+
+
+def proj_matrix(po, method):
+    """float64 mat_y \\ (rigid @ mat_yx | mat_x) and the grid dims
+    (unires/_project.py:145-150)."""
+    if method == 'super-resolution':
+        return torch.linalg.solve(po.mat_y, po.rigid.mm(po.mat_yx)), tuple(po.dim_yx)
+    if method == 'denoising':
+        return torch.linalg.solve(po.mat_y, po.rigid.mm(po.mat_x)), tuple(po.dim_x)
+    raise ValueError('Undefined method')
+
+
+def regime_of(method, do_proj):
+    if method not in ('denoising', 'super-resolution'):
+        raise ValueError('Undefined method')
+    if not do_proj:
+        return REGIME_IDENTITY
+    return REGIME_SUPERRES if method == 'super-resolution' else REGIME_DENOISE
+
+
+def _repeat_desc(po, tau, method, regime, keep):
+    r = Repeat()
+    r.tau = float(tau)
+    if regime == REGIME_IDENTITY:
+        return r
+    mat, dim_g = proj_matrix(po, method)
+    r.dim_x = i3(po.dim_x)
+    r.dim_g = i3(dim_g)
+    r.M = _lib.c_f32x12(*_m12(mat).tolist())
+    if regime == REGIME_SUPERRES:
+        taps = [np.ascontiguousarray(np.asarray(k, dtype=np.float32)) for k in po.smo_ker_1d]
+        keep.extend(taps)
+        r.ratio = i3(po.ratio)
+        r.ntaps = i3([len(k) for k in taps])
+        r.taps = _lib.c_fptrx3(*[k.ctypes.data_as(C.POINTER(C.c_float)) for k in taps])
+        r.scl = float(po.scl)
+        r.dim_thick = int(po.dim_thick)
+    else:
+        r.ratio = i3((1, 1, 1))
+        r.ntaps = i3((1, 1, 1))
+    return r
+
+
+class ChannelPlan:
+    """One channel's fused operator. ``xs``: list of (po, tau) per repeat."""
+
+    def __init__(self, dim_y, vx_y, repeats, method, do_proj, fov_tol=FOV_TOL):
+        self.lib = _lib.load()
+        self.dim_y = tuple(int(d) for d in dim_y)
+        self.regime = regime_of(method, do_proj)
+        self.method = method
+        self.n_repeats = len(repeats)
+        keep = []
+        arr = (Repeat * len(repeats))(*[_repeat_desc(po, tau, method, self.regime, keep)
+                                       for po, tau in repeats])
+        self._h = C.c_void_p()
+        check(self.lib.unires_plan_create(C.byref(self._h), i3(self.dim_y), f3(vx_y), self.regime,
+                                          len(repeats), arr, fov_tol))
+        self.dims_x = [self.dim_y if self.regime == REGIME_IDENTITY else tuple(po.dim_x)
+                       for po, _ in repeats]
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self.lib.unires_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def workspace_bytes(self):
+        return int(self.lib.unires_plan_workspace_bytes(self._h))
+
+    def set_repeat(self, n, po, tau):
+        keep = []
+        r = _repeat_desc(po, tau, self.method, self.regime, keep)
+        check(self.lib.unires_plan_set_repeat(self._h, n, C.byref(r)))
+
+    def _y(self, t, name):
+        v, _ = _vol(t, name)
+        if tuple(v.shape) != self.dim_y:
+            raise ValueError('unires_amd: %s has shape %s, expected %s'
+                             % (name, tuple(v.shape), self.dim_y))
+        return v
+
+    def proj_apply(self, n, operator, dat):
+        """_proj_apply(operator, dat, po_n) without tau."""
+        if operator not in _lib.OP:
+            raise ValueError('Undefined operator')
+        d, lead = _vol(dat)
+        out_dim = self.dims_x[n] if operator == 'A' else self.dim_y
+        in_dim = self.dims_x[n] if operator == 'At' else self.dim_y
+        if tuple(d.shape) != tuple(in_dim):
+            raise ValueError('unires_amd: input has shape %s, expected %s'
+                             % (tuple(d.shape), tuple(in_dim)))
+        out = torch.empty(out_dim, dtype=torch.float32, device=d.device)
+        check(self.lib.unires_proj_apply(self._h, n, _lib.OP[operator], _ptr(d), _ptr(out),
+                                         _stream()))
+        return out.reshape(lead + tuple(out_dim))
+
+    def matvec(self, p, rho, lam, out=None, dot=None):
+        """q = sum tau AtA p + rho lam^2 DtD p; ``dot``: 0-d float64 device tensor or None."""
+        p = self._y(p, 'p')
+        if out is None:
+            out = torch.empty_like(p)
+        check(self.lib.unires_ata_matvec(self._h, float(rho), float(lam), _ptr(p), _ptr(out),
+                                         _ptr(dot) if dot is not None else None, _stream()))
+        return out
+
+    def rhs(self, x_dats, w_c, z_c, rho, lam, out=None):
+        """b = sum tau At x - lam Dt(w - rho z)   (unires/_update.py:124-133)."""
+        xs = [_vol(t, 'x')[0] for t in x_dats]
+        for t, dx in zip(xs, self.dims_x):
+            if tuple(t.shape) != tuple(dx):
+                raise ValueError('unires_amd: observation shape mismatch')
+        if len(xs) != self.n_repeats:
+            raise ValueError('unires_amd: need one observation per repeat')
+        for t in (w_c, z_c):
+            if tuple(t.shape) != (3,) + self.dim_y or not t.is_cuda or t.dtype != torch.float32:
+                raise ValueError('unires_amd: w/z must be (3,X,Y,Z) float32 device tensors')
+        w_c, z_c = w_c.contiguous(), z_c.contiguous()
+        if out is None:
+            out = torch.empty(self.dim_y, dtype=torch.float32, device=w_c.device)
+        ptrs = (C.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
+        check(self.lib.unires_rhs_assemble(self._h, ptrs, _ptr(w_c), _ptr(z_c), float(rho),
+                                           float(lam), _ptr(out), _stream()))
+        return out
+
+    def cg(self, b, x, rho, lam, max_iter=20, tolerance=1e-3, stop='max_gain', sync=True):
+        """In-place CG on x (must be contiguous (X,Y,Z)).  Returns (iters, obj) when
+        ``sync`` (one stream sync), else None with everything left enqueued."""
+        b = self._y(b, 'b')
+        if not x.is_contiguous():
+            raise ValueError('unires_amd: cg updates x in place and needs it contiguous')
+        self._y(x, 'x')
+        s = stop if stop in _lib.STOP else stop[0].lower()
+        mode = _lib.STOP[s] if s in _lib.STOP else (0 if s == 'e' else 1)
+        if sync:
+            it = C.c_int32(0)
+            obj = (C.c_double * (max_iter + 1))()
+            check(self.lib.unires_cg_solve(self._h, float(rho), float(lam), _ptr(b), _ptr(x),
+                                           int(max_iter), float(tolerance), mode, 0, C.byref(it),
+                                           obj, _stream()))
+            trace = list(obj)[:it.value + 1] if tolerance else None
+            return it.value, trace
+        check(self.lib.unires_cg_solve(self._h, float(rho), float(lam), _ptr(b), _ptr(x),
+                                       int(max_iter), float(tolerance), mode, 0, None, None,
+                                       _stream()))
+        return None

@@ -1,0 +1,501 @@
+// api.hip - the C ABI of libunires_hip.so (include/unires_hip.h): argument
+// checking, the plan object, and the host-side sequencing of kernels for
+// _proj_apply / _proj('AtA') / the y-update RHS / nitorch-style cg().
+// Nothing here touches torch; the caller hands over raw device pointers and a
+// hipStream_t.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "cg.hpp"
+#include "ops.hpp"
+
+using namespace unires;
+
+// --------------------------------------------------------------------------
+// error plumbing
+// --------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                               \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+      return UNIRES_ERR_HIP;                                                        \
+    }                                                                               \
+  } while (0)
+
+#define CHECK_LAUNCH()                                                              \
+  do {                                                                              \
+    hipError_t e_ = hipGetLastError();                                              \
+    if (e_ != hipSuccess) {                                                         \
+      g_err = std::string("kernel launch: ") + hipGetErrorString(e_);               \
+      return UNIRES_ERR_HIP;                                                        \
+    }                                                                               \
+  } while (0)
+
+static bool dims_ok(const int32_t d[3]) {
+  return d[0] > 0 && d[1] > 0 && d[2] > 0 && d[0] <= 65535 &&
+         (long long)d[0] * d[1] * d[2] < (1ll << 40);
+}
+static Dim3i mk(const int32_t d[3]) { return Dim3i{d[0], d[1], d[2]}; }
+
+static int make_taps(const float *const taps[3], const int32_t ntaps[3], const int32_t stride[3],
+                     Taps &T) {
+  memset(&T, 0, sizeof(T));
+  for (int d = 0; d < 3; ++d) {
+    if (ntaps[d] < 1 || ntaps[d] > UNIRES_MAX_TAPS)
+      return fail(UNIRES_ERR_UNSUPPORTED, "ntaps must be in [1, UNIRES_MAX_TAPS]");
+    if (stride[d] < 1) return fail(UNIRES_ERR_ARG, "stride must be >= 1");
+    if (!taps[d]) return fail(UNIRES_ERR_NULL, "null taps pointer");
+    T.n[d] = ntaps[d];
+    T.s[d] = stride[d];
+    for (int i = 0; i < ntaps[d]; ++i) T.t[d][i] = taps[d][i];
+  }
+  return UNIRES_OK;
+}
+
+static Scaling make_scaling(float scl, int dim) {
+  if (scl == 0.f) return Scaling{1.f, 1.f, -1};
+  return Scaling{expf(scl), expf(-scl), dim};
+}
+
+static int check_conv_dims(const Dim3i &hi, const Dim3i &lo, const Taps &T) {
+  const int h[3] = {hi.x, hi.y, hi.z}, l[3] = {lo.x, lo.y, lo.z};
+  for (int d = 0; d < 3; ++d)
+    if (h[d] != (l[d] - 1) * T.s[d] + T.n[d])
+      return fail(UNIRES_ERR_DIM, "conv dims: need hi = (lo-1)*stride + ntaps");
+  return UNIRES_OK;
+}
+
+extern "C" const char *unires_last_error(void) { return g_err.c_str(); }
+extern "C" int unires_abi_version(void) { return UNIRES_HIP_ABI_VERSION; }
+
+// --------------------------------------------------------------------------
+// op level
+// --------------------------------------------------------------------------
+extern "C" int unires_pull3d_affine(const float *src, const int32_t sdim[3], const float M[12],
+                                    float *dst, const int32_t gdim[3], float fov_tol,
+                                    void *stream) {
+  if (!src || !dst || !sdim || !gdim || !M) return fail(UNIRES_ERR_NULL, "null argument");
+  if (!dims_ok(sdim) || !dims_ok(gdim)) return fail(UNIRES_ERR_DIM, "bad dimensions");
+  Affine A;
+  memcpy(A.m, M, sizeof(A.m));
+  launch_pull(src, mk(sdim), A, dst, mk(gdim), fov_tol, nullptr, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+extern "C" int unires_push3d_affine(const float *src, const int32_t gdim[3], const float M[12],
+                                    float *dst, const int32_t ddim[3], float alpha, float fov_tol,
+                                    int accumulate, void *stream) {
+  if (!src || !dst || !ddim || !gdim || !M) return fail(UNIRES_ERR_NULL, "null argument");
+  if (!dims_ok(ddim) || !dims_ok(gdim)) return fail(UNIRES_ERR_DIM, "bad dimensions");
+  Affine A;
+  memcpy(A.m, M, sizeof(A.m));
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) HIP_TRY(hipMemsetAsync(dst, 0, mk(ddim).numel() * sizeof(float), st));
+  launch_push(src, mk(gdim), A, dst, mk(ddim), alpha, fov_tol, nullptr, st);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+extern "C" int unires_conv_down3d(const float *src, const int32_t sdim[3],
+                                  const float *const taps[3], const int32_t ntaps[3],
+                                  const int32_t stride[3], float *dst, const int32_t ddim[3],
+                                  float scl, int32_t scl_dim, void *stream) {
+  if (!src || !dst || !sdim || !ddim || !taps || !ntaps || !stride)
+    return fail(UNIRES_ERR_NULL, "null argument");
+  if (!dims_ok(sdim) || !dims_ok(ddim)) return fail(UNIRES_ERR_DIM, "bad dimensions");
+  if (scl != 0.f && (scl_dim < 0 || scl_dim > 2)) return fail(UNIRES_ERR_ARG, "bad scl_dim");
+  Taps T;
+  int rc = make_taps(taps, ntaps, stride, T);
+  if (rc) return rc;
+  if ((rc = check_conv_dims(mk(sdim), mk(ddim), T))) return rc;
+  launch_conv_down(src, mk(sdim), T, make_scaling(scl, scl_dim), dst, mk(ddim), nullptr,
+                   (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+extern "C" int unires_conv_up3d(const float *src, const int32_t sdim[3],
+                                const float *const taps[3], const int32_t ntaps[3],
+                                const int32_t stride[3], float *dst, const int32_t ddim[3],
+                                float scl, int32_t scl_dim, void *stream) {
+  if (!src || !dst || !sdim || !ddim || !taps || !ntaps || !stride)
+    return fail(UNIRES_ERR_NULL, "null argument");
+  if (!dims_ok(sdim) || !dims_ok(ddim)) return fail(UNIRES_ERR_DIM, "bad dimensions");
+  if (scl != 0.f && (scl_dim < 0 || scl_dim > 2)) return fail(UNIRES_ERR_ARG, "bad scl_dim");
+  Taps T;
+  int rc = make_taps(taps, ntaps, stride, T);
+  if (rc) return rc;
+  if ((rc = check_conv_dims(mk(ddim), mk(sdim), T))) return rc;
+  launch_conv_up(src, mk(sdim), T, make_scaling(scl, scl_dim), dst, mk(ddim), (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+static bool vx_ok(const float vx[3]) { return vx && vx[0] > 0 && vx[1] > 0 && vx[2] > 0; }
+
+extern "C" int unires_grad_fwd_zero(const float *src, const int32_t dim[3], const float vx[3],
+                                    float *dst3, void *stream) {
+  if (!src || !dst3 || !dim) return fail(UNIRES_ERR_NULL, "null argument");
+  if (!dims_ok(dim)) return fail(UNIRES_ERR_DIM, "bad dimensions");
+  if (!vx_ok(vx)) return fail(UNIRES_ERR_ARG, "voxel size must be positive");
+  launch_grad(src, mk(dim), vx, dst3, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+extern "C" int unires_div_fwd_zero(const float *src3, const int32_t dim[3], const float vx[3],
+                                   float *dst, void *stream) {
+  if (!src3 || !dst || !dim) return fail(UNIRES_ERR_NULL, "null argument");
+  if (!dims_ok(dim)) return fail(UNIRES_ERR_DIM, "bad dimensions");
+  if (!vx_ok(vx)) return fail(UNIRES_ERR_ARG, "voxel size must be positive");
+  launch_div(src3, nullptr, 1.f, 0.f, mk(dim), vx, 1.f, dst, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+extern "C" int unires_dtd(const float *src, const int32_t dim[3], const float vx[3], float a,
+                          float c, float *dst, void *stream) {
+  if (!src || !dst || !dim) return fail(UNIRES_ERR_NULL, "null argument");
+  if (!dims_ok(dim)) return fail(UNIRES_ERR_DIM, "bad dimensions");
+  if (!vx_ok(vx)) return fail(UNIRES_ERR_ARG, "voxel size must be positive");
+  if (src == dst) return fail(UNIRES_ERR_ARG, "dtd cannot run in place");
+  launch_dtd(src, mk(dim), vx, a, c, dst, nullptr, nullptr, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+// --------------------------------------------------------------------------
+// plan
+// --------------------------------------------------------------------------
+struct Repeat {
+  Dim3i dim_x, dim_g;
+  Affine A;
+  Taps T;
+  float scl;
+  int dim_thick;
+  float tau;
+};
+
+struct unires_plan {
+  Dim3i dy;
+  float vx[3];
+  int regime;
+  float fov_tol;
+  std::vector<Repeat> reps;
+  // device workspace (one allocation)
+  char *ws = nullptr;
+  size_t ws_bytes = 0;
+  float *r = nullptr, *p = nullptr, *ap = nullptr, *ax = nullptr;  // N_y each
+  float *gbuf = nullptr;                                           // max N_g
+  float *xbuf = nullptr;                                           // max N_x
+  double *part0 = nullptr, *part1 = nullptr;                       // kMaxPartials each
+  CgState *state = nullptr;
+  size_t cap_g = 0, cap_x = 0;
+};
+
+static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat &out) {
+  if (!in) return fail(UNIRES_ERR_NULL, "null repeat descriptor");
+  if (!(in->tau > 0.f)) return fail(UNIRES_ERR_ARG, "tau must be positive");
+  memset(&out, 0, sizeof(out));
+  out.tau = in->tau;
+  out.scl = in->scl;
+  out.dim_thick = in->dim_thick;
+  if (pl->regime == UNIRES_REGIME_IDENTITY) {
+    out.dim_x = pl->dy;
+    out.dim_g = pl->dy;
+    return UNIRES_OK;
+  }
+  if (!dims_ok(in->dim_x) || !dims_ok(in->dim_g)) return fail(UNIRES_ERR_DIM, "bad repeat dims");
+  out.dim_x = mk(in->dim_x);
+  out.dim_g = mk(in->dim_g);
+  memcpy(out.A.m, in->M, sizeof(out.A.m));
+  for (int i = 0; i < 12; ++i)
+    if (!isfinite(out.A.m[i])) return fail(UNIRES_ERR_ARG, "non-finite affine");
+  if (pl->regime == UNIRES_REGIME_SUPERRES) {
+    int rc = make_taps(in->taps, in->ntaps, in->ratio, out.T);
+    if (rc) return rc;
+    if ((rc = check_conv_dims(out.dim_g, out.dim_x, out.T))) return rc;
+    if (out.scl != 0.f && (out.dim_thick < 0 || out.dim_thick > 2))
+      return fail(UNIRES_ERR_ARG, "bad dim_thick");
+  } else {
+    if (out.dim_g.x != out.dim_x.x || out.dim_g.y != out.dim_x.y || out.dim_g.z != out.dim_x.z)
+      return fail(UNIRES_ERR_DIM, "denoising regime needs dim_g == dim_x");
+  }
+  return UNIRES_OK;
+}
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
+                                  const float vx_y[3], int32_t regime, int32_t n_repeats,
+                                  const unires_repeat_t *repeats, float fov_tol) {
+  if (!plan || !dim_y) return fail(UNIRES_ERR_NULL, "null argument");
+  *plan = nullptr;
+  if (!dims_ok(dim_y)) return fail(UNIRES_ERR_DIM, "bad dim_y");
+  if (!vx_ok(vx_y)) return fail(UNIRES_ERR_ARG, "voxel size must be positive");
+  if (regime < 0 || regime > 2) return fail(UNIRES_ERR_ARG, "Undefined method");
+  if (n_repeats < 1 || !repeats) return fail(UNIRES_ERR_ARG, "need at least one repeat");
+  unires_plan *pl = new (std::nothrow) unires_plan();
+  if (!pl) return fail(UNIRES_ERR_ALLOC, "host allocation failed");
+  pl->dy = mk(dim_y);
+  memcpy(pl->vx, vx_y, sizeof(pl->vx));
+  pl->regime = regime;
+  pl->fov_tol = fov_tol;
+  pl->reps.resize(n_repeats);
+  for (int n = 0; n < n_repeats; ++n) {
+    int rc = fill_repeat(pl, &repeats[n], pl->reps[n]);
+    if (rc) {
+      delete pl;
+      return rc;
+    }
+    if (regime != UNIRES_REGIME_IDENTITY) {
+      pl->cap_g = std::max(pl->cap_g, pl->reps[n].dim_g.numel());
+      pl->cap_x = std::max(pl->cap_x, pl->reps[n].dim_x.numel());
+    }
+  }
+  const size_t ny = pl->dy.numel();
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off += align_up(bytes);
+    return o;
+  };
+  const size_t o_r = carve(ny * 4), o_p = carve(ny * 4), o_ap = carve(ny * 4), o_ax = carve(ny * 4);
+  const size_t o_g = carve(pl->cap_g * 4), o_x = carve(pl->cap_x * 4);
+  const size_t o_p0 = carve(kMaxPartials * 8), o_p1 = carve(kMaxPartials * 8);
+  const size_t o_st = carve(sizeof(CgState));
+  pl->ws_bytes = off;
+  hipError_t e = hipMalloc((void **)&pl->ws, pl->ws_bytes);
+  if (e != hipSuccess) {
+    g_err = std::string("hipMalloc workspace: ") + hipGetErrorString(e);
+    delete pl;
+    return UNIRES_ERR_ALLOC;
+  }
+  pl->r = (float *)(pl->ws + o_r);
+  pl->p = (float *)(pl->ws + o_p);
+  pl->ap = (float *)(pl->ws + o_ap);
+  pl->ax = (float *)(pl->ws + o_ax);
+  pl->gbuf = (float *)(pl->ws + o_g);
+  pl->xbuf = (float *)(pl->ws + o_x);
+  pl->part0 = (double *)(pl->ws + o_p0);
+  pl->part1 = (double *)(pl->ws + o_p1);
+  pl->state = (CgState *)(pl->ws + o_st);
+  e = hipMemset(pl->state, 0, sizeof(CgState));
+  if (e != hipSuccess) {
+    g_err = std::string("hipMemset: ") + hipGetErrorString(e);
+    (void)hipFree(pl->ws);
+    delete pl;
+    return UNIRES_ERR_HIP;
+  }
+  *plan = pl;
+  return UNIRES_OK;
+}
+
+extern "C" int unires_plan_destroy(unires_plan_t *plan) {
+  if (!plan) return UNIRES_OK;
+  if (plan->ws) (void)hipFree(plan->ws);
+  delete plan;
+  return UNIRES_OK;
+}
+
+extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
+                                      const unires_repeat_t *repeat) {
+  if (!plan || !repeat) return fail(UNIRES_ERR_NULL, "null argument");
+  if (n < 0 || n >= (int)plan->reps.size()) return fail(UNIRES_ERR_ARG, "repeat index");
+  Repeat tmp;
+  int rc = fill_repeat(plan, repeat, tmp);
+  if (rc) return rc;
+  if (plan->regime != UNIRES_REGIME_IDENTITY &&
+      (tmp.dim_g.numel() > plan->cap_g || tmp.dim_x.numel() > plan->cap_x))
+    return fail(UNIRES_ERR_DIM, "new repeat exceeds the plan's workspace");
+  plan->reps[n] = tmp;
+  return UNIRES_OK;
+}
+
+extern "C" int64_t unires_plan_workspace_bytes(const unires_plan_t *plan) {
+  return plan ? (int64_t)plan->ws_bytes : 0;
+}
+
+// --------------------------------------------------------------------------
+// operators
+// --------------------------------------------------------------------------
+// out (+)= alpha * AtA_n(in) for regimes 1/2 ("accumulate" into an initialised out)
+static void ata_accumulate(unires_plan *pl, const Repeat &R, const float *in, float *out,
+                           float alpha, const int *done, hipStream_t st) {
+  if (pl->regime == UNIRES_REGIME_DENOISE) {
+    launch_pull(in, pl->dy, R.A, pl->gbuf, R.dim_g, pl->fov_tol, done, st);
+    launch_push(pl->gbuf, R.dim_g, R.A, out, pl->dy, alpha, pl->fov_tol, done, st);
+  } else {
+    launch_pull(in, pl->dy, R.A, pl->gbuf, R.dim_g, pl->fov_tol, done, st);
+    // S(2 scl) once between conv and conv^T  (unires/_project.py:175-177)
+    launch_conv_down(pl->gbuf, R.dim_g, R.T, make_scaling(2.f * R.scl, R.dim_thick), pl->xbuf,
+                     R.dim_x, done, st);
+    launch_push_convup(pl->xbuf, R.dim_x, R.T, Scaling{1.f, 1.f, -1}, R.dim_g, R.A, out, pl->dy,
+                       alpha, pl->fov_tol, done, st);
+  }
+}
+
+// out (+)= alpha * At_n(x)
+static void at_accumulate(unires_plan *pl, const Repeat &R, const float *x, float *out, float alpha,
+                          hipStream_t st) {
+  if (pl->regime == UNIRES_REGIME_IDENTITY) {
+    launch_axpy(alpha, x, out, pl->dy.numel(), st);
+  } else if (pl->regime == UNIRES_REGIME_DENOISE) {
+    launch_push(x, R.dim_g, R.A, out, pl->dy, alpha, pl->fov_tol, nullptr, st);
+  } else {
+    launch_push_convup(x, R.dim_x, R.T, make_scaling(R.scl, R.dim_thick), R.dim_g, R.A, out,
+                       pl->dy, alpha, pl->fov_tol, nullptr, st);
+  }
+}
+
+extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, const float *in,
+                                 float *out, void *stream) {
+  if (!plan || !in || !out) return fail(UNIRES_ERR_NULL, "null argument");
+  if (n < 0 || n >= (int)plan->reps.size()) return fail(UNIRES_ERR_ARG, "repeat index");
+  if (op != UNIRES_OP_A && op != UNIRES_OP_AT && op != UNIRES_OP_ATA)
+    return fail(UNIRES_ERR_ARG, "Undefined operator");
+  if (in == out) return fail(UNIRES_ERR_ARG, "proj_apply cannot run in place");
+  hipStream_t st = (hipStream_t)stream;
+  const Repeat &R = plan->reps[n];
+  const size_t ny = plan->dy.numel();
+  if (plan->regime == UNIRES_REGIME_IDENTITY) {  // operator 'none': return dat
+    HIP_TRY(hipMemcpyAsync(out, in, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return UNIRES_OK;
+  }
+  if (op == UNIRES_OP_A) {
+    if (plan->regime == UNIRES_REGIME_DENOISE) {
+      launch_pull(in, plan->dy, R.A, out, R.dim_g, plan->fov_tol, nullptr, st);
+    } else {
+      launch_pull(in, plan->dy, R.A, plan->gbuf, R.dim_g, plan->fov_tol, nullptr, st);
+      launch_conv_down(plan->gbuf, R.dim_g, R.T, make_scaling(R.scl, R.dim_thick), out, R.dim_x,
+                       nullptr, st);
+    }
+  } else {
+    HIP_TRY(hipMemsetAsync(out, 0, ny * sizeof(float), st));
+    if (op == UNIRES_OP_AT)
+      at_accumulate(plan, R, in, out, 1.f, st);
+    else
+      ata_accumulate(plan, R, in, out, 1.f, nullptr, st);
+  }
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+// q = sum_n tau_n AtA_n p + rho lam^2 DtD p ; optional dot partials of sum(p*q).
+// Returns the number of partials written (0 if none requested).
+static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *q, double *part,
+                  const int *done, hipStream_t st) {
+  const float c = rho * (lam * lam);
+  if (pl->regime == UNIRES_REGIME_IDENTITY) {
+    float a0 = 0.f;
+    for (const Repeat &R : pl->reps) a0 += R.tau;
+    launch_dtd(p, pl->dy, pl->vx, a0, c, q, part, done, st);
+    return part ? dtd_num_blocks(pl->dy) : 0;
+  }
+  launch_dtd(p, pl->dy, pl->vx, 0.f, c, q, nullptr, done, st);
+  for (const Repeat &R : pl->reps) ata_accumulate(pl, R, p, q, R.tau, done, st);
+  if (!part) return 0;
+  launch_dot(p, q, pl->dy.numel(), part, done, st);
+  return vec_num_blocks(pl->dy.numel());
+}
+
+extern "C" int unires_ata_matvec(unires_plan_t *plan, float rho, float lam, const float *p,
+                                 float *q, double *dot_dev, void *stream) {
+  if (!plan || !p || !q) return fail(UNIRES_ERR_NULL, "null argument");
+  if (p == q) return fail(UNIRES_ERR_ARG, "matvec cannot run in place");
+  hipStream_t st = (hipStream_t)stream;
+  const int g = matvec(plan, rho, lam, p, q, dot_dev ? plan->part0 : nullptr, nullptr, st);
+  if (dot_dev) launch_sum_to(plan->part0, g, dot_dev, st);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+extern "C" int unires_rhs_assemble(unires_plan_t *plan, const float *const *x_ptrs,
+                                   const float *w_c, const float *z_c, float rho, float lam,
+                                   float *b, void *stream) {
+  if (!plan || !x_ptrs || !w_c || !z_c || !b) return fail(UNIRES_ERR_NULL, "null argument");
+  for (size_t n = 0; n < plan->reps.size(); ++n)
+    if (!x_ptrs[n]) return fail(UNIRES_ERR_NULL, "null observation pointer");
+  hipStream_t st = (hipStream_t)stream;
+  // b = -lam * Dt(w - rho z)   (unires/_update.py:131-133)
+  launch_div(w_c, z_c, 1.f, -rho, plan->dy, plan->vx, -lam, b, st);
+  // b += tau_n At_n x_n         (unires/_update.py:125-128)
+  for (size_t n = 0; n < plan->reps.size(); ++n)
+    at_accumulate(plan, plan->reps[n], x_ptrs[n], b, plan->reps[n].tau, st);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+// --------------------------------------------------------------------------
+// CG  (nitorch.core.optim.cg as UniRes calls it)
+// --------------------------------------------------------------------------
+extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const float *b, float *x,
+                               int32_t max_iter, double tol, int32_t stop_mode,
+                               int32_t precond_mode, int32_t *iters_out, double *obj_trace,
+                               void *stream) {
+  if (!plan || !b || !x) return fail(UNIRES_ERR_NULL, "null argument");
+  if (b == x) return fail(UNIRES_ERR_ARG, "b and x must not alias");
+  if (max_iter < 0 || max_iter > kMaxCgIter) return fail(UNIRES_ERR_ARG, "max_iter out of range");
+  if (stop_mode < 0 || stop_mode > 2) return fail(UNIRES_ERR_ARG, "bad stop mode");
+  if (precond_mode != UNIRES_PRECOND_IDENTITY)
+    return fail(UNIRES_ERR_UNSUPPORTED, "only the identity preconditioner is built");
+  if (!(tol >= 0.0)) return fail(UNIRES_ERR_ARG, "tolerance must be >= 0");
+  hipStream_t st = (hipStream_t)stream;
+  unires_plan *pl = plan;
+  const size_t ny = pl->dy.numel();
+  const bool check = tol != 0.0;
+  CgState *S = pl->state;
+  const int *done = &S->done;
+  const int gv = vec_num_blocks(ny);
+
+  // r = b - A(x); p = r; rz = r.r; obj[0]
+  HIP_TRY(hipMemsetAsync(&S->done, 0, sizeof(int), st));
+  matvec(pl, rho, lam, x, pl->ap, nullptr, nullptr, st);
+  const bool want_obj0 = check && stop_mode != UNIRES_STOP_RESIDUAL;
+  launch_residual_init(b, pl->ap, x, pl->r, pl->p, ny, pl->part0, want_obj0 ? pl->part1 : nullptr,
+                       st);
+  launch_sc_init(S, pl->part0, pl->part1, gv, stop_mode, check ? 1 : 0, st);
+
+  for (int k = 1; k <= max_iter; ++k) {
+    const int g = matvec(pl, rho, lam, pl->p, pl->ap, pl->part0, done, st);
+    launch_sc_alpha(S, pl->part0, g, st);
+    const bool recur = check && stop_mode == UNIRES_STOP_MAXGAIN_RECURRED;
+    launch_update_xr(S, pl->p, pl->ap, x, pl->r, b, ny, pl->part0, recur ? pl->part1 : nullptr, st);
+    int obj_kind = 0;
+    if (check && stop_mode == UNIRES_STOP_RESIDUAL) obj_kind = 1;
+    if (recur) obj_kind = 2;
+    launch_sc_beta(S, pl->part0, pl->part1, gv, k, obj_kind, tol, st);
+    launch_update_p(S, pl->r, pl->p, ny, st);
+    if (check && stop_mode == UNIRES_STOP_MAXGAIN) {
+      matvec(pl, rho, lam, x, pl->ax, nullptr, done, st);
+      launch_obj(pl->ax, b, x, ny, pl->part1, done, st);
+      launch_sc_obj(S, pl->part1, gv, k, tol, st);
+    }
+  }
+  CHECK_LAUNCH();
+
+  if (iters_out) {
+    int it = 0;
+    HIP_TRY(hipMemcpyAsync(&it, &S->iters, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (obj_trace && check)
+      HIP_TRY(hipMemcpyAsync(obj_trace, S->obj, sizeof(double) * (size_t)(max_iter + 1),
+                             hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *iters_out = it;
+  }
+  return UNIRES_OK;
+}

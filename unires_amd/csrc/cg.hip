@@ -1,0 +1,313 @@
+// cg.hip - CG vector kernels (fused updates + float64 dot partials) and the
+// one-block scalar kernels that turn partials into alpha / beta / objective /
+// convergence flag ON THE DEVICE, so a whole nitorch-style cg() call
+// (unires/_update.py:142-148) is enqueued without a single host sync.
+//
+// Numerics follow the reference: products are rounded to float32 and summed
+// in float64 (torch.sum(p * Ap, dtype=float64)); alpha/beta are float64 scalars
+// rounded to float32 at use (0-d tensor promotion); x += alpha*p is a rounded
+// multiply followed by a rounded add (no FMA contraction).
+#include "cg.hpp"
+
+namespace unires {
+
+static inline int vec_blocks(size_t n) {
+  size_t b = (n / 4 + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  return (int)(b < (size_t)kMaxPartials ? b : (size_t)kMaxPartials);
+}
+
+#define GRID_STRIDE_VEC4(n)                                                   \
+  const size_t n4 = (n) / 4;                                                  \
+  const size_t stride = (size_t)gridDim.x * blockDim.x;                       \
+  const size_t tid0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x
+
+__device__ __forceinline__ float4 ld4(const float *p, size_t i) {
+  return reinterpret_cast<const float4 *>(p)[i];
+}
+__device__ __forceinline__ void st4(float *p, size_t i, float4 v) {
+  reinterpret_cast<float4 *>(p)[i] = v;
+}
+
+// obj term of nitorch cg for stop != 'e': (A(x) - 2b) * x, rounded like
+// A(x).sub_(2*b).mul_(x)
+__device__ __forceinline__ float obj_term(float ax, float b, float x) {
+  return __fmul_rn(__fsub_rn(ax, __fmul_rn(2.f, b)), x);
+}
+
+// r = b - A(x); p = r; partial[0..G) = sum r*r; partial2 = sum (Ax-2b)*x (optional)
+__global__ void __launch_bounds__(kBlock)
+    k_residual_init(const float *__restrict__ b, const float *__restrict__ ax,
+                    const float *__restrict__ x, float *__restrict__ r, float *__restrict__ p,
+                    size_t n, double *__restrict__ part_rr, double *__restrict__ part_obj) {
+  GRID_STRIDE_VEC4(n);
+  double rr = 0.0, ob = 0.0;
+  for (size_t i = tid0; i < n4; i += stride) {
+    const float4 vb = ld4(b, i), va = ld4(ax, i);
+    float4 vr;
+    vr.x = __fsub_rn(vb.x, va.x);
+    vr.y = __fsub_rn(vb.y, va.y);
+    vr.z = __fsub_rn(vb.z, va.z);
+    vr.w = __fsub_rn(vb.w, va.w);
+    st4(r, i, vr);
+    st4(p, i, vr);
+    rr += (double)__fmul_rn(vr.x, vr.x) + (double)__fmul_rn(vr.y, vr.y) +
+          (double)__fmul_rn(vr.z, vr.z) + (double)__fmul_rn(vr.w, vr.w);
+    if (part_obj) {
+      const float4 vx = ld4(x, i);
+      ob += (double)obj_term(va.x, vb.x, vx.x) + (double)obj_term(va.y, vb.y, vx.y) +
+            (double)obj_term(va.z, vb.z, vx.z) + (double)obj_term(va.w, vb.w, vx.w);
+    }
+  }
+  for (size_t i = n4 * 4 + tid0; i < n; i += stride) {  // tail
+    const float vr = __fsub_rn(b[i], ax[i]);
+    r[i] = vr;
+    p[i] = vr;
+    rr += (double)__fmul_rn(vr, vr);
+    if (part_obj) ob += (double)obj_term(ax[i], b[i], x[i]);
+  }
+  const double t = block_sum(rr);
+  if (threadIdx.x == 0) part_rr[blockIdx.x] = t;
+  if (part_obj) {
+    const double t2 = block_sum(ob);
+    if (threadIdx.x == 0) part_obj[blockIdx.x] = t2;
+  }
+}
+
+// partial = sum a*b
+__global__ void __launch_bounds__(kBlock)
+    k_dot(const float *__restrict__ a, const float *__restrict__ b, size_t n,
+          double *__restrict__ part, const int *__restrict__ done) {
+  if (done && *done) return;
+  GRID_STRIDE_VEC4(n);
+  double acc = 0.0;
+  for (size_t i = tid0; i < n4; i += stride) {
+    const float4 va = ld4(a, i), vb = ld4(b, i);
+    acc += (double)__fmul_rn(va.x, vb.x) + (double)__fmul_rn(va.y, vb.y) +
+           (double)__fmul_rn(va.z, vb.z) + (double)__fmul_rn(va.w, vb.w);
+  }
+  for (size_t i = n4 * 4 + tid0; i < n; i += stride) acc += (double)__fmul_rn(a[i], b[i]);
+  const double t = block_sum(acc);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// partial = sum (Ax - 2b) * x
+__global__ void __launch_bounds__(kBlock)
+    k_obj(const float *__restrict__ ax, const float *__restrict__ b, const float *__restrict__ x,
+          size_t n, double *__restrict__ part, const int *__restrict__ done) {
+  if (done && *done) return;
+  GRID_STRIDE_VEC4(n);
+  double acc = 0.0;
+  for (size_t i = tid0; i < n4; i += stride) {
+    const float4 va = ld4(ax, i), vb = ld4(b, i), vx = ld4(x, i);
+    acc += (double)obj_term(va.x, vb.x, vx.x) + (double)obj_term(va.y, vb.y, vx.y) +
+           (double)obj_term(va.z, vb.z, vx.z) + (double)obj_term(va.w, vb.w, vx.w);
+  }
+  for (size_t i = n4 * 4 + tid0; i < n; i += stride) acc += (double)obj_term(ax[i], b[i], x[i]);
+  const double t = block_sum(acc);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// x += alpha p ; r -= alpha Ap ; part_rr = sum r*r ;
+// part_obj (optional) = sum x*(b+r)  (recurred objective -0.5*sum x (b+r))
+__global__ void __launch_bounds__(kBlock)
+    k_update_xr(const CgState *__restrict__ st, const float *__restrict__ p,
+                const float *__restrict__ ap, float *__restrict__ x, float *__restrict__ r,
+                const float *__restrict__ b, size_t n, double *__restrict__ part_rr,
+                double *__restrict__ part_obj) {
+  if (st->done) return;
+  const float alpha = (float)st->alpha;
+  GRID_STRIDE_VEC4(n);
+  double rr = 0.0, ob = 0.0;
+  for (size_t i = tid0; i < n4; i += stride) {
+    const float4 vp = ld4(p, i), va = ld4(ap, i);
+    float4 vx = ld4(x, i), vr = ld4(r, i);
+    vx.x = __fadd_rn(vx.x, __fmul_rn(alpha, vp.x));
+    vx.y = __fadd_rn(vx.y, __fmul_rn(alpha, vp.y));
+    vx.z = __fadd_rn(vx.z, __fmul_rn(alpha, vp.z));
+    vx.w = __fadd_rn(vx.w, __fmul_rn(alpha, vp.w));
+    vr.x = __fsub_rn(vr.x, __fmul_rn(alpha, va.x));
+    vr.y = __fsub_rn(vr.y, __fmul_rn(alpha, va.y));
+    vr.z = __fsub_rn(vr.z, __fmul_rn(alpha, va.z));
+    vr.w = __fsub_rn(vr.w, __fmul_rn(alpha, va.w));
+    st4(x, i, vx);
+    st4(r, i, vr);
+    rr += (double)__fmul_rn(vr.x, vr.x) + (double)__fmul_rn(vr.y, vr.y) +
+          (double)__fmul_rn(vr.z, vr.z) + (double)__fmul_rn(vr.w, vr.w);
+    if (part_obj) {
+      const float4 vb = ld4(b, i);
+      ob += (double)__fmul_rn(vx.x, __fadd_rn(vb.x, vr.x)) +
+            (double)__fmul_rn(vx.y, __fadd_rn(vb.y, vr.y)) +
+            (double)__fmul_rn(vx.z, __fadd_rn(vb.z, vr.z)) +
+            (double)__fmul_rn(vx.w, __fadd_rn(vb.w, vr.w));
+    }
+  }
+  for (size_t i = n4 * 4 + tid0; i < n; i += stride) {
+    const float vx = __fadd_rn(x[i], __fmul_rn(alpha, p[i]));
+    const float vr = __fsub_rn(r[i], __fmul_rn(alpha, ap[i]));
+    x[i] = vx;
+    r[i] = vr;
+    rr += (double)__fmul_rn(vr, vr);
+    if (part_obj) ob += (double)__fmul_rn(vx, __fadd_rn(b[i], vr));
+  }
+  const double t = block_sum(rr);
+  if (threadIdx.x == 0) part_rr[blockIdx.x] = t;
+  if (part_obj) {
+    const double t2 = block_sum(ob);
+    if (threadIdx.x == 0) part_obj[blockIdx.x] = t2;
+  }
+}
+
+// p = beta*p + r   (p *= beta; p += z with z = r)
+__global__ void __launch_bounds__(kBlock)
+    k_update_p(const CgState *__restrict__ st, const float *__restrict__ r, float *__restrict__ p,
+               size_t n) {
+  if (st->done) return;
+  const float beta = (float)st->beta;
+  GRID_STRIDE_VEC4(n);
+  for (size_t i = tid0; i < n4; i += stride) {
+    const float4 vr = ld4(r, i);
+    float4 vp = ld4(p, i);
+    vp.x = __fadd_rn(__fmul_rn(beta, vp.x), vr.x);
+    vp.y = __fadd_rn(__fmul_rn(beta, vp.y), vr.y);
+    vp.z = __fadd_rn(__fmul_rn(beta, vp.z), vr.z);
+    vp.w = __fadd_rn(__fmul_rn(beta, vp.w), vr.w);
+    st4(p, i, vp);
+  }
+  for (size_t i = n4 * 4 + tid0; i < n; i += stride) p[i] = __fadd_rn(__fmul_rn(beta, p[i]), r[i]);
+}
+
+// y = a*x + y (generic axpy; used by the identity regime's RHS)
+__global__ void __launch_bounds__(kBlock)
+    k_axpy(float a, const float *__restrict__ x, float *__restrict__ y, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = fmaf(a, x[i], y[i]);
+}
+
+// ---- scalar kernels: <<<1, kBlock>>> -------------------------------------
+__device__ __forceinline__ double sum_partials(const double *part, int g) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < g; i += kBlock) v += part[i];
+  return block_sum(v);
+}
+
+// nitorch get_gain(obj[:k+1], 'decreasing') and the |gain| < tol test
+__device__ __forceinline__ void record_obj(CgState *st, int k, double obj, double tol) {
+  st->obj[k] = obj;
+  if (k == 0) {
+    st->obj_max = obj;
+    st->obj_min = obj;
+    return;
+  }
+  st->obj_max = fmax(st->obj_max, obj);
+  st->obj_min = fmin(st->obj_min, obj);
+  const double gain = (st->obj[k - 1] - obj) / (st->obj_max - st->obj_min);
+  if (fabs(gain) < tol) st->done = 1;  // NaN compares false, like torch
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_sc_init(CgState *st, const double *part_rr, const double *part_obj, int g, int mode,
+              int check) {
+  const double rr = sum_partials(part_rr, g);
+  double ob = 0.0;
+  if (check && mode != UNIRES_STOP_RESIDUAL) ob = sum_partials(part_obj, g);
+  if (threadIdx.x == 0) {
+    st->rz = rr;
+    st->done = 0;
+    st->iters = 0;
+    st->alpha = 0.0;
+    st->beta = 0.0;
+    if (check) record_obj(st, 0, mode == UNIRES_STOP_RESIDUAL ? sqrt(rr) : 0.5 * ob, 0.0);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_sc_alpha(CgState *st, const double *part_pap, int g) {
+  if (st->done) return;
+  const double pap = sum_partials(part_pap, g);
+  if (threadIdx.x == 0) {
+    st->pAp = pap;
+    st->alpha = st->rz / pap;
+  }
+}
+
+// obj_kind: 0 none, 1 sqrt(rz) ('e'), 2 recurred (-0.5 * sum x(b+r))
+__global__ void __launch_bounds__(kBlock)
+    k_sc_beta(CgState *st, const double *part_rr, const double *part_obj, int g, int k,
+              int obj_kind, double tol) {
+  if (st->done) return;
+  const double rr = sum_partials(part_rr, g);
+  double ob = 0.0;
+  if (obj_kind == 2) ob = sum_partials(part_obj, g);
+  if (threadIdx.x == 0) {
+    const double rz0 = st->rz;
+    st->rz = rr;
+    st->beta = rr / rz0;
+    st->iters = k;
+    if (obj_kind == 1) record_obj(st, k, sqrt(rr), tol);
+    if (obj_kind == 2) record_obj(st, k, -0.5 * ob, tol);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_sc_obj(CgState *st, const double *part_obj, int g, int k, double tol) {
+  if (st->done) return;
+  const double ob = sum_partials(part_obj, g);
+  if (threadIdx.x == 0) record_obj(st, k, 0.5 * ob, tol);
+}
+
+__global__ void __launch_bounds__(kBlock) k_sum_to(const double *part, int g, double *out) {
+  const double v = sum_partials(part, g);
+  if (threadIdx.x == 0) *out = v;
+}
+
+// ---- launchers -------------------------------------------------------------
+int vec_num_blocks(size_t n) { return vec_blocks(n); }
+
+void launch_residual_init(const float *b, const float *ax, const float *x, float *r, float *p,
+                          size_t n, double *part_rr, double *part_obj, hipStream_t st) {
+  hipLaunchKernelGGL(k_residual_init, dim3(vec_blocks(n)), dim3(kBlock), 0, st, b, ax, x, r, p, n,
+                     part_rr, part_obj);
+}
+void launch_dot(const float *a, const float *b, size_t n, double *part, const int *done,
+                hipStream_t st) {
+  hipLaunchKernelGGL(k_dot, dim3(vec_blocks(n)), dim3(kBlock), 0, st, a, b, n, part, done);
+}
+void launch_obj(const float *ax, const float *b, const float *x, size_t n, double *part,
+                const int *done, hipStream_t st) {
+  hipLaunchKernelGGL(k_obj, dim3(vec_blocks(n)), dim3(kBlock), 0, st, ax, b, x, n, part, done);
+}
+void launch_update_xr(const CgState *s, const float *p, const float *ap, float *x, float *r,
+                      const float *b, size_t n, double *part_rr, double *part_obj,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(k_update_xr, dim3(vec_blocks(n)), dim3(kBlock), 0, st, s, p, ap, x, r, b, n,
+                     part_rr, part_obj);
+}
+void launch_update_p(const CgState *s, const float *r, float *p, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_update_p, dim3(vec_blocks(n)), dim3(kBlock), 0, st, s, r, p, n);
+}
+void launch_axpy(float a, const float *x, float *y, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_axpy, dim3(vec_blocks(n) * 4 > 4096 ? 4096 : vec_blocks(n) * 4),
+                     dim3(kBlock), 0, st, a, x, y, n);
+}
+void launch_sc_init(CgState *s, const double *part_rr, const double *part_obj, int g, int mode,
+                    int check, hipStream_t st) {
+  hipLaunchKernelGGL(k_sc_init, dim3(1), dim3(kBlock), 0, st, s, part_rr, part_obj, g, mode,
+                     check);
+}
+void launch_sc_alpha(CgState *s, const double *part, int g, hipStream_t st) {
+  hipLaunchKernelGGL(k_sc_alpha, dim3(1), dim3(kBlock), 0, st, s, part, g);
+}
+void launch_sc_beta(CgState *s, const double *part_rr, const double *part_obj, int g, int k,
+                    int obj_kind, double tol, hipStream_t st) {
+  hipLaunchKernelGGL(k_sc_beta, dim3(1), dim3(kBlock), 0, st, s, part_rr, part_obj, g, k,
+                     obj_kind, tol);
+}
+void launch_sc_obj(CgState *s, const double *part, int g, int k, double tol, hipStream_t st) {
+  hipLaunchKernelGGL(k_sc_obj, dim3(1), dim3(kBlock), 0, st, s, part, g, k, tol);
+}
+void launch_sum_to(const double *part, int g, double *out, hipStream_t st) {
+  hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(kBlock), 0, st, part, g, out);
+}
+
+}  // namespace unires

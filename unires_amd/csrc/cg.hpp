@@ -1,0 +1,34 @@
+// cg.hpp - device-resident CG state + launchers of the vector / scalar kernels (cg.hip).
+#pragma once
+#include "common.hpp"
+
+namespace unires {
+
+constexpr int kMaxCgIter = 4096;
+
+struct CgState {  // lives in device memory, owned by the plan
+  double rz, pAp, alpha, beta, obj_max, obj_min;
+  int done, iters;
+  double obj[kMaxCgIter + 1];
+};
+
+int vec_num_blocks(size_t n);  // grid (= number of partials) of the vector kernels
+void launch_residual_init(const float *b, const float *ax, const float *x, float *r, float *p,
+                          size_t n, double *part_rr, double *part_obj, hipStream_t st);
+void launch_dot(const float *a, const float *b, size_t n, double *part, const int *done,
+                hipStream_t st);
+void launch_obj(const float *ax, const float *b, const float *x, size_t n, double *part,
+                const int *done, hipStream_t st);
+void launch_update_xr(const CgState *s, const float *p, const float *ap, float *x, float *r,
+                      const float *b, size_t n, double *part_rr, double *part_obj, hipStream_t st);
+void launch_update_p(const CgState *s, const float *r, float *p, size_t n, hipStream_t st);
+void launch_axpy(float a, const float *x, float *y, size_t n, hipStream_t st);
+void launch_sc_init(CgState *s, const double *part_rr, const double *part_obj, int g, int mode,
+                    int check, hipStream_t st);
+void launch_sc_alpha(CgState *s, const double *part, int g, hipStream_t st);
+void launch_sc_beta(CgState *s, const double *part_rr, const double *part_obj, int g, int k,
+                    int obj_kind, double tol, hipStream_t st);
+void launch_sc_obj(CgState *s, const double *part, int g, int k, double tol, hipStream_t st);
+void launch_sum_to(const double *part, int g, double *out, hipStream_t st);
+
+}  // namespace unires

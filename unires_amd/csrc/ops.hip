@@ -1,0 +1,324 @@
+// ops.hip - op-level kernels: affine trilinear pull / push, strided separable
+// conv down / up, forward-difference gradient / divergence / DtD.
+//
+// Layout: float32 volumes, (X,Y,Z) C-contiguous, Z fastest.  Every kernel puts
+// the 64 lanes of a wave along Z so that HBM/L2 requests are coalesced.
+// Launch shape: block (64,4,1) -> grid (ceil(Z/64), ceil(Y/4), X).
+#include "common.hpp"
+#include "ops.hpp"
+
+namespace unires {
+
+static inline dim3 vol_block() { return dim3(kWave, kBlock / kWave, 1); }
+static inline dim3 vol_grid(const Dim3i &d) {
+  return dim3((d.z + kWave - 1) / kWave, (d.y + 3) / 4, d.x);
+}
+
+// --------------------------------------------------------------------------
+// pull: dst[g] = mask(g) * sum_8 w_c * src[corner_c(M g)]
+// (nitorch grid_pull linear / zero / extrapolate=False)
+// --------------------------------------------------------------------------
+__device__ __forceinline__ float pull_sample(const float *__restrict__ src, const Dim3i &sd,
+                                             float gx, float gy, float gz, float tol) {
+  if (!in_fov(gx, gy, gz, sd, tol)) return 0.f;
+  const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+  const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+  const float wx1 = gx - fx, wy1 = gy - fy, wz1 = gz - fz;
+  const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
+  const bool x0 = ix >= 0 && ix < sd.x, x1 = ix + 1 >= 0 && ix + 1 < sd.x;
+  const bool y0 = iy >= 0 && iy < sd.y, y1 = iy + 1 >= 0 && iy + 1 < sd.y;
+  const bool z0 = iz >= 0 && iz < sd.z, z1 = iz + 1 >= 0 && iz + 1 < sd.z;
+  const long long sx = (long long)sd.y * sd.z, sy = sd.z;
+  const float *p = src + ((long long)ix * sx + (long long)iy * sy + iz);
+  float acc = 0.f;
+  if (x0 && y0 && z0) acc += p[0] * (wx0 * wy0 * wz0);
+  if (x0 && y0 && z1) acc += p[1] * (wx0 * wy0 * wz1);
+  if (x0 && y1 && z0) acc += p[sy] * (wx0 * wy1 * wz0);
+  if (x0 && y1 && z1) acc += p[sy + 1] * (wx0 * wy1 * wz1);
+  if (x1 && y0 && z0) acc += p[sx] * (wx1 * wy0 * wz0);
+  if (x1 && y0 && z1) acc += p[sx + 1] * (wx1 * wy0 * wz1);
+  if (x1 && y1 && z0) acc += p[sx + sy] * (wx1 * wy1 * wz0);
+  if (x1 && y1 && z1) acc += p[sx + sy + 1] * (wx1 * wy1 * wz1);
+  return acc;
+}
+
+__global__ void __launch_bounds__(kBlock) k_pull(const float *__restrict__ src, Dim3i sd, Affine A,
+                                                 float *__restrict__ dst, Dim3i gd, float tol,
+                                                 const int *__restrict__ done) {
+  if (done && *done) return;
+  const int k = blockIdx.x * kWave + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int i = blockIdx.z;
+  if (k >= gd.z || j >= gd.y) return;
+  float gx, gy, gz;
+  affine_point(A, (float)i, (float)j, (float)k, gx, gy, gz);
+  dst[((size_t)i * gd.y + j) * gd.z + k] = pull_sample(src, sd, gx, gy, gz, tol);
+}
+
+// --------------------------------------------------------------------------
+// conv_up gather: h[u] = sum_k ker[u - r k] * S(k) * xs[k]   (F.conv_transpose3d)
+// --------------------------------------------------------------------------
+__device__ __forceinline__ void up_range(int u, int K, int r, int n, int &lo, int &hi) {
+  hi = u / r;
+  if (hi > n - 1) hi = n - 1;
+  const int t = u - K + 1;
+  lo = t <= 0 ? 0 : (t + r - 1) / r;
+}
+
+__device__ __forceinline__ float conv_up_sample(const float *__restrict__ xs, const Dim3i &xd,
+                                                const Taps &T, const Scaling &S, int ux, int uy,
+                                                int uz) {
+  int ilo, ihi, jlo, jhi, klo, khi;
+  up_range(ux, T.n[0], T.s[0], xd.x, ilo, ihi);
+  up_range(uy, T.n[1], T.s[1], xd.y, jlo, jhi);
+  up_range(uz, T.n[2], T.s[2], xd.z, klo, khi);
+  float acc = 0.f;
+  for (int i = ilo; i <= ihi; ++i) {
+    const float wi = T.t[0][ux - T.s[0] * i];
+    for (int j = jlo; j <= jhi; ++j) {
+      const float wij = wi * T.t[1][uy - T.s[1] * j];
+      const float *row = xs + ((size_t)i * xd.y + j) * xd.z;
+      for (int k = klo; k <= khi; ++k) {
+        float v = row[k] * (wij * T.t[2][uz - T.s[2] * k]);
+        if (S.dim >= 0) {
+          const int par = (S.dim == 0 ? i : (S.dim == 1 ? j : k)) & 1;
+          v *= par ? S.o : S.e;
+        }
+        acc += v;
+      }
+    }
+  }
+  return acc;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_conv_up(const float *__restrict__ xs, Dim3i xd, Taps T, Scaling S, float *__restrict__ dst,
+              Dim3i gd) {
+  const int k = blockIdx.x * kWave + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int i = blockIdx.z;
+  if (k >= gd.z || j >= gd.y) return;
+  dst[((size_t)i * gd.y + j) * gd.z + k] = conv_up_sample(xs, xd, T, S, i, j, k);
+}
+
+// --------------------------------------------------------------------------
+// push: dst[corner_c(M g)] += alpha * w_c * mask(g) * val(g)   (scatter, f32 atomics)
+// val(g) = src[g]                       (CONVUP = false; regime 1)
+//        = conv_up(S xs)[g]             (CONVUP = true;  regime 2, fuses the
+//                                        transposed conv so the grid-space
+//                                        intermediate never exists in HBM)
+// --------------------------------------------------------------------------
+template <bool CONVUP>
+__global__ void __launch_bounds__(kBlock)
+    k_push(const float *__restrict__ src, Dim3i xd, Taps T, Scaling S, Dim3i gd, Affine A,
+           float *__restrict__ dst, Dim3i dd, float alpha, float tol,
+           const int *__restrict__ done) {
+  if (done && *done) return;
+  const int k = blockIdx.x * kWave + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int i = blockIdx.z;
+  if (k >= gd.z || j >= gd.y) return;
+  float gx, gy, gz;
+  affine_point(A, (float)i, (float)j, (float)k, gx, gy, gz);
+  if (!in_fov(gx, gy, gz, dd, tol)) return;
+  float v;
+  if (CONVUP)
+    v = conv_up_sample(src, xd, T, S, i, j, k);
+  else
+    v = src[((size_t)i * gd.y + j) * gd.z + k];
+  v *= alpha;
+  if (v == 0.f) return;
+  const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+  const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+  const float wx1 = gx - fx, wy1 = gy - fy, wz1 = gz - fz;
+  const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
+  const bool x0 = ix >= 0 && ix < dd.x, x1 = ix + 1 >= 0 && ix + 1 < dd.x;
+  const bool y0 = iy >= 0 && iy < dd.y, y1 = iy + 1 >= 0 && iy + 1 < dd.y;
+  const bool z0 = iz >= 0 && iz < dd.z, z1 = iz + 1 >= 0 && iz + 1 < dd.z;
+  const long long sx = (long long)dd.y * dd.z, sy = dd.z;
+  float *p = dst + ((long long)ix * sx + (long long)iy * sy + iz);
+  if (x0 && y0 && z0) atomicAdd(p, v * (wx0 * wy0 * wz0));
+  if (x0 && y0 && z1) atomicAdd(p + 1, v * (wx0 * wy0 * wz1));
+  if (x0 && y1 && z0) atomicAdd(p + sy, v * (wx0 * wy1 * wz0));
+  if (x0 && y1 && z1) atomicAdd(p + sy + 1, v * (wx0 * wy1 * wz1));
+  if (x1 && y0 && z0) atomicAdd(p + sx, v * (wx1 * wy0 * wz0));
+  if (x1 && y0 && z1) atomicAdd(p + sx + 1, v * (wx1 * wy0 * wz1));
+  if (x1 && y1 && z0) atomicAdd(p + sx + sy, v * (wx1 * wy1 * wz0));
+  if (x1 && y1 && z1) atomicAdd(p + sx + sy + 1, v * (wx1 * wy1 * wz1));
+}
+
+// --------------------------------------------------------------------------
+// conv_down: dst[i,j,k] = S(i,j,k) * sum_abc kx[a]ky[b]kz[c] src[rx i+a, ry j+b, rz k+c]
+// (F.conv3d, cross-correlation, no padding) + _apply_scaling epilogue
+// --------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    k_conv_down(const float *__restrict__ src, Dim3i gd, Taps T, Scaling S,
+                float *__restrict__ dst, Dim3i xd, const int *__restrict__ done) {
+  if (done && *done) return;
+  const int k = blockIdx.x * kWave + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int i = blockIdx.z;
+  if (k >= xd.z || j >= xd.y) return;
+  float acc = 0.f;
+  for (int a = 0; a < T.n[0]; ++a) {
+    for (int b = 0; b < T.n[1]; ++b) {
+      const float wab = T.t[0][a] * T.t[1][b];
+      const float *row = src + ((size_t)(T.s[0] * i + a) * gd.y + (T.s[1] * j + b)) * gd.z +
+                         (size_t)T.s[2] * k;
+      for (int c = 0; c < T.n[2]; ++c) acc += row[c] * (wab * T.t[2][c]);
+    }
+  }
+  if (S.dim >= 0) {
+    const int par = (S.dim == 0 ? i : (S.dim == 1 ? j : k)) & 1;
+    acc *= par ? S.o : S.e;
+  }
+  dst[((size_t)i * xd.y + j) * xd.z + k] = acc;
+}
+
+// --------------------------------------------------------------------------
+// forward differences, zero bound
+// --------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    k_grad(const float *__restrict__ src, Dim3i d, float ivx, float ivy, float ivz,
+           float *__restrict__ dst) {
+  const int k = blockIdx.x * kWave + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int i = blockIdx.z;
+  if (k >= d.z || j >= d.y) return;
+  const size_t n = d.numel();
+  const size_t idx = ((size_t)i * d.y + j) * d.z + k;
+  const float c = src[idx];
+  const float xn = i + 1 < d.x ? src[idx + (size_t)d.y * d.z] : 0.f;
+  const float yn = j + 1 < d.y ? src[idx + d.z] : 0.f;
+  const float zn = k + 1 < d.z ? src[idx + 1] : 0.f;
+  dst[idx] = (xn - c) * ivx;
+  dst[n + idx] = (yn - c) * ivy;
+  dst[2 * n + idx] = (zn - c) * ivz;
+}
+
+// dst = beta*dst_in + scale * Dt(u), u = a*src_a (+ b*src_b if src_b != NULL)
+__global__ void __launch_bounds__(kBlock)
+    k_div(const float *__restrict__ ua, const float *__restrict__ ub, float ca, float cb, Dim3i d,
+          float ivx, float ivy, float ivz, float scale, float *__restrict__ dst) {
+  const int k = blockIdx.x * kWave + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int i = blockIdx.z;
+  if (k >= d.z || j >= d.y) return;
+  const size_t n = d.numel();
+  const size_t idx = ((size_t)i * d.y + j) * d.z + k;
+  const size_t sx = (size_t)d.y * d.z, sy = d.z;
+  auto U = [&](size_t off) -> float {
+    float v = ca * ua[off];
+    if (ub) v += cb * ub[off];
+    return v;
+  };
+  float acc = 0.f;
+  acc += ((i > 0 ? U(idx - sx) : 0.f) - U(idx)) * ivx;
+  acc += ((j > 0 ? U(n + idx - sy) : 0.f) - U(n + idx)) * ivy;
+  acc += ((k > 0 ? U(2 * n + idx - 1) : 0.f) - U(2 * n + idx)) * ivz;
+  dst[idx] = scale * acc;
+}
+
+// dst = a*src + c*DtD(src): 7-point stencil with Neumann row at 0 and Dirichlet
+// row at n-1 along every axis.  Optional fused float64 partial of sum(src*dst).
+template <bool DOT>
+__global__ void __launch_bounds__(kBlock)
+    k_dtd(const float *__restrict__ src, Dim3i d, float cx, float cy, float cz, float a,
+          float *__restrict__ dst, double *__restrict__ partials,
+          const int *__restrict__ done) {
+  if (done && *done) return;
+  // tiles of 4 y-rows x 64 z; a bounded grid (<= kMaxPartials blocks) strides over them
+  const int tz = (d.z + kWave - 1) / kWave, ty = (d.y + 3) / 4;
+  const long long ntiles = (long long)tz * ty * d.x;
+  const size_t sx = (size_t)d.y * d.z, sy = d.z;
+  double prod = 0.0;
+  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int kc = (int)(t % tz);
+    const long long t2 = t / tz;
+    const int jq = (int)(t2 % ty);
+    const int i = (int)(t2 / ty);
+    const int k = kc * kWave + threadIdx.x;
+    const int j = jq * 4 + threadIdx.y;
+    if (k < d.z && j < d.y) {
+      const size_t idx = ((size_t)i * d.y + j) * d.z + k;
+      const float c = src[idx];
+      const float xf = (i + 1 < d.x ? src[idx + sx] : 0.f) - c;
+      const float xb = i > 0 ? c - src[idx - sx] : 0.f;
+      const float yf = (j + 1 < d.y ? src[idx + sy] : 0.f) - c;
+      const float yb = j > 0 ? c - src[idx - sy] : 0.f;
+      const float zf = (k + 1 < d.z ? src[idx + 1] : 0.f) - c;
+      const float zb = k > 0 ? c - src[idx - 1] : 0.f;
+      const float q = a * c + (cx * (xb - xf) + cy * (yb - yf) + cz * (zb - zf));
+      dst[idx] = q;
+      if (DOT) prod += (double)__fmul_rn(c, q);
+    }
+  }
+  if (DOT) {
+    const double tot = block_sum(prod);
+    if (threadIdx.x == 0 && threadIdx.y == 0) partials[blockIdx.x] = tot;
+  }
+}
+
+// --------------------------------------------------------------------------
+// host launchers
+// --------------------------------------------------------------------------
+void launch_pull(const float *src, Dim3i sd, const Affine &A, float *dst, Dim3i gd, float tol,
+                 const int *done, hipStream_t st) {
+  hipLaunchKernelGGL(k_pull, vol_grid(gd), vol_block(), 0, st, src, sd, A, dst, gd, tol, done);
+}
+
+void launch_push(const float *src, Dim3i gd, const Affine &A, float *dst, Dim3i dd, float alpha,
+                 float tol, const int *done, hipStream_t st) {
+  Taps T{};
+  Scaling S{1.f, 1.f, -1};
+  hipLaunchKernelGGL(k_push<false>, vol_grid(gd), vol_block(), 0, st, src, gd, T, S, gd, A, dst,
+                     dd, alpha, tol, done);
+}
+
+void launch_push_convup(const float *xs, Dim3i xd, const Taps &T, const Scaling &S, Dim3i gd,
+                        const Affine &A, float *dst, Dim3i dd, float alpha, float tol,
+                        const int *done, hipStream_t st) {
+  hipLaunchKernelGGL(k_push<true>, vol_grid(gd), vol_block(), 0, st, xs, xd, T, S, gd, A, dst, dd,
+                     alpha, tol, done);
+}
+
+void launch_conv_down(const float *src, Dim3i gd, const Taps &T, const Scaling &S, float *dst,
+                      Dim3i xd, const int *done, hipStream_t st) {
+  hipLaunchKernelGGL(k_conv_down, vol_grid(xd), vol_block(), 0, st, src, gd, T, S, dst, xd, done);
+}
+
+void launch_conv_up(const float *xs, Dim3i xd, const Taps &T, const Scaling &S, float *dst,
+                    Dim3i gd, hipStream_t st) {
+  hipLaunchKernelGGL(k_conv_up, vol_grid(gd), vol_block(), 0, st, xs, xd, T, S, dst, gd);
+}
+
+void launch_grad(const float *src, Dim3i d, const float vx[3], float *dst3, hipStream_t st) {
+  hipLaunchKernelGGL(k_grad, vol_grid(d), vol_block(), 0, st, src, d, 1.f / vx[0], 1.f / vx[1],
+                     1.f / vx[2], dst3);
+}
+
+void launch_div(const float *ua, const float *ub, float ca, float cb, Dim3i d, const float vx[3],
+                float scale, float *dst, hipStream_t st) {
+  hipLaunchKernelGGL(k_div, vol_grid(d), vol_block(), 0, st, ua, ub, ca, cb, d, 1.f / vx[0],
+                     1.f / vx[1], 1.f / vx[2], scale, dst);
+}
+
+int dtd_num_blocks(Dim3i d) {
+  const long long ntiles = (long long)((d.z + kWave - 1) / kWave) * ((d.y + 3) / 4) * d.x;
+  return (int)(ntiles < kMaxPartials ? ntiles : kMaxPartials);
+}
+
+// partials (nullable) must hold dtd_num_blocks(d) doubles.
+void launch_dtd(const float *src, Dim3i d, const float vx[3], float a, float c, float *dst,
+                double *partials, const int *done, hipStream_t st) {
+  const float cx = c / (vx[0] * vx[0]), cy = c / (vx[1] * vx[1]), cz = c / (vx[2] * vx[2]);
+  const dim3 grid(dtd_num_blocks(d));
+  if (partials)
+    hipLaunchKernelGGL(k_dtd<true>, grid, vol_block(), 0, st, src, d, cx, cy, cz, a, dst,
+                       partials, done);
+  else
+    hipLaunchKernelGGL(k_dtd<false>, grid, vol_block(), 0, st, src, d, cx, cy, cz, a, dst,
+                       partials, done);
+}
+
+}  // namespace unires

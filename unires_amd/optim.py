@@ -1,0 +1,36 @@
+"""nitorch.core.optim-shaped entry points used by UniRes
+(cg: unires/_update.py:9,142-148; get_gain: unires/run.py:7,100)."""
+import torch
+
+
+def get_gain(obj, monotonicity='increasing'):
+    """Normalised gain of the last objective value (host-side scalar logic)."""
+    obj = torch.as_tensor(obj, dtype=torch.float64)
+    if len(obj) <= 1:
+        return torch.tensor(float('inf'), dtype=torch.float64)
+    gain = obj[-1] - obj[-2] if monotonicity == 'increasing' else obj[-2] - obj[-1]
+    return gain / (torch.max(obj) - torch.min(obj))
+
+
+def cg(A, b, x=None, precond=None, max_iter=None, tolerance=1e-5, verbose=False,
+       sum_dtype=torch.float64, inplace=True, stop='E', rho=1.0, lam=1.0):
+    """Solve A x = b by conjugate gradients, entirely on the device.
+
+    ``A`` is a :class:`unires_amd._plan.ChannelPlan` (the fused
+    ``sum tau AtA + rho lam^2 DtD`` of one channel) instead of a Python callable:
+    the whole iteration - matvec, float64 dots, alpha/beta, objective and the
+    ``|gain| < tolerance`` test - is enqueued without host round trips.
+    """
+    if precond is not None:
+        raise NotImplementedError('the reference runs with the identity preconditioner '
+                                  '(unires/_update.py:136-137)')
+    if sum_dtype != torch.float64:
+        raise NotImplementedError('dot products accumulate in float64')
+    if max_iter is None:
+        max_iter = 4096
+    if x is None:
+        x = torch.zeros_like(b)
+    elif not inplace:
+        x = x.clone()
+    A.cg(b, x, rho, lam, max_iter=max_iter, tolerance=tolerance, stop=stop, sync=True)
+    return x

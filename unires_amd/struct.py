@@ -1,0 +1,81 @@
+"""Data structures the hot path reads - counterparts of unires/struct.py:4-111.
+
+Only the fields the y-update path touches carry meaning here; the rest of the
+reference's ``settings`` (I/O, registration, plotting) is out of scope.
+"""
+
+
+class _input:
+    """One observed image (unires/struct.py:4-22)."""
+
+    def __init__(self, dat=None, mat=None, tau=1.0, po=None):
+        self.dat = dat      # (X,Y,Z) float32 device tensor
+        self.dim = None if dat is None else tuple(dat.shape)
+        self.mat = mat      # (4,4) float64 affine
+        self.tau = tau      # noise precision
+        self.po = po        # _proj_op
+        self.ct = False
+        self.mu = 1.0
+        self.sd = 1.0
+        self.rigid_q = None
+
+
+class _output:
+    """One reconstructed channel (unires/struct.py:25-33)."""
+
+    def __init__(self, dat=None, mat=None, lam=None):
+        self.dat = dat      # (X,Y,Z) float32 device tensor, updated in place by the CG
+        self.dim = None if dat is None else tuple(dat.shape)
+        self.mat = mat
+        self.lam = lam
+        self.lam0 = lam
+
+
+class _proj_op:
+    """Projection-operator descriptor (unires/struct.py:36-54)."""
+
+    def __init__(self):
+        self.dim_x = None
+        self.mat_x = None
+        self.vx_x = None
+        self.dim_y = None
+        self.mat_y = None
+        self.vx_y = None
+        self.dim_yx = None
+        self.mat_yx = None
+        self.ratio = None
+        self.smo_ker = None     # dense (1,1,kx,ky,kz) float32, as the reference stores it
+        self.smo_ker_1d = None  # its separable factors (what the kernels consume)
+        self.rigid = None
+        self.scl = None
+        self.dim_thick = None
+        self.D_x = None
+        self.D_y = None
+
+
+class settings:
+    """The subset of unires/struct.py:57-111 that reaches the hot path
+    (SURVEY.md Appendix A), same names and defaults."""
+
+    def __init__(self):
+        self.alpha = 1.0
+        self.bound = 'zero'
+        self.cgs_max_iter = 20
+        self.cgs_tol = 1e-3
+        self.cgs_verbose = False
+        self.device = 'cuda'
+        self.diff = 'forward'
+        self.do_proj = None
+        self.gap = 0.0
+        self.interpolation = 'linear'
+        self.method = None
+        self.profile_ip = 2
+        self.profile_tp = 0
+        self.reg_scl = 4.0
+        self.rho = None
+        self.rho_scl = 1.0
+        self.tolerance = 1e-4
+        self.do_print = 0
+        # build-side knob: which nitorch-cg objective branch to reproduce
+        # ('max_gain' = what the reference passes, unires/_update.py:145)
+        self.cgs_stop = 'max_gain'
