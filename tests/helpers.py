@@ -5,6 +5,7 @@ import math
 import torch
 
 from oracle import unires_restated as O
+from oracle.nitorch_restated import affine_grid as N_affine_grid
 
 
 def rigid_matrix(t, r):
@@ -34,6 +35,21 @@ def smooth_volume(dim, gen, scale):
     return (v * scale).float()
 
 
+def fov_margin(po, method):
+    """Smallest distance of any grid coordinate to the +-5e-2 in-FOV thresholds.
+    The reference's mask is discontinuous there: a coordinate that ties with a
+    threshold in float32 flips with the last-ulp rounding of the coordinate
+    arithmetic (torch-CPU matmul vs cuBLAS vs FMA), so parity problems are drawn
+    away from such ties."""
+    mat, dim = O.proj_matrix(po, method)
+    g = N_affine_grid(mat.float(), dim)
+    m = float('inf')
+    for d, n in enumerate(po.dim_y):
+        for thr in (-5e-2, n - 1 + 5e-2):
+            m = min(m, (g[..., d] - thr).abs().min().item())
+    return m
+
+
 def make_problem(dim_y=(16, 14, 12), n_channels=1, thick=3, seed=0, scl=0.0, regime='sr',
                  n_repeats=1, vx_y=1.0, rot=0.05, trans=0.7, noise_sd=20.0, prof_tp=0,
                  prof_ip=0, thick_axes=None, aniso=None):
@@ -53,8 +69,25 @@ def make_problem(dim_y=(16, 14, 12), n_channels=1, thick=3, seed=0, scl=0.0, reg
     for c in range(C):
         reps = []
         for n in range(n_repeats):
-            u = torch.rand(6, generator=gen) * 2 - 1
-            rigid = rigid_matrix((u[:3] * trans).tolist(), (u[3:] * rot).tolist())
+            for _attempt in range(20):
+                u = torch.rand(6, generator=gen) * 2 - 1
+                rigid = rigid_matrix((u[:3] * trans).tolist(), (u[3:] * rot).tolist())
+                if regime == 'id':
+                    break
+                if regime == 'sr':
+                    ax_ = (thick_axes[c] if thick_axes is not None else (2 - c - n) % 3)
+                    sc_ = [1.0, 1.0, 1.0]
+                    sc_[ax_] = float(thick)
+                    mx_ = mat_y @ torch.diag(torch.tensor(sc_ + [1.0], dtype=torch.float64))
+                    dx_ = tuple(int(math.floor(d / s_)) for d, s_ in zip(dim_y, sc_))
+                    po_ = O.proj_info(dim_y, mat_y, dx_, mx_, rigid=rigid, prof_ip=prof_ip,
+                                      prof_tp=prof_tp)
+                    if fov_margin(po_, 'super-resolution') > 1e-4:
+                        break
+                else:
+                    po_ = O.proj_info(dim_y, mat_y, dim_y, mat_y, rigid=rigid)
+                    if fov_margin(po_, 'denoising') > 1e-4:
+                        break
             if regime == 'sr':
                 ax = (thick_axes[c] if thick_axes is not None else (2 - c - n) % 3)
                 scale = [1.0, 1.0, 1.0]
