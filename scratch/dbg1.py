@@ -1,5 +1,5 @@
 import torch, sys
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.helpers import *
 from tests.test_gpu_path import CASES
 from oracle import nitorch_restated as N, unires_restated as O

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "cg.hpp"
+#include "fused.hpp"
 #include "ops.hpp"
 
 using namespace unires;
@@ -70,6 +71,44 @@ static Scaling make_scaling(float scl, int dim) {
   return Scaling{expf(scl), expf(-scl), dim};
 }
 
+// inverse of a row-major 3x4 float32 affine, computed in double
+static bool invert_affine(const Affine &A, Affine &out) {
+  const double a = A.m[0], b = A.m[1], c = A.m[2], d = A.m[4], e = A.m[5], f = A.m[6],
+               g = A.m[8], h = A.m[9], i = A.m[10];
+  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  if (!(fabs(det) > 1e-12)) return false;
+  const double inv[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
+                         (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                         (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+  const double t[3] = {A.m[3], A.m[7], A.m[11]};
+  for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < 3; ++k) out.m[4 * r + k] = (float)inv[3 * r + k];
+    out.m[4 * r + 3] = (float)-(inv[3 * r] * t[0] + inv[3 * r + 1] * t[1] + inv[3 * r + 2] * t[2]);
+  }
+  return true;
+}
+
+// Drop leading/trailing zero taps (nitorch's rect profile carries one on each
+// side): the skipped grid voxels contribute exactly 0, so A is unchanged; the
+// grid shrinks and its affine is shifted by the number of leading zeros.
+static void trim_taps(const Taps &T, const Affine &A, const Dim3i &gd, Taps &Tt, Affine &At,
+                      Dim3i &gdt) {
+  Tt = T;
+  At = A;
+  int g[3] = {gd.x, gd.y, gd.z};
+  for (int d = 0; d < 3; ++d) {
+    int lead = 0, trail = 0;
+    while (lead < T.n[d] - 1 && T.t[d][lead] == 0.f) ++lead;
+    while (trail < T.n[d] - 1 - lead && T.t[d][T.n[d] - 1 - trail] == 0.f) ++trail;
+    Tt.n[d] = T.n[d] - lead - trail;
+    for (int i = 0; i < UNIRES_MAX_TAPS; ++i) Tt.t[d][i] = i < Tt.n[d] ? T.t[d][lead + i] : 0.f;
+    g[d] -= lead + trail;
+    for (int r = 0; r < 3; ++r)
+      At.m[4 * r + 3] = (float)((double)At.m[4 * r + 3] + (double)lead * (double)A.m[4 * r + d]);
+  }
+  gdt = Dim3i{g[0], g[1], g[2]};
+}
+
 static int check_conv_dims(const Dim3i &hi, const Dim3i &lo, const Taps &T) {
   const int h[3] = {hi.x, hi.y, hi.z}, l[3] = {lo.x, lo.y, lo.z};
   for (int d = 0; d < 3; ++d)
@@ -103,9 +142,19 @@ extern "C" int unires_push3d_affine(const float *src, const int32_t gdim[3], con
   if (!dims_ok(ddim) || !dims_ok(gdim)) return fail(UNIRES_ERR_DIM, "bad dimensions");
   Affine A;
   memcpy(A.m, M, sizeof(A.m));
-  hipStream_t st = (hipStream_t)stream;
-  if (!accumulate) HIP_TRY(hipMemsetAsync(dst, 0, mk(ddim).numel() * sizeof(float), st));
-  launch_push(src, mk(gdim), A, dst, mk(ddim), alpha, fov_tol, nullptr, st);
+  Affine Ainv;
+  if (!invert_affine(A, Ainv)) return fail(UNIRES_ERR_ARG, "singular affine");
+  PushSrc ps;
+  memset(&ps, 0, sizeof(ps));
+  ps.data = src;
+  ps.gd = mk(gdim);
+  ps.S = Scaling{1.f, 1.f, -1};
+  PushEpilogue ep;
+  ep.accumulate = accumulate ? 1 : 0;
+  SplatSafety safe;
+  splat_safety(A, safe.row_sep, safe.use_atomics);
+  (void)launch_push_tile(ps, A, Ainv, safe, alpha, fov_tol, ep, dst, mk(ddim), nullptr,
+                         (hipStream_t)stream);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -188,6 +237,11 @@ struct Repeat {
   float scl;
   int dim_thick;
   float tau;
+  // fused path: zero taps trimmed, grid shifted accordingly, inverse affine
+  Dim3i dim_gf;
+  Affine Af, Afinv;
+  Taps Tf;
+  SplatSafety safe;  // of Af (the linear part is the same for A)
 };
 
 struct unires_plan {
@@ -234,7 +288,11 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
   } else {
     if (out.dim_g.x != out.dim_x.x || out.dim_g.y != out.dim_x.y || out.dim_g.z != out.dim_x.z)
       return fail(UNIRES_ERR_DIM, "denoising regime needs dim_g == dim_x");
+    for (int d = 0; d < 3; ++d) out.T.n[d] = out.T.s[d] = 1, out.T.t[d][0] = 1.f;
   }
+  trim_taps(out.T, out.A, out.dim_g, out.Tf, out.Af, out.dim_gf);
+  if (!invert_affine(out.Af, out.Afinv)) return fail(UNIRES_ERR_ARG, "singular affine");
+  splat_safety(out.Af, out.safe.row_sep, out.safe.use_atomics);
   return UNIRES_OK;
 }
 
@@ -333,33 +391,60 @@ extern "C" int64_t unires_plan_workspace_bytes(const unires_plan_t *plan) {
 // --------------------------------------------------------------------------
 // operators
 // --------------------------------------------------------------------------
-// out (+)= alpha * AtA_n(in) for regimes 1/2 ("accumulate" into an initialised out)
-static void ata_accumulate(unires_plan *pl, const Repeat &R, const float *in, float *out,
-                           float alpha, const int *done, hipStream_t st) {
+static PushSrc push_src(const Repeat &R, const float *data, bool convup, float scl) {
+  PushSrc src;
+  src.data = data;
+  src.convup = convup ? 1 : 0;
+  src.xd = R.dim_x;
+  src.gd = convup ? R.dim_gf : R.dim_g;
+  src.T = R.Tf;
+  src.S = make_scaling(scl, R.dim_thick);
+  return src;
+}
+
+// x-space intermediate of AtA: xbuf = S(2 scl) conv_down pull(in)  (regime 2) or
+// gbuf = pull(in) (regime 1); returns the push source that finishes the operator.
+static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, const int *done,
+                           hipStream_t st) {
   if (pl->regime == UNIRES_REGIME_DENOISE) {
     launch_pull(in, pl->dy, R.A, pl->gbuf, R.dim_g, pl->fov_tol, done, st);
-    launch_push(pl->gbuf, R.dim_g, R.A, out, pl->dy, alpha, pl->fov_tol, done, st);
-  } else {
+    return push_src(R, pl->gbuf, false, 0.f);
+  }
+  // S(2 scl) once between conv and conv^T  (unires/_project.py:175-177)
+  const Scaling S2 = make_scaling(2.f * R.scl, R.dim_thick);
+  if (launch_pull_conv(in, pl->dy, R.Af, R.Tf, S2, pl->xbuf, R.dim_x, R.dim_gf, pl->fov_tol, done,
+                       st)) {
     launch_pull(in, pl->dy, R.A, pl->gbuf, R.dim_g, pl->fov_tol, done, st);
-    // S(2 scl) once between conv and conv^T  (unires/_project.py:175-177)
-    launch_conv_down(pl->gbuf, R.dim_g, R.T, make_scaling(2.f * R.scl, R.dim_thick), pl->xbuf,
-                     R.dim_x, done, st);
-    launch_push_convup(pl->xbuf, R.dim_x, R.T, Scaling{1.f, 1.f, -1}, R.dim_g, R.A, out, pl->dy,
-                       alpha, pl->fov_tol, done, st);
+    launch_conv_down(pl->gbuf, R.dim_g, R.T, S2, pl->xbuf, R.dim_x, done, st);
+  }
+  return push_src(R, pl->xbuf, true, 0.f);
+}
+
+// out = [out +] alpha * push(src) [+ epilogue]; falls back to a materialised conv_up when
+// the conv_up fan-in is beyond what the fused kernel tabulates.
+static void push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float alpha,
+                     const PushEpilogue &ep, float *out, const int *done, hipStream_t st) {
+  const Affine &A = src.convup ? R.Af : R.A;
+  if (launch_push_tile(src, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st)) {
+    launch_conv_up(src.data, src.xd, src.T, src.S, pl->gbuf, src.gd, st);
+    PushSrc d = src;
+    d.data = pl->gbuf;
+    d.convup = 0;
+    (void)launch_push_tile(d, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st);
   }
 }
 
 // out (+)= alpha * At_n(x)
 static void at_accumulate(unires_plan *pl, const Repeat &R, const float *x, float *out, float alpha,
-                          hipStream_t st) {
+                          bool accumulate, hipStream_t st) {
   if (pl->regime == UNIRES_REGIME_IDENTITY) {
-    launch_axpy(alpha, x, out, pl->dy.numel(), st);
-  } else if (pl->regime == UNIRES_REGIME_DENOISE) {
-    launch_push(x, R.dim_g, R.A, out, pl->dy, alpha, pl->fov_tol, nullptr, st);
-  } else {
-    launch_push_convup(x, R.dim_x, R.T, make_scaling(R.scl, R.dim_thick), R.dim_g, R.A, out,
-                       pl->dy, alpha, pl->fov_tol, nullptr, st);
+    launch_axpy(alpha, x, out, pl->dy.numel(), st);  // caller initialised out
+    return;
   }
+  PushEpilogue ep;
+  ep.accumulate = accumulate ? 1 : 0;
+  const bool sr = pl->regime == UNIRES_REGIME_SUPERRES;
+  push_any(pl, push_src(R, x, sr, sr ? R.scl : 0.f), R, alpha, ep, out, nullptr, st);
 }
 
 extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, const float *in,
@@ -384,12 +469,11 @@ extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, con
       launch_conv_down(plan->gbuf, R.dim_g, R.T, make_scaling(R.scl, R.dim_thick), out, R.dim_x,
                        nullptr, st);
     }
+  } else if (op == UNIRES_OP_AT) {
+    at_accumulate(plan, R, in, out, 1.f, false, st);
   } else {
-    HIP_TRY(hipMemsetAsync(out, 0, ny * sizeof(float), st));
-    if (op == UNIRES_OP_AT)
-      at_accumulate(plan, R, in, out, 1.f, st);
-    else
-      ata_accumulate(plan, R, in, out, 1.f, nullptr, st);
+    const PushSrc src = ata_forward(plan, R, in, nullptr, st);
+    push_any(plan, src, R, 1.f, PushEpilogue(), out, nullptr, st);
   }
   CHECK_LAUNCH();
   return UNIRES_OK;
@@ -406,11 +490,23 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
     launch_dtd(p, pl->dy, pl->vx, a0, c, q, part, done, st);
     return part ? dtd_num_blocks(pl->dy) : 0;
   }
-  launch_dtd(p, pl->dy, pl->vx, 0.f, c, q, nullptr, done, st);
-  for (const Repeat &R : pl->reps) ata_accumulate(pl, R, p, q, R.tau, done, st);
-  if (!part) return 0;
-  launch_dot(p, q, pl->dy.numel(), part, done, st);
-  return vec_num_blocks(pl->dy.numel());
+  // regimes 1/2: two kernels per repeat; the last one also adds c DtD p and the dot
+  const size_t nrep = pl->reps.size();
+  for (size_t n = 0; n < nrep; ++n) {
+    const Repeat &R = pl->reps[n];
+    const PushSrc src = ata_forward(pl, R, p, done, st);
+    PushEpilogue ep;
+    ep.p = p;
+    ep.accumulate = n > 0;
+    if (n == 0) {  // the stencil term goes in once
+      ep.cx = c / (pl->vx[0] * pl->vx[0]);
+      ep.cy = c / (pl->vx[1] * pl->vx[1]);
+      ep.cz = c / (pl->vx[2] * pl->vx[2]);
+    }
+    if (n + 1 == nrep) ep.partials = part;
+    push_any(pl, src, R, R.tau, ep, q, done, st);
+  }
+  return part ? push_tile_blocks(pl->dy) : 0;
 }
 
 extern "C" int unires_ata_matvec(unires_plan_t *plan, float rho, float lam, const float *p,
@@ -435,7 +531,7 @@ extern "C" int unires_rhs_assemble(unires_plan_t *plan, const float *const *x_pt
   launch_div(w_c, z_c, 1.f, -rho, plan->dy, plan->vx, -lam, b, st);
   // b += tau_n At_n x_n         (unires/_update.py:125-128)
   for (size_t n = 0; n < plan->reps.size(); ++n)
-    at_accumulate(plan, plan->reps[n], x_ptrs[n], b, plan->reps[n].tau, st);
+    at_accumulate(plan, plan->reps[n], x_ptrs[n], b, plan->reps[n].tau, true, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }

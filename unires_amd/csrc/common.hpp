@@ -9,7 +9,7 @@ namespace unires {
 
 constexpr int kWave = 64;           // CDNA wavefront
 constexpr int kBlock = 256;         // 4 waves, one per SIMD
-constexpr int kMaxPartials = 1024;  // blocks of a dot-producing kernel (<= this)
+constexpr int kMaxPartials = 2048;  // blocks of a dot-producing kernel (<= this)
 
 struct Dim3i {
   int x, y, z;
@@ -68,6 +68,133 @@ __device__ __forceinline__ void affine_point(const Affine &A, float i, float j, 
 __device__ __forceinline__ bool in_fov(float gx, float gy, float gz, const Dim3i &d, float tol) {
   return gx > -tol && gx < (float)(d.x - 1) + tol && gy > -tol && gy < (float)(d.y - 1) + tol &&
          gz > -tol && gz < (float)(d.z - 1) + tol;
+}
+
+// Trilinear sample of src at voxel coordinate (gx,gy,gz): zero bound + in-FOV mask
+// (nitorch grid_pull linear / zero / extrapolate=False).
+// Split in two so callers can issue the loads of SEVERAL samples before consuming any
+// (these kernels are latency-bound unless many loads are in flight per lane).
+//   pull_issue : 4 unconditional 8-byte loads (z-adjacent corner pairs, addresses
+//                clamped into the volume)
+//   pull_finish: weights (zero for out-of-bound corners / out-of-FOV samples) and sum
+struct PullLoads {
+  float2 v00, v01, v10, v11;  // (x0,y0) (x0,y1) (x1,y0) (x1,y1) rows, z pair
+  float wx0, wx1, wy0, wy1, wz0, wz1;
+};
+
+__device__ __forceinline__ float2 ld_pair(const float *p) {
+  // 4-byte aligned 8-byte load (gfx950 global memory allows unaligned dwordx2)
+  float2 v;
+  __builtin_memcpy(&v, p, sizeof(v));
+  return v;
+}
+
+__device__ __forceinline__ void pull_issue(const float *__restrict__ src, const Dim3i &sd,
+                                           float gx, float gy, float gz, float tol,
+                                           PullLoads &L) {
+  const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+  const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+  float wx1 = gx - fx, wy1 = gy - fy, wz1 = gz - fz;
+  float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
+  const float m = in_fov(gx, gy, gz, sd, tol) ? 1.f : 0.f;
+  L.wx0 = (ix >= 0 && ix < sd.x) ? wx0 * m : 0.f;
+  L.wx1 = (ix + 1 >= 0 && ix + 1 < sd.x) ? wx1 * m : 0.f;
+  L.wy0 = (iy >= 0 && iy < sd.y) ? wy0 : 0.f;
+  L.wy1 = (iy + 1 >= 0 && iy + 1 < sd.y) ? wy1 : 0.f;
+  // z pair (b, b+1) with b clamped into [0, nz-2]; remap the weights onto the pair
+  const int b = min(max(iz, 0), max(sd.z - 2, 0));
+  wz0 = (iz >= 0 && iz < sd.z) ? wz0 : 0.f;
+  wz1 = (iz + 1 >= 0 && iz + 1 < sd.z) ? wz1 : 0.f;
+  // pair.x holds index b, pair.y index b+1:  iz==b -> (wz0,wz1); iz==b-1 -> z1 is b -> (wz1,0);
+  // iz==b+1 -> z0 is b+1 -> (0,wz0); anything else has both weights zero already
+  L.wz0 = iz == b ? wz0 : (iz == b - 1 ? wz1 : 0.f);
+  L.wz1 = iz == b ? wz1 : (iz == b + 1 ? wz0 : 0.f);
+  const int cx0 = min(max(ix, 0), sd.x - 1), cx1 = min(max(ix + 1, 0), sd.x - 1);
+  const int cy0 = min(max(iy, 0), sd.y - 1), cy1 = min(max(iy + 1, 0), sd.y - 1);
+  const float *r00 = src + ((size_t)cx0 * sd.y + cy0) * sd.z + b;
+  const float *r01 = src + ((size_t)cx0 * sd.y + cy1) * sd.z + b;
+  const float *r10 = src + ((size_t)cx1 * sd.y + cy0) * sd.z + b;
+  const float *r11 = src + ((size_t)cx1 * sd.y + cy1) * sd.z + b;
+  if (sd.z >= 2) {
+    L.v00 = ld_pair(r00), L.v01 = ld_pair(r01), L.v10 = ld_pair(r10), L.v11 = ld_pair(r11);
+  } else {  // single-slice volume: no pair to load
+    L.v00 = make_float2(*r00, 0.f), L.v01 = make_float2(*r01, 0.f);
+    L.v10 = make_float2(*r10, 0.f), L.v11 = make_float2(*r11, 0.f);
+  }
+}
+
+__device__ __forceinline__ float pull_finish(const PullLoads &L) {
+  float acc = L.v00.x * (L.wx0 * L.wy0 * L.wz0);
+  acc += L.v00.y * (L.wx0 * L.wy0 * L.wz1);
+  acc += L.v01.x * (L.wx0 * L.wy1 * L.wz0);
+  acc += L.v01.y * (L.wx0 * L.wy1 * L.wz1);
+  acc += L.v10.x * (L.wx1 * L.wy0 * L.wz0);
+  acc += L.v10.y * (L.wx1 * L.wy0 * L.wz1);
+  acc += L.v11.x * (L.wx1 * L.wy1 * L.wz0);
+  acc += L.v11.y * (L.wx1 * L.wy1 * L.wz1);
+  return acc;
+}
+
+__device__ __forceinline__ float pull_sample(const float *__restrict__ src, const Dim3i &sd,
+                                             float gx, float gy, float gz, float tol) {
+  PullLoads L;
+  pull_issue(src, sd, gx, gy, gz, tol, L);
+  return pull_finish(L);
+}
+
+// (c . DtD p)[i,j,k] with per-axis weights cx,cy,cz = c/vx^2: forward differences, zero
+// bound -> rows [1,-1] at 0, [-1,2,-1] inside, [-1,2] at n-1.  Loads are unconditional
+// (clamped addresses) so the 7 of them issue together; `pc` returns the centre value.
+__device__ __forceinline__ float dtd_at(const float *__restrict__ p, size_t idx, int i, int j,
+                                        int k, const Dim3i &d, float cx, float cy, float cz,
+                                        float &pc) {
+  const size_t sx = (size_t)d.y * d.z, sy = d.z;
+  const bool hx = i + 1 < d.x, lx = i > 0, hy = j + 1 < d.y, ly = j > 0, hz = k + 1 < d.z,
+             lz = k > 0;
+  const float c = p[idx];
+  const float vxp = p[hx ? idx + sx : idx], vxm = p[lx ? idx - sx : idx];
+  const float vyp = p[hy ? idx + sy : idx], vym = p[ly ? idx - sy : idx];
+  const float vzp = p[hz ? idx + 1 : idx], vzm = p[lz ? idx - 1 : idx];
+  const float xf = (hx ? vxp : 0.f) - c, xb = lx ? c - vxm : 0.f;
+  const float yf = (hy ? vyp : 0.f) - c, yb = ly ? c - vym : 0.f;
+  const float zf = (hz ? vzp : 0.f) - c, zb = lz ? c - vzm : 0.f;
+  pc = c;
+  return cx * (xb - xf) + cy * (yb - yf) + cz * (zb - zf);
+}
+
+// conv_transpose index range: all k with 0 <= u - r*k < K and 0 <= k < n
+__device__ __forceinline__ void up_range(int u, int K, int r, int n, int &lo, int &hi) {
+  hi = u / r;
+  if (hi > n - 1) hi = n - 1;
+  const int t = u - K + 1;
+  lo = t <= 0 ? 0 : (t + r - 1) / r;
+}
+
+// conv_up gather: h[u] = sum_k ker[u - r k] * S(k) * xs[k]   (F.conv_transpose3d)
+__device__ __forceinline__ float conv_up_sample(const float *__restrict__ xs, const Dim3i &xd,
+                                                const Taps &T, const Scaling &S, int ux, int uy,
+                                                int uz) {
+  int ilo, ihi, jlo, jhi, klo, khi;
+  up_range(ux, T.n[0], T.s[0], xd.x, ilo, ihi);
+  up_range(uy, T.n[1], T.s[1], xd.y, jlo, jhi);
+  up_range(uz, T.n[2], T.s[2], xd.z, klo, khi);
+  float acc = 0.f;
+  for (int i = ilo; i <= ihi; ++i) {
+    const float wi = T.t[0][ux - T.s[0] * i];
+    for (int j = jlo; j <= jhi; ++j) {
+      const float wij = wi * T.t[1][uy - T.s[1] * j];
+      const float *row = xs + ((size_t)i * xd.y + j) * xd.z;
+      for (int k = klo; k <= khi; ++k) {
+        float v = row[k] * (wij * T.t[2][uz - T.s[2] * k]);
+        if (S.dim >= 0) {
+          const int par = (S.dim == 0 ? i : (S.dim == 1 ? j : k)) & 1;
+          v *= par ? S.o : S.e;
+        }
+        acc += v;
+      }
+    }
+  }
+  return acc;
 }
 
 }  // namespace unires

@@ -18,77 +18,27 @@ static inline dim3 vol_grid(const Dim3i &d) {
 // pull: dst[g] = mask(g) * sum_8 w_c * src[corner_c(M g)]
 // (nitorch grid_pull linear / zero / extrapolate=False)
 // --------------------------------------------------------------------------
-__device__ __forceinline__ float pull_sample(const float *__restrict__ src, const Dim3i &sd,
-                                             float gx, float gy, float gz, float tol) {
-  if (!in_fov(gx, gy, gz, sd, tol)) return 0.f;
-  const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
-  const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-  const float wx1 = gx - fx, wy1 = gy - fy, wz1 = gz - fz;
-  const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
-  const bool x0 = ix >= 0 && ix < sd.x, x1 = ix + 1 >= 0 && ix + 1 < sd.x;
-  const bool y0 = iy >= 0 && iy < sd.y, y1 = iy + 1 >= 0 && iy + 1 < sd.y;
-  const bool z0 = iz >= 0 && iz < sd.z, z1 = iz + 1 >= 0 && iz + 1 < sd.z;
-  const long long sx = (long long)sd.y * sd.z, sy = sd.z;
-  const float *p = src + ((long long)ix * sx + (long long)iy * sy + iz);
-  float acc = 0.f;
-  if (x0 && y0 && z0) acc += p[0] * (wx0 * wy0 * wz0);
-  if (x0 && y0 && z1) acc += p[1] * (wx0 * wy0 * wz1);
-  if (x0 && y1 && z0) acc += p[sy] * (wx0 * wy1 * wz0);
-  if (x0 && y1 && z1) acc += p[sy + 1] * (wx0 * wy1 * wz1);
-  if (x1 && y0 && z0) acc += p[sx] * (wx1 * wy0 * wz0);
-  if (x1 && y0 && z1) acc += p[sx + 1] * (wx1 * wy0 * wz1);
-  if (x1 && y1 && z0) acc += p[sx + sy] * (wx1 * wy1 * wz0);
-  if (x1 && y1 && z1) acc += p[sx + sy + 1] * (wx1 * wy1 * wz1);
-  return acc;
-}
+constexpr int kPullRows = 4;  // grid rows per thread: 16 eight-byte loads in flight per lane
 
 __global__ void __launch_bounds__(kBlock) k_pull(const float *__restrict__ src, Dim3i sd, Affine A,
                                                  float *__restrict__ dst, Dim3i gd, float tol,
                                                  const int *__restrict__ done) {
   if (done && *done) return;
   const int k = blockIdx.x * kWave + threadIdx.x;
-  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int j0 = (blockIdx.y * 4 + threadIdx.y) * kPullRows;
   const int i = blockIdx.z;
-  if (k >= gd.z || j >= gd.y) return;
-  float gx, gy, gz;
-  affine_point(A, (float)i, (float)j, (float)k, gx, gy, gz);
-  dst[((size_t)i * gd.y + j) * gd.z + k] = pull_sample(src, sd, gx, gy, gz, tol);
-}
-
-// --------------------------------------------------------------------------
-// conv_up gather: h[u] = sum_k ker[u - r k] * S(k) * xs[k]   (F.conv_transpose3d)
-// --------------------------------------------------------------------------
-__device__ __forceinline__ void up_range(int u, int K, int r, int n, int &lo, int &hi) {
-  hi = u / r;
-  if (hi > n - 1) hi = n - 1;
-  const int t = u - K + 1;
-  lo = t <= 0 ? 0 : (t + r - 1) / r;
-}
-
-__device__ __forceinline__ float conv_up_sample(const float *__restrict__ xs, const Dim3i &xd,
-                                                const Taps &T, const Scaling &S, int ux, int uy,
-                                                int uz) {
-  int ilo, ihi, jlo, jhi, klo, khi;
-  up_range(ux, T.n[0], T.s[0], xd.x, ilo, ihi);
-  up_range(uy, T.n[1], T.s[1], xd.y, jlo, jhi);
-  up_range(uz, T.n[2], T.s[2], xd.z, klo, khi);
-  float acc = 0.f;
-  for (int i = ilo; i <= ihi; ++i) {
-    const float wi = T.t[0][ux - T.s[0] * i];
-    for (int j = jlo; j <= jhi; ++j) {
-      const float wij = wi * T.t[1][uy - T.s[1] * j];
-      const float *row = xs + ((size_t)i * xd.y + j) * xd.z;
-      for (int k = klo; k <= khi; ++k) {
-        float v = row[k] * (wij * T.t[2][uz - T.s[2] * k]);
-        if (S.dim >= 0) {
-          const int par = (S.dim == 0 ? i : (S.dim == 1 ? j : k)) & 1;
-          v *= par ? S.o : S.e;
-        }
-        acc += v;
-      }
-    }
+  if (k >= gd.z) return;
+  PullLoads L[kPullRows];
+#pragma unroll
+  for (int r = 0; r < kPullRows; ++r) {
+    const int j = min(j0 + r, gd.y - 1);
+    float gx, gy, gz;
+    affine_point(A, (float)i, (float)j, (float)k, gx, gy, gz);
+    pull_issue(src, sd, gx, gy, gz, tol, L[r]);
   }
-  return acc;
+#pragma unroll
+  for (int r = 0; r < kPullRows; ++r)
+    if (j0 + r < gd.y) dst[((size_t)i * gd.y + j0 + r) * gd.z + k] = pull_finish(L[r]);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -230,7 +180,6 @@ __global__ void __launch_bounds__(kBlock)
   // tiles of 4 y-rows x 64 z; a bounded grid (<= kMaxPartials blocks) strides over them
   const int tz = (d.z + kWave - 1) / kWave, ty = (d.y + 3) / 4;
   const long long ntiles = (long long)tz * ty * d.x;
-  const size_t sx = (size_t)d.y * d.z, sy = d.z;
   double prod = 0.0;
   for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int kc = (int)(t % tz);
@@ -241,14 +190,9 @@ __global__ void __launch_bounds__(kBlock)
     const int j = jq * 4 + threadIdx.y;
     if (k < d.z && j < d.y) {
       const size_t idx = ((size_t)i * d.y + j) * d.z + k;
-      const float c = src[idx];
-      const float xf = (i + 1 < d.x ? src[idx + sx] : 0.f) - c;
-      const float xb = i > 0 ? c - src[idx - sx] : 0.f;
-      const float yf = (j + 1 < d.y ? src[idx + sy] : 0.f) - c;
-      const float yb = j > 0 ? c - src[idx - sy] : 0.f;
-      const float zf = (k + 1 < d.z ? src[idx + 1] : 0.f) - c;
-      const float zb = k > 0 ? c - src[idx - 1] : 0.f;
-      const float q = a * c + (cx * (xb - xf) + cy * (yb - yf) + cz * (zb - zf));
+      float c;
+      const float st = dtd_at(src, idx, i, j, k, d, cx, cy, cz, c);
+      const float q = a * c + st;
       dst[idx] = q;
       if (DOT) prod += (double)__fmul_rn(c, q);
     }
@@ -264,7 +208,8 @@ __global__ void __launch_bounds__(kBlock)
 // --------------------------------------------------------------------------
 void launch_pull(const float *src, Dim3i sd, const Affine &A, float *dst, Dim3i gd, float tol,
                  const int *done, hipStream_t st) {
-  hipLaunchKernelGGL(k_pull, vol_grid(gd), vol_block(), 0, st, src, sd, A, dst, gd, tol, done);
+  const dim3 grid((gd.z + kWave - 1) / kWave, (gd.y + 4 * kPullRows - 1) / (4 * kPullRows), gd.x);
+  hipLaunchKernelGGL(k_pull, grid, vol_block(), 0, st, src, sd, A, dst, gd, tol, done);
 }
 
 void launch_push(const float *src, Dim3i gd, const Affine &A, float *dst, Dim3i dd, float alpha,
