@@ -180,3 +180,27 @@ def test_large_volume_properties(dev):
     r0 = b.norm().item()
     r1 = (b - plan.matvec(y.dat, 0.9, 0.006)).norm().item()
     assert r1 < 0.2 * r0
+
+
+def test_gather_push_variant_matches_oracle(dev):
+    """The alternative gather-form push (UNIRES_PUSH=gather, chosen at library load)
+    runs the same parity gate in a fresh process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tests.helpers import make_problem, run_oracle_update_y, run_gpu_update_y, rel_err\n"
+            "from tests.test_gpu_path import CASES\n"
+            "for case in ('sr_3ch_axes', 'dn_2ch', 'sr_2rep'):\n"
+            "    prob = make_problem(seed=21, **CASES[case])\n"
+            "    yr, ir = run_oracle_update_y(prob)\n"
+            "    yg, ig = run_gpu_update_y(prob, 'cuda:0')\n"
+            "    for c in range(len(yr)):\n"
+            "        assert ig[c][0] == ir[c][0]\n"
+            "        assert rel_err(yg[c].cpu(), yr[c]) < 1e-4, case\n"
+            "print('gather OK')\n") % root
+    env = dict(os.environ, UNIRES_PUSH='gather')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and 'gather OK' in out.stdout, out.stderr[-2000:]

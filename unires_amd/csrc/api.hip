@@ -5,6 +5,7 @@
 // hipStream_t.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -422,9 +423,22 @@ static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, co
 
 // out = [out +] alpha * push(src) [+ epilogue]; falls back to a materialised conv_up when
 // the conv_up fan-in is beyond what the fused kernel tabulates.
-static void push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float alpha,
+static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float alpha,
                      const PushEpilogue &ep, float *out, const int *done, hipStream_t st) {
   const Affine &A = src.convup ? R.Af : R.A;
+  // default: owner-computes LDS splat (k_push_tile); UNIRES_PUSH=gather selects the
+  // gather-form kernel (3.6x more instructions, but no LDS tile and any geometry)
+  static const bool use_gather = getenv("UNIRES_PUSH") && !strcmp(getenv("UNIRES_PUSH"), "gather");
+  if (use_gather) {
+    // gather form: conv_up is materialised in grid space first (regime 2)
+    const float *g = src.data;
+    if (src.convup) {
+      launch_conv_up(src.data, src.xd, src.T, src.S, pl->gbuf, src.gd, st);
+      g = pl->gbuf;
+    }
+    if (!launch_push_gather(g, src.gd, A, R.Afinv, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
+      return ep.partials ? push_gather_blocks(pl->dy) : 0;
+  }
   if (launch_push_tile(src, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st)) {
     launch_conv_up(src.data, src.xd, src.T, src.S, pl->gbuf, src.gd, st);
     PushSrc d = src;
@@ -432,6 +446,7 @@ static void push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float
     d.convup = 0;
     (void)launch_push_tile(d, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st);
   }
+  return ep.partials ? push_tile_blocks(pl->dy) : 0;
 }
 
 // out (+)= alpha * At_n(x)
@@ -492,6 +507,7 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
   }
   // regimes 1/2: two kernels per repeat; the last one also adds c DtD p and the dot
   const size_t nrep = pl->reps.size();
+  int npart = 0;
   for (size_t n = 0; n < nrep; ++n) {
     const Repeat &R = pl->reps[n];
     const PushSrc src = ata_forward(pl, R, p, done, st);
@@ -504,9 +520,9 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
       ep.cz = c / (pl->vx[2] * pl->vx[2]);
     }
     if (n + 1 == nrep) ep.partials = part;
-    push_any(pl, src, R, R.tau, ep, q, done, st);
+    npart = push_any(pl, src, R, R.tau, ep, q, done, st);
   }
-  return part ? push_tile_blocks(pl->dy) : 0;
+  return npart;
 }
 
 extern "C" int unires_ata_matvec(unires_plan_t *plan, float rho, float lam, const float *p,

@@ -135,6 +135,57 @@ __device__ __forceinline__ float pull_finish(const PullLoads &L) {
   return acc;
 }
 
+// Interior fast path: all 8 corners inside the volume (so also inside the FOV): no
+// clamps, no masks, 32-bit offsets, lerp form (~46 VALU per sample vs ~140).
+__device__ __forceinline__ float2 ld2_u(const float *p) {
+  return *reinterpret_cast<const float2 *>(p);  // gfx950 global loads may be 4-byte aligned
+}
+
+__device__ __forceinline__ float pull_interior(const float *__restrict__ src, unsigned ny,
+                                               unsigned nz, unsigned nynz, float gx, float gy,
+                                               float gz) {
+  const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+  const float wx = gx - fx, wy = gy - fy, wz = gz - fz;
+  const unsigned ix = (unsigned)(int)fx, iy = (unsigned)(int)fy, iz = (unsigned)(int)fz;
+  const unsigned off = __umul24(__umul24(ix, ny) + iy, nz) + iz;
+  const float2 a = ld2_u(src + off), b = ld2_u(src + off + nz), c = ld2_u(src + off + nynz),
+               d = ld2_u(src + off + nynz + nz);
+  const float a1 = fmaf(wz, a.y - a.x, a.x), b1 = fmaf(wz, b.y - b.x, b.x),
+              c1 = fmaf(wz, c.y - c.x, c.x), d1 = fmaf(wz, d.y - d.x, d.x);
+  const float ab = fmaf(wy, b1 - a1, a1), cd = fmaf(wy, d1 - c1, c1);
+  return fmaf(wx, cd - ab, ab);
+}
+
+// Canonical coordinate arithmetic split so the row part can be hoisted:
+// affine_point(A,i,j,k) == affine_row(A,i,j) then affine_along(A,row,k), bit for bit.
+struct RowBase {
+  float x, y, z;
+};
+__device__ __forceinline__ RowBase affine_row(const Affine &A, float i, float j) {
+  return RowBase{fmaf(A.m[1], j, A.m[0] * i), fmaf(A.m[5], j, A.m[4] * i),
+                 fmaf(A.m[9], j, A.m[8] * i)};
+}
+__device__ __forceinline__ void affine_along(const Affine &A, const RowBase &r, float k, float &gx,
+                                             float &gy, float &gz) {
+  gx = fmaf(A.m[2], k, r.x) + A.m[3];
+  gy = fmaf(A.m[6], k, r.y) + A.m[7];
+  gz = fmaf(A.m[10], k, r.z) + A.m[11];
+}
+
+// True iff the image of the grid box [lo, hi] (inclusive corners) lies inside
+// [margin, n-1-margin]^3, i.e. every sample of the box has all 8 corners in the volume.
+// Affine maps are convex: testing the 8 box corners suffices.  One corner per lane,
+// combined by the caller (block- or wave-wide AND).
+__device__ __forceinline__ bool corner_inside(const Affine &A, int c, const int lo[3],
+                                              const int hi[3], const Dim3i &sd) {
+  float gx, gy, gz;
+  affine_point(A, (float)((c & 4) ? hi[0] : lo[0]), (float)((c & 2) ? hi[1] : lo[1]),
+               (float)((c & 1) ? hi[2] : lo[2]), gx, gy, gz);
+  const float m = 0.01f;
+  return gx >= m && gx <= (float)(sd.x - 1) - m && gy >= m && gy <= (float)(sd.y - 1) - m &&
+         gz >= m && gz <= (float)(sd.z - 1) - m;
+}
+
 __device__ __forceinline__ float pull_sample(const float *__restrict__ src, const Dim3i &sd,
                                              float gx, float gy, float gz, float tol) {
   PullLoads L;

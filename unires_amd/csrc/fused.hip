@@ -17,6 +17,7 @@
 #include "fused.hpp"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -35,13 +36,17 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv) {
 // --------------------------------------------------------------------------
 // k_pull_conv
 // --------------------------------------------------------------------------
+// A workgroup owns an x-space tile ot; the grid-space box it needs (pt = (ot-1)*s + K
+// per axis) is pulled into LDS row by row - one wave per grid row (ux,uy), lanes along
+// grid z, so the y-space reads of a wave are (nearly) contiguous - then reduced by the
+// separable taps.  Tiles whose whole footprint is inside the volume take the
+// `pull_interior` path (no masks / clamps).
 __global__ void __launch_bounds__(kBlock)
     k_pull_conv(const float *__restrict__ src, Dim3i sd, Affine A, Taps T, Scaling S,
                 float *__restrict__ dst, Dim3i xd, Dim3i gd, Dim3i ot, float tol,
                 const int *__restrict__ done) {
   if (done && *done) return;
   extern __shared__ float smem[];
-  // pulled tile extents
   const int ptx = (ot.x - 1) * T.s[0] + T.n[0];
   const int pty = (ot.y - 1) * T.s[1] + T.n[1];
   const int ptz = (ot.z - 1) * T.s[2] + T.n[2];
@@ -49,32 +54,40 @@ __global__ void __launch_bounds__(kBlock)
   float *tile = smem;
   float *taps = smem + ptot;  // 3 * UNIRES_MAX_TAPS
   const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row loop runs on the SALU
   if (tid < 3 * UNIRES_MAX_TAPS) taps[tid] = (&T.t[0][0])[tid];
   const int o0x = blockIdx.z * ot.x, o0y = blockIdx.y * ot.y, o0z = blockIdx.x * ot.z;
   const int p0x = o0x * T.s[0], p0y = o0y * T.s[1], p0z = o0z * T.s[2];
-  const float inv_z = 1.f / (float)ptz, inv_y = 1.f / (float)pty;
-  constexpr int kBatch = 4;  // samples whose loads are issued together (latency hiding)
-  for (int idx0 = tid; idx0 < ptot; idx0 += kBlock * kBatch) {
-    PullLoads L[kBatch];
-    bool in[kBatch];
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      const int idx = min(idx0 + u * kBlock, ptot - 1);
-      const int ab = fast_div(idx, ptz, inv_z);
-      const int c = idx - ab * ptz;
-      const int a = fast_div(ab, pty, inv_y);
-      const int b = ab - a * pty;
-      const int ux = p0x + a, uy = p0y + b, uz = p0z + c;
-      in[u] = ux < gd.x && uy < gd.y && uz < gd.z;
-      float gx, gy, gz;
-      affine_point(A, (float)min(ux, gd.x - 1), (float)min(uy, gd.y - 1), (float)min(uz, gd.z - 1),
-                   gx, gy, gz);
-      pull_issue(src, sd, gx, gy, gz, tol, L[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      const int idx = idx0 + u * kBlock;
-      if (idx < ptot) tile[idx] = in[u] ? pull_finish(L[u]) : 0.f;
+  const int lo[3] = {p0x, p0y, p0z};
+  const int hi[3] = {min(p0x + ptx - 1, gd.x - 1), min(p0y + pty - 1, gd.y - 1),
+                     min(p0z + ptz - 1, gd.z - 1)};
+  const bool interior = __syncthreads_and(corner_inside(A, tid & 7, lo, hi, sd)) && sd.z >= 2;
+  const unsigned ny = sd.y, nz = sd.z, nynz = ny * nz;
+  const int nrows = ptx * pty;
+  for (int row = wave; row < nrows; row += kBlock / kWave) {
+    const int a = row / pty, b = row - a * pty;
+    const int ux = p0x + a, uy = p0y + b;
+    const bool row_in = ux < gd.x && uy < gd.y;
+    const RowBase rb = affine_row(A, (float)min(ux, gd.x - 1), (float)min(uy, gd.y - 1));
+    float *trow = tile + row * ptz;
+    if (interior) {
+#pragma unroll 2
+      for (int c = lane; c < ptz; c += kWave) {
+        const int uz = p0z + c;
+        float gx, gy, gz;
+        affine_along(A, rb, (float)min(uz, gd.z - 1), gx, gy, gz);
+        const float v = pull_interior(src, ny, nz, nynz, gx, gy, gz);
+        trow[c] = (row_in && uz < gd.z) ? v : 0.f;
+      }
+    } else {
+      for (int c = lane; c < ptz; c += kWave) {
+        const int uz = p0z + c;
+        float gx, gy, gz;
+        affine_along(A, rb, (float)min(uz, gd.z - 1), gx, gy, gz);
+        const float v = pull_sample(src, sd, gx, gy, gz, tol);
+        trow[c] = (row_in && uz < gd.z) ? v : 0.f;
+      }
     }
   }
   __syncthreads();
@@ -127,6 +140,7 @@ struct PushArgs {
   int dbg;           // ablation bitmask (UNIRES_DBG env; 0 in production)
   int row_sep;       // min |d(ui,uj)|_inf for two grid rows to be splatted together
   int use_atomics;   // grid-z step too short for the plain read-add-write splat
+  unsigned long long *prof;  // debug: per-phase cycle sums (UNIRES_PROF=1), else nullptr
 };
 
 // Aproned LDS accumulator: storage index 0 <-> output index (tile origin - 1), so
@@ -154,6 +168,12 @@ struct UpTab {
 };
 
 constexpr int kPushThreads = kWave;  // ONE wave per tile (see below)
+
+// compiler-only memory barrier for wave-synchronous LDS code (no instruction emitted)
+#define WAVE_FENCE() asm volatile("" ::: "memory")
+#define PROF_T(var) const unsigned long long var = P.prof ? __builtin_readcyclecounter() : 0ull
+#define PROF_ADD(slot, t0, t1) \
+  if (P.prof && lane == 0) atomicAdd(P.prof + (slot), (t1) - (t0))
 
 // LDS float atomics (ds_add_f32) retire about one lane per clock per CU on gfx950
 // (measured: 8 per source voxel -> 0.9 ms per push), so the splat is done with plain
@@ -199,7 +219,8 @@ __global__ void __launch_bounds__(kPushThreads)
     const int tzi = t % ntz, tyi = (t / ntz) % nty, txi = t / (ntz * nty);
     const int x0 = txi * TX, y0 = tyi * TY, z0 = tzi * TZ;
     const int ex = min(TX, dd.x - x0), ey = min(TY, dd.y - y0), ez = min(TZ, dd.z - z0);
-    __syncthreads();  // previous tile's epilogue done before re-zeroing
+    WAVE_FENCE();  // previous tile's epilogue done before re-zeroing
+    PROF_T(t_start);
     for (int i = lane; i < Tile::N; i += kPushThreads) acc[i] = 0.f;
     // a source voxel touches the tile <=> floor(g) in [lo, hi-1] <=> g in [lo, hi)
     const float flx = (float)(x0 - 1), fly = (float)(y0 - 1), flz = (float)(z0 - 1);
@@ -254,12 +275,15 @@ __global__ void __launch_bounds__(kPushThreads)
         }
       }
     }
+    PROF_T(t_setup);
+    PROF_ADD(0, t_start, t_setup);
     const float c0 = P.A.m[2], c1 = P.A.m[6], c2 = P.A.m[10];  // step of g along grid z
     const int nrow_cand = (P.dbg & 8) ? 0 : max(nbx, 0) * max(nby, 0);
     const int segs_per_row = (max(bz1 - bz0 + 1, 1) + 31) / 32;
     int nseg = 0;
     for (int rc0 = 0;;) {
       // ---- phase A: 64 candidate rows (ui,uj) per pass -> exact grid-z intervals ----
+      PROF_T(t_a0);
       if (rc0 < nrow_cand) {
         const int rc = rc0 + lane;
         int ui = 0, uj = 0, k0 = 0, k1 = -1;
@@ -303,46 +327,52 @@ __global__ void __launch_bounds__(kPushThreads)
         }
         rc0 += kPushThreads;
       }
+      PROF_T(t_a1);
+      PROF_ADD(1, t_a0, t_a1);
       const bool last = rc0 >= nrow_cand;
       if (!last && nseg + kPushThreads * segs_per_row <= Tile::kSegs) continue;
-      __syncthreads();  // segment list (and tables / zeroed acc) visible to all lanes
+      WAVE_FENCE();  // segment list / tables / zeroed acc written before being read
       // ---- phase B: the two half-waves take segments p and p + npair, lanes along grid z.
-      // kU pairs are processed together: all global loads are issued before any is consumed.
+      // Batches of kU segment pairs, software-pipelined: the global loads of batch b+1 are
+      // issued before the LDS updates of batch b.
       const int nr = (P.dbg & 1) ? 0 : min(nseg, Tile::kSegs);
       const int npair = (nr + 1) / 2;
       constexpr int kU = 4;
-      for (int p0 = 0; p0 < npair; p0 += kU) {
+      struct Batch {
         float s0[kU], s1[kU], w0[kU], w1[kU];
         int ui[kU], uj[kU], uk[kU];
         bool act[kU], solo[kU];
+      };
+      auto load_batch = [&](int p0, Batch &B) {
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           const int p = p0 + u;
-          const int ia = min(p, nr - 1), ib = min(p + npair, nr - 1);
+          const int ia = max(min(p, nr - 1), 0), ib = max(min(p + npair, nr - 1), 0);
           const RowSeg Ra = rows[ia], Rb = rows[ib];
           // rows too close to be splatted in the same instruction -> B waits for a solo turn
-          solo[u] = p + npair < nr && max(abs(Ra.ui - Rb.ui), abs(Ra.uj - Rb.uj)) < P.row_sep;
+          B.solo[u] = p + npair < nr && max(abs(Ra.ui - Rb.ui), abs(Ra.uj - Rb.uj)) < P.row_sep;
           const RowSeg R = half ? Rb : Ra;
-          act[u] = p < npair && (half ? p + npair < nr : true) && hl < R.len;
-          ui[u] = R.ui, uj[u] = R.uj, uk[u] = min(R.k0 + hl, gd.z - 1);
+          B.act[u] = p < npair && (half ? p + npair < nr : true) && hl < R.len;
+          B.ui[u] = R.ui, B.uj[u] = R.uj, B.uk[u] = min(R.k0 + hl, gd.z - 1);
+          const int ui = B.ui[u], uj = B.uj[u], uk = B.uk[u];
           if (SRC == 0) {
-            s0[u] = src[((size_t)ui[u] * gd.y + uj[u]) * gd.z + uk[u]];
-            s1[u] = 0.f, w0[u] = 1.f, w1[u] = 0.f;
+            B.s0[u] = src[((size_t)ui * gd.y + uj) * gd.z + uk];
+            B.s1[u] = 0.f, B.w0[u] = 1.f, B.w1[u] = 0.f;
           } else if (SRC == 1 && tab_ok) {
             // thick-slice case: at most 2 x-space voxels along ONE axis feed a grid voxel;
             // both loads are unconditional (a zero weight covers the absent second one)
-            const int ox = ui[u] - bx0, oy = uj[u] - by0, oz = min(uk[u] - bz0, Tile::kTab - 1);
+            const int ox = ui - bx0, oy = uj - by0, oz = min(uk - bz0, Tile::kTab - 1);
             const int ix = tab.lo[0][ox], iy = tab.lo[1][oy], iz = tab.lo[2][oz];
             const bool dx = tab.n[0][ox] > 1, dy = tab.n[1][oy] > 1, dz = tab.n[2][oz] > 1;
             const size_t base = ((size_t)ix * P.xd.y + iy) * P.xd.z + iz;
             const size_t step = dx ? (size_t)P.xd.y * P.xd.z : (dy ? (size_t)P.xd.z : (size_t)dz);
-            s0[u] = src[base], s1[u] = src[base + step];
+            B.s0[u] = src[base], B.s1[u] = src[base + step];
             const float wx = tab.w[0][ox][0], wy = tab.w[1][oy][0], wz = tab.w[2][oz][0];
-            w0[u] = wx * wy * wz;
-            w1[u] = dx ? tab.w[0][ox][1] * wy * wz
-                       : (dy ? wx * tab.w[1][oy][1] * wz : wx * wy * tab.w[2][oz][1]);
+            B.w0[u] = wx * wy * wz;
+            B.w1[u] = dx ? tab.w[0][ox][1] * wy * wz
+                         : (dy ? wx * tab.w[1][oy][1] * wz : wx * wy * tab.w[2][oz][1]);
           } else if (tab_ok) {
-            const int ox = ui[u] - bx0, oy = uj[u] - by0, oz = min(uk[u] - bz0, Tile::kTab - 1);
+            const int ox = ui - bx0, oy = uj - by0, oz = min(uk - bz0, Tile::kTab - 1);
             float v = 0.f;
             for (int a = 0; a < tab.n[0][ox]; ++a)
               for (int b = 0; b < tab.n[1][oy]; ++b) {
@@ -352,19 +382,21 @@ __global__ void __launch_bounds__(kPushThreads)
                     tab.lo[2][oz];
                 for (int c = 0; c < tab.n[2][oz]; ++c) v += row[c] * (wab * tab.w[2][oz][c]);
               }
-            s0[u] = v, s1[u] = 0.f, w0[u] = 1.f, w1[u] = 0.f;
+            B.s0[u] = v, B.s1[u] = 0.f, B.w0[u] = 1.f, B.w1[u] = 0.f;
           } else {
-            s0[u] = conv_up_sample(src, P.xd, P.T, P.S, ui[u], uj[u], uk[u]);
-            s1[u] = 0.f, w0[u] = 1.f, w1[u] = 0.f;
+            B.s0[u] = conv_up_sample(src, P.xd, P.T, P.S, ui, uj, uk);
+            B.s1[u] = 0.f, B.w0[u] = 1.f, B.w1[u] = 0.f;
           }
         }
+      };
+      auto splat_batch = [&](const Batch &B) {
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           float gx, gy, gz;
-          affine_point(P.A, (float)ui[u], (float)uj[u], (float)uk[u], gx, gy, gz);
-          bool ok = act[u] && gx >= flx && gx < fhx && gy >= fly && gy < fhy && gz >= flz && gz < fhz;
+          affine_point(P.A, (float)B.ui[u], (float)B.uj[u], (float)B.uk[u], gx, gy, gz);
+          bool ok = B.act[u] && gx >= flx && gx < fhx && gy >= fly && gy < fhy && gz >= flz && gz < fhz;
           if (edge) ok = ok && in_fov(gx, gy, gz, dd, P.tol);
-          const float v = P.alpha * (s0[u] * w0[u] + s1[u] * w1[u]);
+          const float v = P.alpha * (B.s0[u] * B.w0[u] + B.s1[u] * B.w1[u]);
           ok = ok && v != 0.f && !(P.dbg & 2);
           const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
           const int lx = (int)fx - (x0 - 1), ly = (int)fy - (y0 - 1), lz = (int)fz - (z0 - 1);
@@ -381,14 +413,14 @@ __global__ void __launch_bounds__(kPushThreads)
                       a11 = v * (wx1 * wy1);
           // Turn schedule: lanes that could touch the footprint of another lane of the same
           // instruction wait for a later turn: (row B of a too-close pair) x (replayed
-          // same-cell neighbour).  Turn 0 is the only one that normally runs.
-          const int myturn = ((solo[u] && half) ? 2 : 0) + (dup ? 1 : 0);
+          // same-plane neighbour).  Turn 0 is the only one that normally runs.
+          const int myturn = ((B.solo[u] && half) ? 2 : 0) + (dup ? 1 : 0);
 #pragma unroll
           for (int turn = 0; turn < 4; ++turn) {
             if (!__any(ok && myturn == turn)) continue;  // wave-uniform
-            // __syncthreads() below are single-wave barriers: they only pin the order of
-            // the LDS read-modify-write groups (the hardware runs a wave's LDS ops in order)
-            __syncthreads();
+            // WAVE_FENCE pins the order of the LDS read-modify-write groups for the compiler;
+            // the hardware executes one wave's LDS instructions in order.
+            WAVE_FENCE();
             const bool on = ok && myturn == turn;
             const int mycell = on ? cell : -1 - lane;
             float l00 = a00 * wz0, l01 = a01 * wz0, l10 = a10 * wz0, l11 = a11 * wz0;  // z  plane
@@ -417,24 +449,49 @@ __global__ void __launch_bounds__(kPushThreads)
               const float o00 = q[0], o01 = q[SY], o10 = q[SX], o11 = q[SX + SY];
               q[0] = o00 + l00, q[SY] = o01 + l01, q[SX] = o10 + l10, q[SX + SY] = o11 + l11;
             }
-            __syncthreads();
+            WAVE_FENCE();
             if (on && !sent) {  // group 2: z+1 plane of lanes with nobody above them
               const float o00 = q[1], o01 = q[SY + 1], o10 = q[SX + 1], o11 = q[SX + SY + 1];
               q[1] = o00 + u00, q[SY + 1] = o01 + u01, q[SX + 1] = o10 + u10,
               q[SX + SY + 1] = o11 + u11;
             }
+            WAVE_FENCE();
           }
         }
+      };
+      {
+        PROF_T(t_b0);
+        Batch B0, B1;
+        if (npair > 0) load_batch(0, B0);
+        for (int p0 = 0; p0 < npair; p0 += 2 * kU) {
+          PROF_T(t_l0);
+          if (p0 + kU < npair) load_batch(p0 + kU, B1);
+          PROF_T(t_l1);
+          splat_batch(B0);
+          PROF_T(t_l2);
+          PROF_ADD(2, t_l0, t_l1);
+          PROF_ADD(3, t_l1, t_l2);
+          if (p0 + kU < npair) {
+            if (p0 + 2 * kU < npair) load_batch(p0 + 2 * kU, B0);
+            splat_batch(B1);
+          }
+        }
+        PROF_T(t_b1);
+        PROF_ADD(4, t_b0, t_b1);
+        if (P.prof && lane == 0) atomicAdd(P.prof + 7, (unsigned long long)nr);
       }
       nseg = 0;
       if (last) break;
     }
-    __syncthreads();
+    WAVE_FENCE();
+    PROF_T(t_e0);
     // ---- epilogue: q = [q +] acc + a0 p + c DtD p ; dot += p*q --------------
     // (dst never aliases p: the stencil loads of several outputs are hoisted together)
+    // one output row (lx,ly) per half-wave and pass: contiguous 4*TZ-byte stores, no div/mod
+    static_assert(TZ <= 32, "epilogue maps one row to a half-wave");
 #pragma unroll 4
-    for (int o = lane; o < TX * TY * TZ; o += kPushThreads) {
-      const int lz = o % TZ, ly = (o / TZ) % TY, lx = o / (TZ * TY);
+    for (int r = half; r < TX * TY; r += 2) {
+      const int lx = r / TY, ly = r % TY, lz = hl;
       if (lx >= ex || ly >= ey || lz >= ez) continue;
       const int i = x0 + lx, j = y0 + ly, k = z0 + lz;
       const size_t idx = ((size_t)i * dd.y + j) * dd.z + k;
@@ -448,6 +505,9 @@ __global__ void __launch_bounds__(kPushThreads)
       dst[idx] = q;
       if (P.partials) dot += (double)__fmul_rn(pc, q);
     }
+    PROF_T(t_e1);
+    PROF_ADD(5, t_e0, t_e1);
+    PROF_ADD(6, t_start, t_e1);
   }
   if (P.partials) {
     const double tot = wave_sum(dot);
@@ -459,17 +519,18 @@ __global__ void __launch_bounds__(kPushThreads)
 // launchers
 // --------------------------------------------------------------------------
 static void pick_out_tile(const Taps &T, const Dim3i &xd, Dim3i &ot, size_t &lds_bytes) {
-  // ~256-512 outputs per workgroup, z longest for coalescing; shrink until the
-  // pulled tile fits comfortably in LDS (several workgroups per CU).
-  int t[3] = {4, 4, 16};
+  // z: as many outputs as keep the pulled row within two 64-lane passes (a dirac axis:
+  // one pass); x,y: 4x4 rows, halved until the pulled tile fits ~24 KB of LDS.
   const int xdv[3] = {xd.x, xd.y, xd.z};
+  int t[3] = {4, 4, 1};
+  t[2] = (T.s[2] == 1 && T.n[2] == 1) ? 64 : std::max(1, (128 - T.n[2]) / T.s[2] + 1);
   for (int d = 0; d < 3; ++d)
     if (t[d] > xdv[d]) t[d] = xdv[d];
   auto pt = [&](int d) { return (size_t)(t[d] - 1) * T.s[d] + T.n[d]; };
-  while (pt(0) * pt(1) * pt(2) * 4 > 40 * 1024) {
-    int big = 0;
-    for (int d = 1; d < 3; ++d)
-      if (pt(d) > pt(big)) big = d;
+  while (pt(0) * pt(1) * pt(2) * 4 > 24 * 1024) {
+    int big = pt(0) >= pt(1) ? 0 : 1;
+    if (t[big] == 1) big = 1 - big;
+    if (t[big] == 1) big = 2;
     if (t[big] == 1) break;
     t[big] = (t[big] + 1) / 2;
   }
@@ -572,6 +633,11 @@ int launch_push_tile(const PushSrc &src, const Affine &A, const Affine &Ainv,
   P.dbg = dbg;
   P.row_sep = safe.row_sep;
   P.use_atomics = safe.use_atomics;
+  static unsigned long long *prof = nullptr;
+  static const bool want_prof = getenv("UNIRES_PROF") != nullptr;
+  if (want_prof && !prof) (void)hipMalloc((void **)&prof, 8 * sizeof(unsigned long long));
+  if (want_prof) (void)hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), st);
+  P.prof = want_prof ? prof : nullptr;
   const int kind = push_src_kind(src);
   if (kind == 2)
     for (int d = 0; d < 3; ++d)
@@ -583,6 +649,163 @@ int launch_push_tile(const PushSrc &src, const Affine &A, const Affine &Ainv,
     hipLaunchKernelGGL((k_push_tile<1, kTX, kTY, kTZ>), grid, dim3(kPushThreads), 0, st, P, done);
   else
     hipLaunchKernelGGL((k_push_tile<2, kTX, kTY, kTZ>), grid, dim3(kPushThreads), 0, st, P, done);
+  if (want_prof) {
+    unsigned long long h[8];
+    (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr,
+            "[push prof kind %d] Mcycles: setup %.1f phaseA %.1f loadB %.1f splatB %.1f phaseB %.1f "
+            "epilogue %.1f total %.1f | segments %llu waves %d\n",
+            kind, h[0] * 1e-6, h[1] * 1e-6, h[2] * 1e-6, h[3] * 1e-6, h[4] * 1e-6, h[5] * 1e-6,
+            h[6] * 1e-6, h[7], (int)grid.x);
+  }
+  return 0;
+}
+
+}  // namespace unires
+
+// ==========================================================================
+// k_push_gather - the adjoint of the trilinear pull in GATHER form.
+//
+// out[v] = sum over grid voxels u with |g(u) - v|_inf < 1 of
+//          prod_d (1 - |g_d(u) - v_d|) * mask(g(u)) * src[u]
+//
+// which is exactly what the scatter (nitorch grid_push) accumulates into v: v is
+// one of the 8 corners of g(u) iff |g_d(u) - v_d| < 1 for every axis, and the
+// trilinear weight of that corner is prod (1 - |g_d - v_d|).  No atomics, no LDS
+// tile, fixed summation order (bit-reproducible), full occupancy; the price is
+// enumerating candidate sources: grid rows (ui,uj) within +-h of M^-1 v, and per
+// row the 2-3 grid-z positions whose image is within one voxel of v along z.
+// ==========================================================================
+namespace unires {
+
+struct GatherArgs {
+  const float *src;  // grid-space volume
+  Dim3i gd;
+  Affine A, Ainv;
+  float hx, hy, hz;  // half-widths of M^-1 (-1,1)^3 per grid axis
+  int nrx, nry, nrz; // candidates per axis = ceil(2h)
+  int zsolve;        // |dz/dk| large enough to solve the grid-z candidates per row
+  float alpha, tol;
+  const float *p;
+  float a0, cx, cy, cz;
+  float *dst;
+  Dim3i dd;
+  int accumulate;
+  double *partials;
+};
+
+__device__ __forceinline__ float hat(float d) { return __saturatef(1.f - fabsf(d)); }
+
+__global__ void __launch_bounds__(kBlock)
+    k_push_gather(GatherArgs G, const int *__restrict__ done) {
+  if (done && *done) return;
+  const Dim3i dd = G.dd, gd = G.gd;
+  const float *__restrict__ src = G.src;
+  const float *__restrict__ pin = G.p;
+  float *__restrict__ dst = G.dst;
+  const int tz = (dd.z + kWave - 1) / kWave, ty = (dd.y + 3) / 4;
+  const long long ntiles = (long long)tz * ty * dd.x;
+  const float c2 = G.A.m[10];
+  const float inv_c2 = G.zsolve ? 1.f / c2 : 0.f;
+  const float span = G.zsolve ? fabsf(inv_c2) : 0.f;  // grid-z half-width of |dz| < 1
+  double dot = 0.0;
+  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int kc = (int)(t % tz);
+    const long long t2 = t / tz;
+    const int jq = (int)(t2 % ty);
+    const int i = (int)(t2 / ty);
+    const int k = kc * kWave + threadIdx.x;
+    const int j = jq * 4 + threadIdx.y;
+    if (k >= dd.z || j >= dd.y) continue;
+    const float vx = (float)i, vy = (float)j, vz = (float)k;
+    float ux, uy, uz;
+    affine_point(G.Ainv, vx, vy, vz, ux, uy, uz);
+    // first integer strictly above u* - h  (candidates: that one and the next n-1)
+    const int ix0 = (int)floorf(ux - G.hx) + 1, iy0 = (int)floorf(uy - G.hy) + 1;
+    const int iz0 = (int)floorf(uz - G.hz) + 1;
+    const bool edge = i == 0 || j == 0 || k == 0 || i == dd.x - 1 || j == dd.y - 1 || k == dd.z - 1;
+    float acc = 0.f;
+    for (int a = 0; a < G.nrx; ++a) {
+      const int ui = ix0 + a;
+      if (ui < 0 || ui >= gd.x) continue;
+      for (int b = 0; b < G.nry; ++b) {
+        const int uj = iy0 + b;
+        if (uj < 0 || uj >= gd.y) continue;
+        const RowBase rb = affine_row(G.A, (float)ui, (float)uj);
+        const float *row = src + ((size_t)ui * gd.y + uj) * gd.z;
+        int k0, nk;
+        if (G.zsolve) {
+          // |r.z + c2*uk + m11 - vz| < 1  ->  uk in (tc - span, tc + span)
+          const float tc = (vz - (rb.z + G.A.m[11])) * inv_c2;
+          k0 = (int)floorf(tc - span - 1e-3f) + 1;
+          nk = 2 + (int)(span > 1.f) + 1;  // covers the open interval plus rounding slack
+          // cheap row rejection: x,y offsets at the interval centre, widened by their drift
+          float gx, gy, gz;
+          affine_along(G.A, rb, tc, gx, gy, gz);
+          const float slack = 1.f + (span + 1.f) * (fabsf(G.A.m[2]) + fabsf(G.A.m[6]));
+          if (fabsf(gx - vx) >= slack || fabsf(gy - vy) >= slack) continue;
+        } else {
+          k0 = iz0, nk = G.nrz;
+        }
+        for (int m = 0; m < nk; ++m) {
+          const int uk = k0 + m;
+          float gx, gy, gz;
+          affine_along(G.A, rb, (float)uk, gx, gy, gz);
+          float w = hat(gx - vx) * hat(gy - vy) * hat(gz - vz);
+          if (uk < 0 || uk >= gd.z) w = 0.f;
+          if (edge && !in_fov(gx, gy, gz, dd, G.tol)) w = 0.f;
+          acc = fmaf(w, row[min(max(uk, 0), gd.z - 1)], acc);
+        }
+      }
+    }
+    const size_t idx = ((size_t)i * dd.y + j) * dd.z + k;
+    float q = G.alpha * acc;
+    float pc = 0.f;
+    if (pin) {
+      const float st = dtd_at(pin, idx, i, j, k, dd, G.cx, G.cy, G.cz, pc);
+      q += G.a0 * pc + st;
+    }
+    if (G.accumulate) q += dst[idx];
+    dst[idx] = q;
+    if (G.partials) dot += (double)__fmul_rn(pc, q);
+  }
+  if (G.partials) {
+    const double tot = block_sum(dot);
+    if (threadIdx.x == 0 && threadIdx.y == 0) G.partials[blockIdx.x] = tot;
+  }
+}
+
+int push_gather_blocks(Dim3i dd) {
+  const long long ntiles = (long long)((dd.z + kWave - 1) / kWave) * ((dd.y + 3) / 4) * dd.x;
+  return (int)(ntiles < kMaxPartials ? ntiles : kMaxPartials);
+}
+
+// Returns non-zero (nothing launched) when the candidate box would be unreasonably large.
+int launch_push_gather(const float *src, Dim3i gd, const Affine &A, const Affine &Ainv,
+                       float alpha, float tol, const PushEpilogue &ep, float *dst, Dim3i dd,
+                       const int *done, hipStream_t st) {
+  GatherArgs G;
+  G.src = src;
+  G.gd = gd;
+  G.A = A;
+  G.Ainv = Ainv;
+  float h[3];
+  for (int r = 0; r < 3; ++r)
+    h[r] = fabsf(Ainv.m[4 * r]) + fabsf(Ainv.m[4 * r + 1]) + fabsf(Ainv.m[4 * r + 2]) + 1e-3f;
+  G.hx = h[0], G.hy = h[1], G.hz = h[2];
+  G.nrx = (int)ceilf(2.f * h[0]), G.nry = (int)ceilf(2.f * h[1]), G.nrz = (int)ceilf(2.f * h[2]);
+  if (G.nrx > 8 || G.nry > 8 || G.nrz > 8) return 1;
+  G.zsolve = fabsf(A.m[10]) > 0.5f;
+  G.alpha = alpha;
+  G.tol = tol;
+  G.p = ep.p;
+  G.a0 = ep.a0, G.cx = ep.cx, G.cy = ep.cy, G.cz = ep.cz;
+  G.dst = dst;
+  G.dd = dd;
+  G.accumulate = ep.accumulate;
+  G.partials = ep.partials;
+  hipLaunchKernelGGL(k_push_gather, dim3(push_gather_blocks(dd)), dim3(kWave, kBlock / kWave), 0, st,
+                     G, done);
   return 0;
 }
 

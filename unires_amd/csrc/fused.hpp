@@ -39,4 +39,10 @@ int launch_push_tile(const PushSrc &src, const Affine &A, const Affine &Ainv,
                      const SplatSafety &safe, float alpha, float tol, const PushEpilogue &ep,
                      float *dst, Dim3i dd, const int *done, hipStream_t st);
 
+// Gather-form push from a grid-space volume (no atomics, no LDS tile, deterministic).
+int push_gather_blocks(Dim3i dd);
+int launch_push_gather(const float *src, Dim3i gd, const Affine &A, const Affine &Ainv,
+                       float alpha, float tol, const PushEpilogue &ep, float *dst, Dim3i dd,
+                       const int *done, hipStream_t st);
+
 }  // namespace unires

@@ -18,27 +18,52 @@ static inline dim3 vol_grid(const Dim3i &d) {
 // pull: dst[g] = mask(g) * sum_8 w_c * src[corner_c(M g)]
 // (nitorch grid_pull linear / zero / extrapolate=False)
 // --------------------------------------------------------------------------
-constexpr int kPullRows = 4;  // grid rows per thread: 16 eight-byte loads in flight per lane
+constexpr int kPullChunks = 4;  // z chunks of 64 per thread: 16 eight-byte loads in flight
 
+// block = 4 waves = 4 consecutive grid rows j (same i); each lane takes kPullChunks grid-z
+// positions 64 apart.  Blocks whose whole footprint is inside the volume (all but a thin
+// shell) take the interior path.
 __global__ void __launch_bounds__(kBlock) k_pull(const float *__restrict__ src, Dim3i sd, Affine A,
                                                  float *__restrict__ dst, Dim3i gd, float tol,
                                                  const int *__restrict__ done) {
   if (done && *done) return;
-  const int k = blockIdx.x * kWave + threadIdx.x;
-  const int j0 = (blockIdx.y * 4 + threadIdx.y) * kPullRows;
+  const int lane = threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
   const int i = blockIdx.z;
-  if (k >= gd.z) return;
-  PullLoads L[kPullRows];
+  const int kbase = blockIdx.x * (kWave * kPullChunks);
+  const int lo[3] = {i, (int)blockIdx.y * 4, kbase};
+  const int hi[3] = {i, min((int)blockIdx.y * 4 + 3, gd.y - 1),
+                     min(kbase + kWave * kPullChunks - 1, gd.z - 1)};
+  const bool interior = __syncthreads_and(corner_inside(A, lane & 7, lo, hi, sd)) && sd.z >= 2;
+  if (j >= gd.y) return;
+  const RowBase rb = affine_row(A, (float)i, (float)j);
+  float *row = dst + ((size_t)i * gd.y + j) * gd.z;
+  if (interior) {
+    const unsigned ny = sd.y, nz = sd.z, nynz = ny * nz;
 #pragma unroll
-  for (int r = 0; r < kPullRows; ++r) {
-    const int j = min(j0 + r, gd.y - 1);
+    for (int u = 0; u < kPullChunks; ++u) {
+      const int k = kbase + u * kWave + lane;
+      if (k < gd.z) {
+        float gx, gy, gz;
+        affine_along(A, rb, (float)k, gx, gy, gz);
+        row[k] = pull_interior(src, ny, nz, nynz, gx, gy, gz);
+      }
+    }
+    return;
+  }
+  PullLoads L[kPullChunks];
+#pragma unroll
+  for (int u = 0; u < kPullChunks; ++u) {
+    const int k = min(kbase + u * kWave + lane, gd.z - 1);
     float gx, gy, gz;
-    affine_point(A, (float)i, (float)j, (float)k, gx, gy, gz);
-    pull_issue(src, sd, gx, gy, gz, tol, L[r]);
+    affine_along(A, rb, (float)k, gx, gy, gz);
+    pull_issue(src, sd, gx, gy, gz, tol, L[u]);
   }
 #pragma unroll
-  for (int r = 0; r < kPullRows; ++r)
-    if (j0 + r < gd.y) dst[((size_t)i * gd.y + j0 + r) * gd.z + k] = pull_finish(L[r]);
+  for (int u = 0; u < kPullChunks; ++u) {
+    const int k = kbase + u * kWave + lane;
+    if (k < gd.z) row[k] = pull_finish(L[u]);
+  }
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -208,7 +233,8 @@ __global__ void __launch_bounds__(kBlock)
 // --------------------------------------------------------------------------
 void launch_pull(const float *src, Dim3i sd, const Affine &A, float *dst, Dim3i gd, float tol,
                  const int *done, hipStream_t st) {
-  const dim3 grid((gd.z + kWave - 1) / kWave, (gd.y + 4 * kPullRows - 1) / (4 * kPullRows), gd.x);
+  const int zspan = kWave * kPullChunks;
+  const dim3 grid((gd.z + zspan - 1) / zspan, (gd.y + 3) / 4, gd.x);
   hipLaunchKernelGGL(k_pull, grid, vol_block(), 0, st, src, sd, A, dst, gd, tol, done);
 }
 
