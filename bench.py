@@ -201,7 +201,7 @@ def main():
     def step():
         for yc in y:  # same start every step -> identical work
             yc.dat.zero_()
-        U._update_admm(x, y, z, w, rho, tmp, None, 0, sett)
+        U._update_y(x, y, z, w, rho, tmp, sett)
 
     for _ in range(args.warmup):
         step()

@@ -170,6 +170,29 @@ int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const float *b, f
                     int32_t max_iter, double tol, int32_t stop_mode, int32_t precond_mode,
                     int32_t *iters_out, double *obj_trace, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Next rows of the path: the updates and sums that follow the
+ * y-update inside every ADMM iteration  (unires/_update.py:154-195, 396-427)
+ * ---------------------------------------------------------------------- */
+
+/* UPDATE z and w  (_update.py:160-193), all channels:
+ *   u_c = w_c/rho + lam_c D y_c ;  s = max(|u| - 1/rho, 0) / (|u| + 1e-7), |u| joint over c,d
+ *   z_c = s u_c ;  w_c += rho (lam_c D y_c - z_c)
+ * y_ptrs / lam: HOST arrays of n_channels device pointers / scalars (n_channels <= 8);
+ * z, w: (C,3,X,Y,Z) device, updated in place; jtv: (X,Y,Z) device, receives s (the
+ * reference returns it as `tmp`, _update.py:195).  alpha is the over-relaxation
+ * parameter (1 = none). */
+int unires_zw_update(const float *const *y_ptrs, const float *lam, int32_t n_channels,
+                     const int32_t dim[3], const float vx[3], float rho, float alpha, float *z,
+                     float *w, float *jtv, void *stream);
+
+/* -ln p(y) = sum_v sqrt(sum_c |lam_c D y_c|^2)  (_update.py:419-425) -> *out_dev (float64). */
+int unires_nll_prior(const float *const *y_ptrs, const float *lam, int32_t n_channels,
+                     const int32_t dim[3], const float vx[3], double *out_dev, void *stream);
+
+/* sum_{x != 0} (x - ay)^2 in float64  (_update.py:414-417; the caller multiplies by tau/2). */
+int unires_masked_sse(const float *x, const float *ay, int64_t n, double *out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -178,6 +178,6 @@ def run_gpu_update_y(prob, device='cuda:0', max_iter=20, tol=1e-3, stop='max_gai
     z, w = prob['z'].to(device), prob['w'].to(device)
     tmp = torch.zeros_like(y[0].dat)
     info = []
-    U._update_admm(x, y, z, w, prob['rho'], tmp, None, 0, sett, info=info)
+    U._update_y(x, y, z, w, prob['rho'], tmp, sett, info=info)
     torch.cuda.synchronize()
     return [yc.dat for yc in y], info

@@ -182,6 +182,51 @@ def test_large_volume_properties(dev):
     assert r1 < 0.2 * r0
 
 
+@pytest.mark.parametrize('case', ['sr_3ch_axes', 'dn_2ch', 'id_2rep', 'sr_aniso'])
+@pytest.mark.parametrize('alpha', [1.0, 1.5])
+def test_zw_update_and_objective_match_oracle(dev, case, alpha):
+    """z/w updates and the objective, same inputs as the oracle."""
+    import unires_amd as U
+    prob = make_problem(seed=17, **CASES[case])
+    xo, yo = oracle_structs(prob)
+    xg, yg, sett = gpu_structs(prob, dev)
+    sett.alpha = alpha
+    rho = torch.tensor(prob['rho'])
+    zo, wo = prob['z'].clone() * 50, prob['w'].clone() * 50
+    zg, wg = zo.clone().to(dev), wo.clone().to(dev)
+    n_ref = O.compute_nll(xo, yo, prob['method'], prob['do_proj'])
+    n_gpu = U._compute_nll(xg, yg, sett, float(rho))
+    for a, b in zip(n_gpu, n_ref):
+        assert abs(a.item() - b.item()) < 2e-5 * abs(b.item())
+    zo, wo, tmp_o = O.update_zw(yo, zo, wo, rho, alpha=alpha)
+    tmp = torch.zeros_like(yg[0].dat)
+    zg, wg, tmp = U._update_zw(yg, zg, wg, float(rho), tmp, sett)
+    assert rel_err(zg.cpu(), zo) < 2e-5 and rel_err(wg.cpu(), wo) < 2e-5
+    assert rel_err(tmp.cpu(), tmp_o) < 2e-5
+
+
+def test_full_admm_iterations_track_the_oracle(dev):
+    """Three complete ADMM iterations (y, objective, z, w) against the oracle."""
+    import unires_amd as U
+    prob = make_problem(seed=18, **CASES['sr_3ch_axes'])
+    xo, yo = oracle_structs(prob)
+    xg, yg, sett = gpu_structs(prob, dev)
+    rho = torch.tensor(prob['rho'])
+    zo, wo = prob['z'].clone(), prob['w'].clone()
+    zg, wg = zo.clone().to(dev), wo.clone().to(dev)
+    tmp = torch.zeros_like(yg[0].dat)
+    obj = torch.zeros((3, 3), dtype=torch.float64, device=dev)
+    for it in range(3):
+        yo = O.update_y(xo, yo, zo, wo, rho, prob['method'], prob['do_proj'])
+        ref_obj = O.compute_nll(xo, yo, prob['method'], prob['do_proj'])
+        zo, wo, _ = O.update_zw(yo, zo, wo, rho)
+        yg, zg, wg, tmp, obj = U._update_admm(xg, yg, zg, wg, float(rho), tmp, obj, it, sett)
+        for c in range(3):
+            assert rel_err(yg[c].dat.cpu(), yo[c].dat) < GATE, (it, c)
+        assert abs(obj[it, 0].item() - ref_obj[0].item()) < 1e-4 * abs(ref_obj[0].item())
+    assert rel_err(zg.cpu(), zo) < 5e-4 and rel_err(wg.cpu(), wo) < 5e-4
+
+
 def test_gather_push_variant_matches_oracle(dev):
     """The alternative gather-form push (UNIRES_PUSH=gather, chosen at library load)
     runs the same parity gate in a fresh process."""

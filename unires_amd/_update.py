@@ -1,8 +1,13 @@
 """ADMM updates - host-side mirror of the y-update block of unires/_update.py
 (:105-152), plus _step_size (:35-64) and _admm_aux (:17-32)."""
+import ctypes as C
+
 import torch
 
-from ._project import _channel_plan
+from . import _lib
+from ._lib import check, f3, i3
+from ._ops import _ptr, _stream
+from ._project import _channel_plan, _proj
 from .spatial import voxel_size
 
 
@@ -45,9 +50,58 @@ def _update_y(x, y, z, w, rho, tmp, sett, info=None):
     return y
 
 
+def _chan_args(y):
+    for yc in y:
+        if not yc.dat.is_cuda or yc.dat.dtype != torch.float32 or not yc.dat.is_contiguous():
+            raise RuntimeError('unires_amd: y[c].dat must be contiguous float32 CUDA/HIP tensors')
+    ptrs = (C.c_void_p * len(y))(*[yc.dat.data_ptr() for yc in y])
+    lams = (C.c_float * len(y))(*[float(yc.lam) for yc in y])
+    return ptrs, lams
+
+
+def _update_zw(y, z, w, rho, tmp, sett):
+    """UPDATE z and w  (unires/_update.py:160-193): joint-TV shrinkage and dual ascent,
+    two fused kernels per channel instead of three im_gradient passes and a dozen
+    temporaries.  ``tmp`` receives the shrinkage image, as in the reference."""
+    for t in (z, w):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() \
+                or tuple(t.shape) != (len(y), 3) + tuple(y[0].dim):
+            raise ValueError('unires_amd: z/w must be contiguous (C,3,X,Y,Z) float32 device tensors')
+    if not tmp.is_contiguous() or tuple(tmp.shape) != tuple(y[0].dim):
+        raise ValueError('unires_amd: tmp must be a contiguous (X,Y,Z) tensor')
+    vx = [float(v) for v in voxel_size(y[0].mat).tolist()]
+    ptrs, lams = _chan_args(y)
+    check(_lib.load().unires_zw_update(ptrs, lams, len(y), i3(y[0].dim), f3(vx), float(rho),
+                                       float(sett.alpha), _ptr(z), _ptr(w), _ptr(tmp), _stream()))
+    return z, w, tmp
+
+
+def _compute_nll(x, y, sett, rho, sum_dtype=torch.float64):
+    """Negative model log-likelihood (unires/_update.py:396-427); returns 0-d float64
+    device tensors (nll_yx, nll_xy, nll_y) without synchronising."""
+    dev = y[0].dat.device
+    lib = _lib.load()
+    vx = [float(v) for v in voxel_size(y[0].mat).tolist()]
+    nll_xy = torch.zeros((), dtype=torch.float64, device=dev)
+    sse = torch.zeros((), dtype=torch.float64, device=dev)
+    for c in range(len(x)):
+        for n in range(len(x[c])):
+            Ay = _proj('A', y[c].dat, x[c], y[c], n=n, method=sett.method, do=sett.do_proj)
+            xd = x[c][n].dat.contiguous()
+            check(lib.unires_masked_sse(_ptr(xd), _ptr(Ay), xd.numel(), _ptr(sse), _stream()))
+            nll_xy = nll_xy + 0.5 * float(x[c][n].tau) * sse
+    ptrs, lams = _chan_args(y)
+    nll_y = torch.zeros((), dtype=torch.float64, device=dev)
+    check(lib.unires_nll_prior(ptrs, lams, len(y), i3(y[0].dim), f3(vx), _ptr(nll_y), _stream()))
+    return nll_xy + nll_y, nll_xy, nll_y
+
+
 def _update_admm(x, y, z, w, rho, tmp, obj, n_iter, sett, info=None):
-    """One ADMM iteration.  This round builds the y-update (the hot path);
-    the z/w updates and the objective (unires/_update.py:154-195) are the next
-    rows of SURVEY.md 8(f)."""
+    """One ADMM iteration (unires/_update.py:105-195): y-update (CG), objective,
+    z-update, w-update - same order, same in-place semantics, `tmp` returned as the
+    joint-TV shrinkage image."""
     y = _update_y(x, y, z, w, rho, tmp, sett, info)
+    if obj is not None and sett.tolerance > 0:
+        obj[n_iter, 0], obj[n_iter, 1], obj[n_iter, 2] = _compute_nll(x, y, sett, rho)
+    z, w, tmp = _update_zw(y, z, w, rho, tmp, sett)
     return y, z, w, tmp, obj

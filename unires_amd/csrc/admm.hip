@@ -1,0 +1,156 @@
+// admm.hip - the updates that follow the y-update in every ADMM iteration
+// (unires/_update.py:154-195): joint-total-variation
+// shrinkage of z, dual ascent on w, and the objective's prior / likelihood sums.
+//
+// The reference evaluates im_gradient three times per channel and materialises a
+// dozen volume-sized temporaries; here Dy is recomputed in registers:
+//   k_jtv_scale : s(v) = max(n - 1/rho, 0) / (n + 1e-7),  n = sqrt(sum_c |w_c/rho + lam_c D y_c|^2)
+//   k_zw_update : z_c = s * (w_c/rho + lam_c D y_c);  w_c += rho * (lam_c D y_c - z_c)
+// (alpha == 1 path; over-relaxation is a per-voxel blend with z_old and is built too).
+#include "admm.hpp"
+
+namespace unires {
+
+struct ChanPtrs {  // up to 8 channels per launch
+  const float *y[8];
+  float lam[8];
+  int n;
+};
+
+// forward differences of y at (i,j,k), zero bound, times lam / vx
+__device__ __forceinline__ void grad_at(const float *__restrict__ y, size_t idx, int i, int j,
+                                        int k, const Dim3i &d, float sx, float sy, float sz,
+                                        float &gx, float &gy, float &gz) {
+  const size_t px = (size_t)d.y * d.z, py = d.z;
+  const bool hx = i + 1 < d.x, hy = j + 1 < d.y, hz = k + 1 < d.z;
+  const float c = y[idx];
+  const float vx = y[hx ? idx + px : idx], vy = y[hy ? idx + py : idx], vz = y[hz ? idx + 1 : idx];
+  gx = ((hx ? vx : 0.f) - c) * sx;
+  gy = ((hy ? vy : 0.f) - c) * sy;
+  gz = ((hz ? vz : 0.f) - c) * sz;
+}
+
+// s = shrinkage factor of the joint TV norm (written to `scale`); optional partial of
+// sum(n) (the -ln p(y) term of the objective when called with w = 0, rho = 1)
+__global__ void __launch_bounds__(kBlock)
+    k_jtv_scale(ChanPtrs C, const float *__restrict__ w, const float *__restrict__ z_old, Dim3i d,
+                float ivx, float ivy, float ivz, float rho, float alpha, float *__restrict__ scale,
+                double *__restrict__ partials /* single accumulator */, int norm_only) {
+  const int tz = (d.z + kWave - 1) / kWave, ty = (d.y + 3) / 4;
+  const long long ntiles = (long long)tz * ty * d.x;
+  const size_t n = d.numel();
+  const float irho = 1.f / rho;
+  double tot = 0.0;
+  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int kc = (int)(t % tz);
+    const long long t2 = t / tz;
+    const int jq = (int)(t2 % ty), i = (int)(t2 / ty);
+    const int k = kc * kWave + threadIdx.x, j = jq * 4 + threadIdx.y;
+    if (k >= d.z || j >= d.y) continue;
+    const size_t idx = ((size_t)i * d.y + j) * d.z + k;
+    float acc = 0.f;
+    for (int c = 0; c < C.n; ++c) {
+      float gx, gy, gz;
+      grad_at(C.y[c], idx, i, j, k, d, C.lam[c] * ivx, C.lam[c] * ivy, C.lam[c] * ivz, gx, gy, gz);
+      const size_t o = (size_t)c * 3 * n + idx;
+      if (alpha != 1.f) {  // Dy = alpha*Dy + (1-alpha)*z_old   (_update.py:169-170)
+        gx = alpha * gx + (1.f - alpha) * z_old[o];
+        gy = alpha * gy + (1.f - alpha) * z_old[o + n];
+        gz = alpha * gz + (1.f - alpha) * z_old[o + 2 * n];
+      }
+      if (!norm_only) {
+        gx += w[o] * irho, gy += w[o + n] * irho, gz += w[o + 2 * n] * irho;
+      }
+      acc += gx * gx + gy * gy + gz * gz;
+    }
+    const float nrm = sqrtf(acc);
+    if (norm_only) {
+      tot += (double)nrm;
+    } else {
+      scale[idx] = fmaxf(nrm - irho, 0.f) / (nrm + 1e-7f);
+    }
+  }
+  if (partials) {  // one float64 atomic per workgroup (<= 2048 per launch, once per ADMM iteration)
+    const double s = block_sum(tot);
+    if (threadIdx.x == 0 && threadIdx.y == 0) atomicAdd(partials, s);
+  }
+}
+
+// z_c = s * (w_c/rho + Dy_c);  w_c += rho * (Dy_c - z_c)     for ONE channel
+__global__ void __launch_bounds__(kBlock)
+    k_zw_update(const float *__restrict__ y, float lam, const float *__restrict__ scale,
+                float *__restrict__ z, float *__restrict__ w, Dim3i d, float ivx, float ivy,
+                float ivz, float rho, float alpha) {
+  const int k = blockIdx.x * kWave + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int i = blockIdx.z;
+  if (k >= d.z || j >= d.y) return;
+  const size_t n = d.numel();
+  const size_t idx = ((size_t)i * d.y + j) * d.z + k;
+  float g[3];
+  grad_at(y, idx, i, j, k, d, lam * ivx, lam * ivy, lam * ivz, g[0], g[1], g[2]);
+  const float s = scale[idx], irho = 1.f / rho;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const size_t o = (size_t)a * n + idx;
+    float dy = g[a];
+    if (alpha != 1.f) dy = alpha * dy + (1.f - alpha) * z[o];
+    const float wo = w[o];
+    const float zn = s * (wo * irho + dy);
+    z[o] = zn;
+    w[o] = wo + rho * (dy - zn);
+  }
+}
+
+// partial of sum_{x != 0} (x - Ay)^2   (masked likelihood term, _update.py:414-417)
+__global__ void __launch_bounds__(kBlock)
+    k_masked_sse(const float *__restrict__ x, const float *__restrict__ ay, size_t n,
+                 double *__restrict__ partials) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float xv = x[i];
+    if (xv != 0.f) {
+      const float r = xv - ay[i];
+      acc += (double)__fmul_rn(r, r);
+    }
+  }
+  const double s = block_sum(acc);
+  if (threadIdx.x == 0) atomicAdd(partials, s);
+}
+
+static inline dim3 vblock() { return dim3(kWave, kBlock / kWave, 1); }
+static inline int tile_blocks(Dim3i d) {
+  const long long nt = (long long)((d.z + kWave - 1) / kWave) * ((d.y + 3) / 4) * d.x;
+  return (int)(nt < kMaxPartials ? nt : kMaxPartials);
+}
+
+int launch_jtv_scale(const float *const *y, const float *lam, int nc, const float *w,
+                     const float *z_old, Dim3i d, const float vx[3], float rho, float alpha,
+                     float *scale, double *partials, int norm_only, hipStream_t st) {
+  if (nc > 8) return -1;
+  ChanPtrs C;
+  C.n = nc;
+  for (int c = 0; c < nc; ++c) C.y[c] = y[c], C.lam[c] = lam[c];
+  const int g = tile_blocks(d);
+  hipLaunchKernelGGL(k_jtv_scale, dim3(g), vblock(), 0, st, C, w, z_old, d, 1.f / vx[0],
+                     1.f / vx[1], 1.f / vx[2], rho, alpha, scale, partials, norm_only);
+  return g;
+}
+
+void launch_zw_update(const float *y, float lam, const float *scale, float *z, float *w, Dim3i d,
+                      const float vx[3], float rho, float alpha, hipStream_t st) {
+  const dim3 grid((d.z + kWave - 1) / kWave, (d.y + 3) / 4, d.x);
+  hipLaunchKernelGGL(k_zw_update, grid, vblock(), 0, st, y, lam, scale, z, w, d, 1.f / vx[0],
+                     1.f / vx[1], 1.f / vx[2], rho, alpha);
+}
+
+int launch_masked_sse(const float *x, const float *ay, size_t n, double *partials, hipStream_t st) {
+  size_t b = (n + kBlock - 1) / kBlock;
+  if (b > (size_t)kMaxPartials) b = kMaxPartials;
+  if (b < 1) b = 1;
+  hipLaunchKernelGGL(k_masked_sse, dim3((int)b), dim3(kBlock), 0, st, x, ay, n, partials);
+  return (int)b;
+}
+
+}  // namespace unires

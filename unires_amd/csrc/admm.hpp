@@ -1,0 +1,16 @@
+// admm.hpp - launchers of the z/w-update and objective kernels (admm.hip).
+#pragma once
+#include "common.hpp"
+
+namespace unires {
+
+// scale = JTV shrinkage factor (norm_only == 0) or partials of sum(JTV norm) (norm_only == 1);
+// returns the number of partials written (or -1 if nc > 8).
+int launch_jtv_scale(const float *const *y, const float *lam, int nc, const float *w,
+                     const float *z_old, Dim3i d, const float vx[3], float rho, float alpha,
+                     float *scale, double *partials, int norm_only, hipStream_t st);
+void launch_zw_update(const float *y, float lam, const float *scale, float *z, float *w, Dim3i d,
+                      const float vx[3], float rho, float alpha, hipStream_t st);
+int launch_masked_sse(const float *x, const float *ay, size_t n, double *partials, hipStream_t st);
+
+}  // namespace unires

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "admm.hpp"
 #include "cg.hpp"
 #include "fused.hpp"
 #include "ops.hpp"
@@ -609,5 +610,63 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
     HIP_TRY(hipStreamSynchronize(st));
     *iters_out = it;
   }
+  return UNIRES_OK;
+}
+
+// --------------------------------------------------------------------------
+// z / w updates and objective sums  (unires/_update.py:154-195, 396-427)
+// --------------------------------------------------------------------------
+static int check_channels(const float *const *y_ptrs, const float *lam, int32_t n) {
+  if (!y_ptrs || !lam) return fail(UNIRES_ERR_NULL, "null argument");
+  if (n < 1 || n > 8) return fail(UNIRES_ERR_UNSUPPORTED, "1..8 channels per call");
+  for (int c = 0; c < n; ++c)
+    if (!y_ptrs[c]) return fail(UNIRES_ERR_NULL, "null channel pointer");
+  return UNIRES_OK;
+}
+
+extern "C" int unires_zw_update(const float *const *y_ptrs, const float *lam, int32_t n_channels,
+                                const int32_t dim[3], const float vx[3], float rho, float alpha,
+                                float *z, float *w, float *jtv, void *stream) {
+  int rc = check_channels(y_ptrs, lam, n_channels);
+  if (rc) return rc;
+  if (!z || !w || !jtv || !dim) return fail(UNIRES_ERR_NULL, "null argument");
+  if (!dims_ok(dim)) return fail(UNIRES_ERR_DIM, "bad dimensions");
+  if (!vx_ok(vx)) return fail(UNIRES_ERR_ARG, "voxel size must be positive");
+  if (!(rho > 0.f)) return fail(UNIRES_ERR_ARG, "rho must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  const Dim3i d = mk(dim);
+  launch_jtv_scale(y_ptrs, lam, n_channels, w, z, d, vx, rho, alpha, jtv, nullptr, 0, st);
+  const size_t n = d.numel();
+  for (int c = 0; c < n_channels; ++c)
+    launch_zw_update(y_ptrs[c], lam[c], jtv, z + (size_t)c * 3 * n, w + (size_t)c * 3 * n, d, vx,
+                     rho, alpha, st);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+extern "C" int unires_nll_prior(const float *const *y_ptrs, const float *lam, int32_t n_channels,
+                                const int32_t dim[3], const float vx[3], double *out_dev,
+                                void *stream) {
+  int rc = check_channels(y_ptrs, lam, n_channels);
+  if (rc) return rc;
+  if (!out_dev || !dim) return fail(UNIRES_ERR_NULL, "null argument");
+  if (!dims_ok(dim)) return fail(UNIRES_ERR_DIM, "bad dimensions");
+  if (!vx_ok(vx)) return fail(UNIRES_ERR_ARG, "voxel size must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(double), st));
+  launch_jtv_scale(y_ptrs, lam, n_channels, nullptr, nullptr, mk(dim), vx, 1.f, 1.f, nullptr,
+                   out_dev, 1, st);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+extern "C" int unires_masked_sse(const float *x, const float *ay, int64_t n, double *out_dev,
+                                 void *stream) {
+  if (!x || !ay || !out_dev) return fail(UNIRES_ERR_NULL, "null argument");
+  if (n < 1) return fail(UNIRES_ERR_DIM, "bad length");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(double), st));
+  launch_masked_sse(x, ay, (size_t)n, out_dev, st);
+  CHECK_LAUNCH();
   return UNIRES_OK;
 }
