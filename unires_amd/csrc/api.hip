@@ -155,8 +155,11 @@ extern "C" int unires_push3d_affine(const float *src, const int32_t gdim[3], con
   ep.accumulate = accumulate ? 1 : 0;
   SplatSafety safe;
   splat_safety(A, safe.row_sep, safe.use_atomics);
-  (void)launch_push_tile(ps, A, Ainv, safe, alpha, fov_tol, ep, dst, mk(ddim), nullptr,
-                         (hipStream_t)stream);
+  static const bool use_tile = getenv("UNIRES_PUSH") && !strcmp(getenv("UNIRES_PUSH"), "tile");
+  if (use_tile || launch_splat(ps, A, Ainv, safe, alpha, fov_tol, ep, dst, mk(ddim), nullptr,
+                               (hipStream_t)stream))
+    (void)launch_push_tile(ps, A, Ainv, safe, alpha, fov_tol, ep, dst, mk(ddim), nullptr,
+                           (hipStream_t)stream);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -440,6 +443,10 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
     if (!launch_push_gather(g, src.gd, A, R.Afinv, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
       return ep.partials ? push_gather_blocks(pl->dy) : 0;
   }
+  static const bool use_tile = getenv("UNIRES_PUSH") && !strcmp(getenv("UNIRES_PUSH"), "tile");
+  if (!use_tile &&
+      !launch_splat(src, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
+    return ep.partials ? splat_blocks(pl->dy) : 0;
   if (launch_push_tile(src, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st)) {
     launch_conv_up(src.data, src.xd, src.T, src.S, pl->gbuf, src.gd, st);
     PushSrc d = src;

@@ -39,6 +39,13 @@ int launch_push_tile(const PushSrc &src, const Affine &A, const Affine &Ainv,
                      const SplatSafety &safe, float alpha, float tol, const PushEpilogue &ep,
                      float *dst, Dim3i dd, const int *done, hipStream_t st);
 
+// Lean specialisation of the tile push (splat.hip): grid-space source, or conv_up along z
+// with fan-in <= 2.  Non-zero return: not applicable, nothing launched.
+int splat_blocks(Dim3i dd);
+int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const SplatSafety &safe,
+                 float alpha, float tol, const PushEpilogue &ep, float *dst, Dim3i dd,
+                 const int *done, hipStream_t st);
+
 // Gather-form push from a grid-space volume (no atomics, no LDS tile, deterministic).
 int push_gather_blocks(Dim3i dd);
 int launch_push_gather(const float *src, Dim3i gd, const Affine &A, const Affine &Ainv,

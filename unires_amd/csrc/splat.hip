@@ -1,0 +1,376 @@
+// splat.hip - k_splat: the lean, specialised form of the owner-computes push
+// (same algorithm and race-freedom argument as k_push_tile in fused.hip, which stays
+// as the general fallback) for the two sources the headline configurations use:
+//
+//   CONVZ = false : grid-space source (denoising regime, op-level push)
+//   CONVZ = true  : thick slices along z: conv_up along z only, fan-in <= 2
+//                   (every rect profile), regenerated on the fly from x-space
+//
+// Differences that matter for instruction count (this kernel is issue-bound, not
+// HBM-bound - DESIGN.md 4): one z table instead of three, the two x-space values of a
+// grid voxel fetched with ONE 8-byte load, lane hand-over with DPP wave shifts instead
+// of ds_bpermute, a straight-line splat for the common no-conflict case, small kernel
+// argument block (no SGPR spills).
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "fused.hpp"
+
+namespace unires {
+
+struct SplatArgs {
+  const float *src;
+  int gx, gy, gz;     // grid dims
+  int xdy, xdz;       // x-space dims (CONVZ)
+  int nkz, sz;        // z taps / stride (CONVZ)
+  float kz[UNIRES_MAX_TAPS];
+  float se, so;       // even/odd slice scaling along z (1,1 = none)
+  Affine A, Ainv;
+  float alpha, tol;
+  const float *p;
+  float a0, cx, cy, cz;
+  float *dst;
+  Dim3i dd;
+  int accumulate;
+  double *partials;
+  int row_sep;
+  int dbg;
+};
+
+constexpr int kSTX = 8, kSTY = 8, kSTZ = 30;
+
+struct Seg {  // one <=32-long run of a grid row (ui,uj)
+  short ui, uj, k0;
+  unsigned char len, solo;  // solo: its partner row is too close -> splat in its own turn
+};
+
+#ifdef UNIRES_NO_DPP
+__device__ __forceinline__ int dpp_up1(int v) { return __shfl_up(v, 1, kWave); }
+__device__ __forceinline__ int dpp_dn1(int v) { return __shfl_down(v, 1, kWave); }
+#else
+__device__ __forceinline__ int dpp_up1(int v) {  // lane i <- lane i-1 (lane 0 keeps its own)
+  return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_dn1(int v) {  // lane i <- lane i+1 (lane 63 keeps its own)
+  return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false);
+}
+#endif
+__device__ __forceinline__ float dpp_up1f(float v) {
+  return __int_as_float(dpp_up1(__float_as_int(v)));
+}
+
+#ifdef UNIRES_HARD_FENCE
+#define SPLAT_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define SPLAT_FENCE() asm volatile("" ::: "memory")
+#endif
+
+template <bool CONVZ>
+__global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restrict__ done) {
+  if (done && *done) return;
+  constexpr int TX = kSTX, TY = kSTY, TZ = kSTZ;
+  constexpr int SZ = TZ + 2, SY = TY + 2, SXd = TX + 2, N = SXd * SY * SZ;
+  constexpr int XS = SY * SZ, YS = SZ;  // strides of the aproned accumulator (x, y; z = 1)
+  constexpr int kSegs = 256;
+  __shared__ __align__(16) float acc[N];
+  __shared__ __align__(8) Seg rows[kSegs];
+  __shared__ __align__(16) float4 ztab[64];  // {bits(k offset), w0, w1, -}
+  const int lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
+  const Dim3i dd = P.dd;
+  const float *__restrict__ src = P.src;
+  const float *__restrict__ pin = P.p;
+  float *__restrict__ dst = P.dst;
+  const int ntx = (dd.x + TX - 1) / TX, nty = (dd.y + TY - 1) / TY, ntz = (dd.z + TZ - 1) / TZ;
+  const int ntiles = ntx * nty * ntz;
+  const int nxcd = 8;  // XCD-aware persistent schedule (see k_push_tile)
+  const int per_xcd = (ntiles + nxcd - 1) / nxcd;
+  const int xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd;
+  const int slots = (gridDim.x + nxcd - 1 - xcd) / nxcd;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const float c0 = P.A.m[2], c1 = P.A.m[6], c2 = P.A.m[10];
+  const float inv_sz = CONVZ ? 1.f / (float)P.sz : 1.f;
+  double dot = 0.0;
+  for (int tl = slot; tl < per_xcd; tl += slots) {
+    const int t = xcd * per_xcd + tl;
+    if (t >= ntiles) break;
+    const int tzi = t % ntz, tyi = (t / ntz) % nty, txi = t / (ntz * nty);
+    const int x0 = txi * TX, y0 = tyi * TY, z0 = tzi * TZ;
+    const int ex = min(TX, dd.x - x0), ey = min(TY, dd.y - y0), ez = min(TZ, dd.z - z0);
+    SPLAT_FENCE();
+    for (int i = lane; i < N / 4; i += kWave)
+      reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float flx = (float)(x0 - 1), fly = (float)(y0 - 1), flz = (float)(z0 - 1);
+    const float fhx = (float)(x0 + ex), fhy = (float)(y0 + ey), fhz = (float)(z0 + ez);
+    const bool edge = x0 == 0 || y0 == 0 || z0 == 0 || x0 + ex >= dd.x || y0 + ey >= dd.y ||
+                      z0 + ez >= dd.z;
+    // grid-space bounding box of everything that can touch the tile
+    float lo0 = 1e30f, lo1 = 1e30f, lo2 = 1e30f, hi0 = -1e30f, hi1 = -1e30f, hi2 = -1e30f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float ux, uy, uz;
+      affine_point(P.Ainv, (c & 4) ? fhx : flx, (c & 2) ? fhy : fly, (c & 1) ? fhz : flz, ux, uy,
+                   uz);
+      lo0 = fminf(lo0, ux), hi0 = fmaxf(hi0, ux);
+      lo1 = fminf(lo1, uy), hi1 = fmaxf(hi1, uy);
+      lo2 = fminf(lo2, uz), hi2 = fmaxf(hi2, uz);
+    }
+    const int bx0 = max(0, (int)floorf(lo0 - 0.01f)), bx1 = min(P.gx - 1, (int)ceilf(hi0 + 0.01f));
+    const int by0 = max(0, (int)floorf(lo1 - 0.01f)), by1 = min(P.gy - 1, (int)ceilf(hi1 + 0.01f));
+    const int bz0 = max(0, (int)floorf(lo2 - 0.01f)), bz1 = min(P.gz - 1, (int)ceilf(hi2 + 0.01f));
+    const int nby = by1 - by0 + 1;
+    const int nrow_cand = max(bx1 - bx0 + 1, 0) * max(nby, 0);
+    if (CONVZ) {
+      // which x-space slices feed grid slice uz = bz0 + lane, packed for ONE 8-byte load
+      const int uz = min(bz0 + lane, P.gz - 1);
+      int khi = (int)(((float)uz + 0.5f) * inv_sz);
+      if (khi * P.sz > uz) --khi;
+      if ((khi + 1) * P.sz <= uz) ++khi;                  // khi = uz / sz exactly
+      khi = min(khi, P.xdz - 1);
+      const int tt = uz - P.nkz + 1;
+      int klo = 0;
+      if (tt > 0) {
+        klo = (int)(((float)(tt + P.sz - 1) + 0.5f) * inv_sz);
+        if (klo * P.sz > tt + P.sz - 1) --klo;
+        if ((klo + 1) * P.sz <= tt + P.sz - 1) ++klo;     // ceil(tt / sz)
+      }
+      const int n = khi - klo + 1;
+      float w0 = 0.f, w1 = 0.f;
+      if (n >= 1) w0 = P.kz[uz - P.sz * klo] * ((klo & 1) ? P.so : P.se);
+      if (n >= 2) w1 = P.kz[uz - P.sz * (klo + 1)] * (((klo + 1) & 1) ? P.so : P.se);
+      int koff = klo;
+      if (n < 1) koff = 0;
+      if (koff > P.xdz - 2) {  // last slice: fetch the pair (xdz-2, xdz-1), weight on .y
+        koff = P.xdz - 2;
+        w1 = w0, w0 = 0.f;
+      }
+      ztab[lane] = make_float4(__int_as_float(koff), w0, w1, 0.f);
+    }
+    // ---- phase A: rows (ui,uj) -> exact grid-z intervals -> <=32-long segments ----
+    const int segs_per_row = (max(bz1 - bz0 + 1, 1) + 31) / 32;
+    int nseg = 0;
+    for (int rc0 = 0;;) {
+      if (rc0 < nrow_cand) {
+        const int rc = rc0 + lane;
+        int ui = 0, uj = 0, k0 = 0, k1 = -1;
+        if (rc < nrow_cand) {
+          const int a = rc / nby, b = rc - a * nby;
+          ui = bx0 + a, uj = by0 + b;
+          float r0, r1, r2;
+          affine_point(P.A, (float)ui, (float)uj, 0.f, r0, r1, r2);
+          k0 = bz0, k1 = bz1;
+          const float rr[3] = {r0, r1, r2}, cc[3] = {c0, c1, c2};
+          const float lw[3] = {flx, fly, flz}, hg[3] = {fhx, fhy, fhz};
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            if (fabsf(cc[d]) > 1e-6f) {
+              float ta = (lw[d] - rr[d]) / cc[d], tb = (hg[d] - rr[d]) / cc[d];
+              const float tmin = fminf(ta, tb), tmax = fmaxf(ta, tb);
+              ta = fmaxf(tmin, -1e6f), tb = fminf(tmax, 1e6f);
+              k0 = max(k0, (int)ceilf(ta - 2e-3f - 1e-5f * fabsf(ta)));
+              k1 = min(k1, (int)floorf(tb + 2e-3f + 1e-5f * fabsf(tb)));
+            } else if (rr[d] < lw[d] - 0.01f || rr[d] >= hg[d] + 0.01f) {
+              k1 = k0 - 1;
+            }
+          }
+        }
+        bool has = k1 >= k0;
+        while (__any(has)) {
+          const unsigned long long m = __ballot(has);
+          const int pos = nseg + __popcll(m & lt_mask);
+          if (has && pos < kSegs)
+            rows[pos] = Seg{(short)ui, (short)uj, (short)k0, (unsigned char)min(32, k1 - k0 + 1), 0};
+          nseg += __popcll(m);
+          k0 += 32;
+          has = has && k1 >= k0;
+        }
+        rc0 += kWave;
+      }
+      const bool last = rc0 >= nrow_cand;
+      if (!last && nseg + kWave * segs_per_row <= kSegs) continue;
+      SPLAT_FENCE();
+      const int nr = min(nseg, kSegs);
+      const int npair = (nr + 1) / 2;
+      // partner rows (p, p + npair) closer than row_sep cannot share an instruction
+      for (int p = lane; p + npair < nr; p += kWave) {
+        const Seg a = rows[p], b = rows[p + npair];
+        if (max(abs(a.ui - b.ui), abs(a.uj - b.uj)) < P.row_sep) rows[p + npair].solo = 1;
+      }
+      SPLAT_FENCE();
+      // ---- phase B: half-wave per segment, lanes along grid z, kU pairs per batch ----
+      constexpr int kU = 4;
+      for (int p0 = 0; p0 < npair; p0 += kU) {
+        float val[kU];
+        int ui[kU], uj[kU], uk[kU];
+        bool act[kU], solo[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const int p = p0 + u;
+          const int idx = half ? p + npair : p;
+          const Seg R = rows[min(idx, nr - 1)];
+          act[u] = p < npair && idx < nr && hl < R.len;
+          solo[u] = R.solo && half;
+          ui[u] = R.ui, uj[u] = R.uj, uk[u] = min(R.k0 + hl, P.gz - 1);
+          if (CONVZ) {
+            const float4 tb = ztab[min(uk[u] - bz0, 63)];
+            const unsigned base =
+                __umul24(__umul24((unsigned)ui[u], (unsigned)P.xdy) + (unsigned)uj[u],
+                         (unsigned)P.xdz) + (unsigned)__float_as_int(tb.x);
+            const float2 pr = ld2_u(src + base);
+            val[u] = tb.y * pr.x + tb.z * pr.y;
+          } else {
+            const unsigned base =
+                __umul24(__umul24((unsigned)ui[u], (unsigned)P.gy) + (unsigned)uj[u],
+                         (unsigned)P.gz) + (unsigned)uk[u];
+            val[u] = src[base];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          float gx, gy, gz;
+          affine_point(P.A, (float)ui[u], (float)uj[u], (float)uk[u], gx, gy, gz);
+          bool ok = act[u] && gx >= flx && gx < fhx && gy >= fly && gy < fhy && gz >= flz && gz < fhz;
+          if (edge) ok = ok && in_fov(gx, gy, gz, dd, P.tol);
+          const float v = P.alpha * val[u];
+          ok = ok && v != 0.f;
+          const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+          const int lx = (int)fx - (x0 - 1), ly = (int)fy - (y0 - 1), lz = (int)fz - (z0 - 1);
+          const float wx1 = gx - fx, wy1 = gy - fy, wz1 = gz - fz;
+          const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
+          const int cell = ok ? (lx * SY + ly) * SZ + lz : -2 - lane;
+          const int lzk = ok ? lz : -2 - lane;
+          const float a00 = v * (wx0 * wy0), a01 = v * (wx0 * wy1), a10 = v * (wx1 * wy0),
+                      a11 = v * (wx1 * wy1);
+          float l00 = a00 * wz0, l01 = a01 * wz0, l10 = a10 * wz0, l11 = a11 * wz0;
+          const float u00 = a00 * wz1, u01 = a01 * wz1, u10 = a10 * wz1, u11 = a11 * wz1;
+          // a lane in the same z plane as its predecessor may overlap it inside one update
+          // group: replay it in a later turn (rare: |dz/dk| < 1 by a hair)
+          const int prev_lz = dpp_up1(lzk);  // executed by ALL lanes: a DPP read of a lane that
+                                             // is masked off returns the reader's own value
+          const bool dup = ok && hl > 0 && lzk == prev_lz;
+          const bool slow = __any(dup) || __any(ok && solo[u]) || (P.dbg & 1);
+          if (!slow) {
+            // common case, straight line: z-adjacent lanes hand their shared plane over in
+            // registers, then every lane updates ONE z plane (+ the top plane of lanes
+            // with nobody above them)
+            const int below = dpp_up1(cell), above = dpp_dn1(cell);
+            const float p00 = dpp_up1f(u00), p01 = dpp_up1f(u01), p10 = dpp_up1f(u10),
+                        p11 = dpp_up1f(u11);
+            const bool recv = ok && hl > 0 && below + 1 == cell;
+            const bool sent = ok && hl < 31 && above == cell + 1;
+            if (recv) l00 += p00, l01 += p01, l10 += p10, l11 += p11;
+            float *q = acc + (ok ? cell : 0);
+            SPLAT_FENCE();
+            if (ok) {
+              const float o00 = q[0], o01 = q[YS], o10 = q[XS], o11 = q[XS + YS];
+              q[0] = o00 + l00, q[YS] = o01 + l01, q[XS] = o10 + l10, q[XS + YS] = o11 + l11;
+            }
+            SPLAT_FENCE();
+            if (ok && !sent) {
+              const float o00 = q[1], o01 = q[YS + 1], o10 = q[XS + 1], o11 = q[XS + YS + 1];
+              q[1] = o00 + u00, q[YS + 1] = o01 + u01, q[XS + 1] = o10 + u10,
+              q[XS + YS + 1] = o11 + u11;
+            }
+            SPLAT_FENCE();
+          } else {
+            // turn schedule: (row B of a too-close pair) x (replayed same-plane neighbour);
+            // within a turn no hand-over, each lane updates both of its planes
+            const int myturn = (solo[u] ? 2 : 0) + (dup ? 1 : 0);
+            for (int turn = 0; turn < 4; ++turn) {
+              if (!__any(ok && myturn == turn)) continue;
+              SPLAT_FENCE();
+              if (ok && myturn == turn) {
+                float *q = acc + cell;
+                const float o00 = q[0], o01 = q[YS], o10 = q[XS], o11 = q[XS + YS];
+                q[0] = o00 + l00, q[YS] = o01 + l01, q[XS] = o10 + l10, q[XS + YS] = o11 + l11;
+              }
+              SPLAT_FENCE();
+              if (ok && myturn == turn) {
+                float *q = acc + cell;
+                const float o00 = q[1], o01 = q[YS + 1], o10 = q[XS + 1], o11 = q[XS + YS + 1];
+                q[1] = o00 + u00, q[YS + 1] = o01 + u01, q[XS + 1] = o10 + u10,
+                q[XS + YS + 1] = o11 + u11;
+              }
+              SPLAT_FENCE();
+            }
+          }
+        }
+      }
+      nseg = 0;
+      if (last) break;
+    }
+    SPLAT_FENCE();
+    // ---- epilogue: q = [q +] acc + a0 p + c DtD p ; dot += p*q  (one row per half-wave) ----
+    static_assert(TZ <= 32, "epilogue maps one row to a half-wave");
+#pragma unroll 4
+    for (int r = half; r < TX * TY; r += 2) {
+      const int lx = r / TY, ly = r % TY, lz = hl;
+      if (lx >= ex || ly >= ey || lz >= ez) continue;
+      const int i = x0 + lx, j = y0 + ly, k = z0 + lz;
+      const size_t idx = ((size_t)i * dd.y + j) * dd.z + k;
+      float q = acc[((lx + 1) * SY + ly + 1) * SZ + lz + 1];
+      float pc = 0.f;
+      if (pin) {
+        const float st = dtd_at(pin, idx, i, j, k, dd, P.cx, P.cy, P.cz, pc);
+        q += P.a0 * pc + st;
+      }
+      if (P.accumulate) q += dst[idx];
+      dst[idx] = q;
+      if (P.partials) dot += (double)__fmul_rn(pc, q);
+    }
+  }
+  if (P.partials) {
+    const double tot = wave_sum(dot);
+    if (lane == 0) P.partials[blockIdx.x] = tot;
+  }
+}
+
+int splat_blocks(Dim3i dd) {
+  const long long nt = (long long)((dd.x + kSTX - 1) / kSTX) * ((dd.y + kSTY - 1) / kSTY) *
+                       ((dd.z + kSTZ - 1) / kSTZ);
+  return (int)(nt < kMaxPartials ? nt : kMaxPartials);
+}
+
+// Returns non-zero (nothing launched) when the operator is outside this kernel's domain;
+// the caller then uses the general k_push_tile.
+int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const SplatSafety &safe,
+                 float alpha, float tol, const PushEpilogue &ep, float *dst, Dim3i dd,
+                 const int *done, hipStream_t st) {
+  if (safe.use_atomics) return 1;
+  if (dd.x > 32000 || dd.y > 32000 || dd.z > 32000) return 1;
+  SplatArgs P;
+  P.src = src.data;
+  P.gx = src.gd.x, P.gy = src.gd.y, P.gz = src.gd.z;
+  if (P.gx > 32000 || P.gy > 32000 || P.gz > 32000) return 1;
+  P.xdy = src.xd.y, P.xdz = src.xd.z;
+  P.nkz = 1, P.sz = 1, P.se = 1.f, P.so = 1.f;
+  if (src.convup) {
+    // conv_up must act along z only, with at most two x-space slices per grid slice
+    if (src.T.n[0] != 1 || src.T.n[1] != 1 || src.T.s[0] != 1 || src.T.s[1] != 1) return 1;
+    if (src.T.t[0][0] != 1.f || src.T.t[1][0] != 1.f) return 1;
+    if ((src.T.n[2] + src.T.s[2] - 1) / src.T.s[2] > 2 || src.xd.z < 2) return 1;
+    if (src.S.dim >= 0 && src.S.dim != 2) return 1;
+    P.nkz = src.T.n[2], P.sz = src.T.s[2];
+    for (int i = 0; i < UNIRES_MAX_TAPS; ++i) P.kz[i] = src.T.t[2][i];
+    if (src.S.dim == 2) P.se = src.S.e, P.so = src.S.o;
+  } else {
+    for (int i = 0; i < UNIRES_MAX_TAPS; ++i) P.kz[i] = 0.f;
+  }
+  P.A = A, P.Ainv = Ainv;
+  P.alpha = alpha, P.tol = tol;
+  P.p = ep.p, P.a0 = ep.a0, P.cx = ep.cx, P.cy = ep.cy, P.cz = ep.cz;
+  P.dst = dst, P.dd = dd;
+  P.accumulate = ep.accumulate;
+  P.partials = ep.partials;
+  P.row_sep = safe.row_sep;
+  static const int dbg = getenv("UNIRES_DBG") ? atoi(getenv("UNIRES_DBG")) : 0;
+  P.dbg = dbg;
+  const dim3 grid(splat_blocks(dd));
+  if (src.convup)
+    hipLaunchKernelGGL(k_splat<true>, grid, dim3(kWave), 0, st, P, done);
+  else
+    hipLaunchKernelGGL(k_splat<false>, grid, dim3(kWave), 0, st, P, done);
+  return 0;
+}
+
+}  // namespace unires
