@@ -38,7 +38,11 @@ struct SplatArgs {
   int dbg;
 };
 
-constexpr int kSTX = 8, kSTY = 8, kSTZ = 30;
+#ifndef UNIRES_STX
+#define UNIRES_STX 8  // measured on config 3: 8x4 218 us, 6x6 230, 4x8 249, 8x8 297, 4x4 329
+#define UNIRES_STY 4
+#endif
+constexpr int kSTX = UNIRES_STX, kSTY = UNIRES_STY, kSTZ = 30;
 
 struct Seg {  // one <=32-long run of a grid row (ui,uj)
   short ui, uj, k0;
@@ -72,7 +76,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
   constexpr int TX = kSTX, TY = kSTY, TZ = kSTZ;
   constexpr int SZ = TZ + 2, SY = TY + 2, SXd = TX + 2, N = SXd * SY * SZ;
   constexpr int XS = SY * SZ, YS = SZ;  // strides of the aproned accumulator (x, y; z = 1)
-  constexpr int kSegs = 256;
+  constexpr int kSegs = 128;
   __shared__ __align__(16) float acc[N];
   __shared__ __align__(8) Seg rows[kSegs];
   __shared__ __align__(16) float4 ztab[64];  // {bits(k offset), w0, w1, -}
@@ -328,7 +332,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
 int splat_blocks(Dim3i dd) {
   const long long nt = (long long)((dd.x + kSTX - 1) / kSTX) * ((dd.y + kSTY - 1) / kSTY) *
                        ((dd.z + kSTZ - 1) / kSTZ);
-  return (int)(nt < kMaxPartials ? nt : kMaxPartials);
+  return (int)(nt < kMaxPartials ? nt : kMaxPartials);  // persistent: ~14 resident waves per CU
 }
 
 // Returns non-zero (nothing launched) when the operator is outside this kernel's domain;
