@@ -59,35 +59,29 @@ __global__ void __launch_bounds__(kBlock)
   if (tid < 3 * UNIRES_MAX_TAPS) taps[tid] = (&T.t[0][0])[tid];
   const int o0x = blockIdx.z * ot.x, o0y = blockIdx.y * ot.y, o0z = blockIdx.x * ot.z;
   const int p0x = o0x * T.s[0], p0y = o0y * T.s[1], p0z = o0z * T.s[2];
-  const int lo[3] = {p0x, p0y, p0z};
-  const int hi[3] = {min(p0x + ptx - 1, gd.x - 1), min(p0y + pty - 1, gd.y - 1),
-                     min(p0z + ptz - 1, gd.z - 1)};
-  const bool interior = __syncthreads_and(corner_inside(A, tid & 7, lo, hi, sd)) && sd.z >= 2;
   const unsigned ny = sd.y, nz = sd.z, nynz = ny * nz;
   const int nrows = ptx * pty;
+  const float bx = (float)(sd.x - 1), by = (float)(sd.y - 1), bz = (float)(sd.z - 1);
   for (int row = wave; row < nrows; row += kBlock / kWave) {
     const int a = row / pty, b = row - a * pty;
     const int ux = p0x + a, uy = p0y + b;
     const bool row_in = ux < gd.x && uy < gd.y;
     const RowBase rb = affine_row(A, (float)min(ux, gd.x - 1), (float)min(uy, gd.y - 1));
     float *trow = tile + row * ptz;
-    if (interior) {
-#pragma unroll 2
-      for (int c = lane; c < ptz; c += kWave) {
-        const int uz = p0z + c;
-        float gx, gy, gz;
-        affine_along(A, rb, (float)min(uz, gd.z - 1), gx, gy, gz);
-        const float v = pull_interior(src, ny, nz, nynz, gx, gy, gz);
-        trow[c] = (row_in && uz < gd.z) ? v : 0.f;
-      }
-    } else {
-      for (int c = lane; c < ptz; c += kWave) {
-        const int uz = p0z + c;
-        float gx, gy, gz;
-        affine_along(A, rb, (float)min(uz, gd.z - 1), gx, gy, gz);
-        const float v = pull_sample(src, sd, gx, gy, gz, tol);
-        trow[c] = (row_in && uz < gd.z) ? v : 0.f;
-      }
+    for (int c0 = 0; c0 < ptz; c0 += kWave) {
+      const int c = c0 + lane;
+      const int uz = p0z + min(c, ptz - 1);
+      float gx, gy, gz;
+      affine_along(A, rb, (float)min(uz, gd.z - 1), gx, gy, gz);
+      // all 8 corners of every lane's sample inside the volume (then the FOV mask is 1 too):
+      // decided per wave-pass, so only the thin boundary shell takes the general path
+      const bool inside = gx >= 0.f && gx < bx && gy >= 0.f && gy < by && gz >= 0.f && gz < bz;
+      float v;
+      if (__all(inside) && sd.z >= 2)
+        v = pull_interior(src, ny, nz, nynz, gx, gy, gz);
+      else
+        v = pull_sample(src, sd, gx, gy, gz, tol);
+      if (c < ptz) trow[c] = (row_in && p0z + c < gd.z) ? v : 0.f;
     }
   }
   __syncthreads();

@@ -31,34 +31,32 @@ __global__ void __launch_bounds__(kBlock) k_pull(const float *__restrict__ src, 
   const int j = blockIdx.y * 4 + threadIdx.y;
   const int i = blockIdx.z;
   const int kbase = blockIdx.x * (kWave * kPullChunks);
-  const int lo[3] = {i, (int)blockIdx.y * 4, kbase};
-  const int hi[3] = {i, min((int)blockIdx.y * 4 + 3, gd.y - 1),
-                     min(kbase + kWave * kPullChunks - 1, gd.z - 1)};
-  const bool interior = __syncthreads_and(corner_inside(A, lane & 7, lo, hi, sd)) && sd.z >= 2;
   if (j >= gd.y) return;
   const RowBase rb = affine_row(A, (float)i, (float)j);
   float *row = dst + ((size_t)i * gd.y + j) * gd.z;
-  if (interior) {
-    const unsigned ny = sd.y, nz = sd.z, nynz = ny * nz;
+  const unsigned ny = sd.y, nz = sd.z, nynz = ny * nz;
+  const float bx = (float)(sd.x - 1), by = (float)(sd.y - 1), bz = (float)(sd.z - 1);
+  float g[kPullChunks][3];
+  bool inside = sd.z >= 2;
+#pragma unroll
+  for (int u = 0; u < kPullChunks; ++u) {
+    const int k = min(kbase + u * kWave + lane, gd.z - 1);
+    affine_along(A, rb, (float)k, g[u][0], g[u][1], g[u][2]);
+    inside = inside && g[u][0] >= 0.f && g[u][0] < bx && g[u][1] >= 0.f && g[u][1] < by &&
+             g[u][2] >= 0.f && g[u][2] < bz;
+  }
+  if (__all(inside)) {  // every corner of every sample of this wave is inside the volume
 #pragma unroll
     for (int u = 0; u < kPullChunks; ++u) {
       const int k = kbase + u * kWave + lane;
-      if (k < gd.z) {
-        float gx, gy, gz;
-        affine_along(A, rb, (float)k, gx, gy, gz);
-        row[k] = pull_interior(src, ny, nz, nynz, gx, gy, gz);
-      }
+      const float v = pull_interior(src, ny, nz, nynz, g[u][0], g[u][1], g[u][2]);
+      if (k < gd.z) row[k] = v;
     }
     return;
   }
   PullLoads L[kPullChunks];
 #pragma unroll
-  for (int u = 0; u < kPullChunks; ++u) {
-    const int k = min(kbase + u * kWave + lane, gd.z - 1);
-    float gx, gy, gz;
-    affine_along(A, rb, (float)k, gx, gy, gz);
-    pull_issue(src, sd, gx, gy, gz, tol, L[u]);
-  }
+  for (int u = 0; u < kPullChunks; ++u) pull_issue(src, sd, g[u][0], g[u][1], g[u][2], tol, L[u]);
 #pragma unroll
   for (int u = 0; u < kPullChunks; ++u) {
     const int k = kbase + u * kWave + lane;
