@@ -19,6 +19,9 @@ CASES = {
     'sr_2rep': dict(dim_y=(14, 12, 15), n_channels=2, thick=2, regime='sr', n_repeats=2, scl=0.05),
     'sr_gauss_tri': dict(dim_y=(12, 12, 12), n_channels=1, thick=2, regime='sr', prof_tp=1, prof_ip=2),
     'sr_aniso': dict(dim_y=(14, 10, 12), n_channels=1, thick=3, regime='sr', aniso=(0.8, 1.0, 1.3)),
+    'sr_iso2_gauss': dict(dim_y=(16, 14, 12), n_channels=2, thick=2, regime='sr', iso=True, prof_ip=2,
+                          prof_tp=0, vx_y=0.5),
+    'sr_iso3_rect': dict(dim_y=(15, 15, 12), n_channels=1, thick=3, regime='sr', iso=True, rot=0.02),
     'dn_2ch': dict(dim_y=(15, 13, 11), n_channels=2, regime='dn', rot=0.1, trans=1.5),
     'dn_2rep': dict(dim_y=(12, 12, 10), n_channels=1, regime='dn', n_repeats=2),
     'id_1ch': dict(dim_y=(18, 17, 13), n_channels=1, regime='id'),
