@@ -70,6 +70,14 @@ class ChannelPlan:
         self.dims_x = [self.dim_y if self.regime == REGIME_IDENTITY else tuple(po.dim_x)
                        for po, _ in repeats]
 
+    def rhs_buffer(self, like):
+        """A per-plan (X,Y,Z) buffer for the RHS when channels run on separate streams."""
+        buf = getattr(self, '_rhs_buf', None)
+        if buf is None or buf.shape != like.shape or buf.device != like.device:
+            buf = torch.empty_like(like)
+            self._rhs_buf = buf
+        return buf
+
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
             self.lib.unires_plan_destroy(self._h)

@@ -34,20 +34,57 @@ def _step_size(x, y, sett, verbose=False):
 
 def _update_y(x, y, z, w, rho, tmp, sett, info=None):
     """UPDATE: y  (unires/_update.py:118-152).  Per channel: assemble
-    b = sum_n tau_n At x_n - lam Dt(w - rho z) into ``tmp`` and solve
-    (sum tau AtA + rho lam^2 DtD) y = b by CG, in place on y[c].dat."""
+    b = sum_n tau_n At x_n - lam Dt(w - rho z) and solve
+    (sum tau AtA + rho lam^2 DtD) y = b by CG, in place on y[c].dat.
+
+    The channels do not couple inside the y-update (no cross-channel term in
+    :122-150), so each channel's RHS + CG is enqueued on its own HIP stream: the
+    issue-bound push kernel of one channel overlaps the HBM-bound vector kernels of
+    another.  Results are identical to the sequential loop; ``tmp`` (the reference's
+    shared RHS buffer) holds channel 0's b, the other channels use per-plan buffers.
+    """
     vx_y = voxel_size(y[0].mat).float()
     rho = float(rho)
     sync = info is not None
-    for c in range(len(x)):
+    C = len(x)
+    concurrent = C > 1 and not sync and getattr(sett, 'channel_streams', True)
+    if not concurrent:
+        for c in range(C):
+            plan = _channel_plan(x[c], y[c], sett.method, sett.do_proj, vx_y)
+            lam = float(y[c].lam)
+            plan.rhs([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=tmp)
+            res = plan.cg(tmp, y[c].dat, rho, lam, max_iter=sett.cgs_max_iter,
+                          tolerance=sett.cgs_tol, stop=sett.cgs_stop, sync=sync)
+            if sync:
+                info.append(res)
+        return y
+    main = torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record(main)
+    streams = _side_streams(y[0].dat.device, C)
+    for c in range(C):
         plan = _channel_plan(x[c], y[c], sett.method, sett.do_proj, vx_y)
         lam = float(y[c].lam)
-        plan.rhs([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=tmp)
-        res = plan.cg(tmp, y[c].dat, rho, lam, max_iter=sett.cgs_max_iter,
-                      tolerance=sett.cgs_tol, stop=sett.cgs_stop, sync=sync)
-        if sync:
-            info.append(res)
+        b = tmp if c == 0 else plan.rhs_buffer(tmp)
+        with torch.cuda.stream(streams[c]):
+            streams[c].wait_event(ready)
+            plan.rhs([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=b)
+            plan.cg(b, y[c].dat, rho, lam, max_iter=sett.cgs_max_iter, tolerance=sett.cgs_tol,
+                    stop=sett.cgs_stop, sync=False)
+    for c in range(C):
+        main.wait_stream(streams[c])
     return y
+
+
+_STREAMS = {}
+
+
+def _side_streams(device, n):
+    key = (device.type, device.index)
+    pool = _STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
 
 
 def _chan_args(y):

@@ -79,3 +79,5 @@ class settings:
         # build-side knob: which nitorch-cg objective branch to reproduce
         # ('max_gain' = what the reference passes, unires/_update.py:145)
         self.cgs_stop = 'max_gain'
+        # build-side knob: enqueue the (independent) channels of the y-update on separate HIP streams
+        self.channel_streams = True
