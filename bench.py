@@ -100,6 +100,7 @@ def build_subject(wl, device, seed):
     sett = U.settings()
     sett.device, sett.method, sett.do_proj = device, 'super-resolution', True
     sett.cgs_max_iter, sett.cgs_tol = 20, 0.0  # fixed-iteration mode
+    sett.cache_atx = False  # every step re-assembles the full RHS (no work skipped in the timed region)
     rho = float(U._step_size(x, y, sett))
     z, w = U._admm_aux(y, sett)
     return x, y, z, w, rho, sett

@@ -160,6 +160,16 @@ int unires_ata_matvec(unires_plan_t *plan, float rho, float lam, const float *p,
 int unires_rhs_assemble(unires_plan_t *plan, const float *const *x_ptrs, const float *w_c,
                         const float *z_c, float rho, float lam, float *b, void *stream);
 
+/* The data term of the RHS alone, atx = sum_n tau_n At_n x_n  (_update.py:125-128).  It only
+ * changes when an observation, its rigid or its scaling changes, so a caller may keep it
+ * across ADMM iterations (the reference recomputes it every time). */
+int unires_atx_assemble(unires_plan_t *plan, const float *const *x_ptrs, float *atx,
+                        void *stream);
+
+/* b = atx - lam * Dt(w_c - rho z_c)   (_update.py:131-133) from a kept atx. */
+int unires_rhs_from_atx(unires_plan_t *plan, const float *atx, const float *w_c,
+                        const float *z_c, float rho, float lam, float *b, void *stream);
+
 /* nitorch cg(A=lhs, b, x, precond=identity, max_iter, tolerance, stop,
  * inplace=True, sum_dtype=float64)  (_update.py:142-148): x is updated in place.
  * tol == 0 runs exactly max_iter iterations with no objective evaluation.

@@ -278,3 +278,29 @@ def compute_nll(x, y, method, do_proj, sum_dtype=torch.float64):
         nll_y = torch.sum(Dy ** 2, dim=0) if nll_y is None else nll_y + torch.sum(Dy ** 2, dim=0)
     nll_y = torch.sum(torch.sqrt(nll_y), dtype=sum_dtype)
     return nll_xy + nll_y, nll_xy, nll_y
+
+
+# --------------------------------------------------------------------------
+# unires/_core.py:371-399  (initial guess: trilinear reslice)
+# --------------------------------------------------------------------------
+def init_y_dat(x, y):
+    """y[c].dat = average over repeats of the inputs pulled into the mean space,
+    clamped to each input's range; zeros where no input covers the voxel."""
+    dim_y = y[0].dim
+    mat_y = y[0].mat
+    for c in range(len(x)):
+        dat_y = torch.zeros(dim_y, dtype=torch.float32)
+        sm = torch.zeros_like(dat_y)
+        for n in range(len(x[c])):
+            dat = x[c][n].dat[None, None]
+            mat = torch.linalg.solve(x[c][n].mat, mat_y)            # :385  mat_x \ mat_y
+            grid = affine_grid(mat.type(dat.dtype), dim_y)          # :386
+            mn, mx = torch.min(dat), torch.max(dat)
+            dat = grid_pull(dat, grid[None], bound='zero', extrapolate=False, interpolation=1)
+            dat[dat < mn] = mn
+            dat[dat > mx] = mx
+            sm = sm + (dat[0, 0] > 0)
+            dat_y = dat_y + dat[0, 0]
+        sm[sm == 0] = 1.0
+        y[c].dat = dat_y / sm
+    return y

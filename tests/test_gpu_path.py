@@ -86,6 +86,18 @@ def test_matvec_and_rhs(dev, case):
         b = plan.rhs([xn.dat for xn in xg[c]], prob['w'][c].to(dev), prob['z'][c].to(dev),
                      float(rho), float(yg[c].lam)).cpu()
         assert rel_err(b, ref_b) < 2e-5
+        # kept data term: same b, recomputed when an observation changes in place
+        out = torch.empty(prob['dim_y'], device=dev)
+        for _ in range(2):
+            plan.rhs_cached([xn.dat for xn in xg[c]], prob['w'][c].to(dev), prob['z'][c].to(dev),
+                            float(rho), float(yg[c].lam), out)
+            assert rel_err(out.cpu(), ref_b) < 2e-5
+        xg[c][0].dat.mul_(1.5)
+        xo[c][0].dat = xo[c][0].dat * 1.5
+        ref_b2 = O.y_rhs(xo[c], yo[c], prob['z'][c], prob['w'][c], rho, vx, prob['method'], prob['do_proj'])
+        plan.rhs_cached([xn.dat for xn in xg[c]], prob['w'][c].to(dev), prob['z'][c].to(dev),
+                        float(rho), float(yg[c].lam), out)
+        assert rel_err(out.cpu(), ref_b2) < 2e-5
 
 
 @pytest.mark.parametrize('case', list(CASES))
@@ -228,6 +240,24 @@ def test_full_admm_iterations_track_the_oracle(dev):
             assert rel_err(yg[c].dat.cpu(), yo[c].dat) < GATE, (it, c)
         assert abs(obj[it, 0].item() - ref_obj[0].item()) < 1e-4 * abs(ref_obj[0].item())
     assert rel_err(zg.cpu(), zo) < 5e-4 and rel_err(wg.cpu(), wo) < 5e-4
+
+
+@pytest.mark.parametrize('case', ['sr_3ch_axes', 'sr_2rep', 'dn_2ch'])
+def test_init_y_dat_matches_oracle(dev, case):
+    """the initial trilinear reslice of the inputs into the mean space."""
+    import unires_amd as U
+    prob = make_problem(seed=19, **CASES[case])
+    xo, yo = oracle_structs(prob)
+    xg, yg, sett = gpu_structs(prob, dev)
+    # the observations carry their own affine: mat_x composed with the rigid, as after coreg
+    for c, ch in enumerate(prob['chans']):
+        for n, r in enumerate(ch['reps']):
+            m = (r['rigid'] @ r['mat_x'])
+            xo[c][n].mat, xg[c][n].mat = m, m
+    yo = O.init_y_dat(xo, yo)
+    yg = U._init_y_dat(xg, yg, sett)
+    for c in range(len(yo)):
+        assert rel_err(yg[c].dat.cpu(), yo[c].dat) < 2e-5
 
 
 def test_gather_push_variant_matches_oracle(dev):

@@ -54,6 +54,9 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p]),
     'unires_rhs_assemble': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'unires_atx_assemble': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    'unires_rhs_from_atx': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                      C.c_float, C.c_void_p, C.c_void_p]),
     'unires_cg_solve': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.c_double, C.c_int32, C.c_int32,
                                   C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p]),

@@ -144,6 +144,25 @@ class ChannelPlan:
                                            float(lam), _ptr(out), _stream()))
         return out
 
+    def rhs_cached(self, x_dats, w_c, z_c, rho, lam, out):
+        """Same b as :meth:`rhs`, but sum_n tau_n At x_n is kept on the plan and only
+        recomputed when an observation tensor changed (the plan itself is rebuilt when a
+        rigid / scaling / tau changes).  The reference recomputes it every ADMM iteration
+        (unires/_update.py:125-128)."""
+        xs = [_vol(t, 'x')[0] for t in x_dats]
+        key = tuple((t.data_ptr(), t._version) for t in xs)
+        cache = getattr(self, '_atx', None)
+        if cache is None or cache[0] != key:
+            atx = cache[1] if cache is not None else torch.empty(self.dim_y, dtype=torch.float32,
+                                                                 device=xs[0].device)
+            ptrs = (C.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
+            check(self.lib.unires_atx_assemble(self._h, ptrs, _ptr(atx), _stream()))
+            self._atx = cache = (key, atx)
+        w_c, z_c = w_c.contiguous(), z_c.contiguous()
+        check(self.lib.unires_rhs_from_atx(self._h, _ptr(cache[1]), _ptr(w_c), _ptr(z_c),
+                                           float(rho), float(lam), _ptr(out), _stream()))
+        return out
+
     def cg(self, b, x, rho, lam, max_iter=20, tolerance=1e-3, stop='max_gain', sync=True):
         """In-place CG on x (must be contiguous (X,Y,Z)).  Returns (iters, obj) when
         ``sync`` (one stream sync), else None with everything left enqueued."""

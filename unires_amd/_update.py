@@ -68,7 +68,10 @@ def _update_y(x, y, z, w, rho, tmp, sett, info=None):
         b = tmp if c == 0 else plan.rhs_buffer(tmp)
         with torch.cuda.stream(streams[c]):
             streams[c].wait_event(ready)
-            plan.rhs([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=b)
+            if getattr(sett, 'cache_atx', True):
+                plan.rhs_cached([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=b)
+            else:
+                plan.rhs([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=b)
             plan.cg(b, y[c].dat, rho, lam, max_iter=sett.cgs_max_iter, tolerance=sett.cgs_tol,
                     stop=sett.cgs_stop, sync=False)
     for c in range(C):

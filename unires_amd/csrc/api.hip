@@ -216,7 +216,7 @@ extern "C" int unires_div_fwd_zero(const float *src3, const int32_t dim[3], cons
   if (!src3 || !dst || !dim) return fail(UNIRES_ERR_NULL, "null argument");
   if (!dims_ok(dim)) return fail(UNIRES_ERR_DIM, "bad dimensions");
   if (!vx_ok(vx)) return fail(UNIRES_ERR_ARG, "voxel size must be positive");
-  launch_div(src3, nullptr, 1.f, 0.f, mk(dim), vx, 1.f, dst, (hipStream_t)stream);
+  launch_div(src3, nullptr, 1.f, 0.f, mk(dim), vx, 1.f, nullptr, dst, (hipStream_t)stream);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -552,10 +552,34 @@ extern "C" int unires_rhs_assemble(unires_plan_t *plan, const float *const *x_pt
     if (!x_ptrs[n]) return fail(UNIRES_ERR_NULL, "null observation pointer");
   hipStream_t st = (hipStream_t)stream;
   // b = -lam * Dt(w - rho z)   (unires/_update.py:131-133)
-  launch_div(w_c, z_c, 1.f, -rho, plan->dy, plan->vx, -lam, b, st);
+  launch_div(w_c, z_c, 1.f, -rho, plan->dy, plan->vx, -lam, nullptr, b, st);
   // b += tau_n At_n x_n         (unires/_update.py:125-128)
   for (size_t n = 0; n < plan->reps.size(); ++n)
     at_accumulate(plan, plan->reps[n], x_ptrs[n], b, plan->reps[n].tau, true, st);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+extern "C" int unires_atx_assemble(unires_plan_t *plan, const float *const *x_ptrs, float *atx,
+                                   void *stream) {
+  if (!plan || !x_ptrs || !atx) return fail(UNIRES_ERR_NULL, "null argument");
+  for (size_t n = 0; n < plan->reps.size(); ++n)
+    if (!x_ptrs[n]) return fail(UNIRES_ERR_NULL, "null observation pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (plan->regime == UNIRES_REGIME_IDENTITY)
+    HIP_TRY(hipMemsetAsync(atx, 0, plan->dy.numel() * sizeof(float), st));
+  for (size_t n = 0; n < plan->reps.size(); ++n)
+    at_accumulate(plan, plan->reps[n], x_ptrs[n], atx, plan->reps[n].tau,
+                  n > 0 || plan->regime == UNIRES_REGIME_IDENTITY, st);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+extern "C" int unires_rhs_from_atx(unires_plan_t *plan, const float *atx, const float *w_c,
+                                   const float *z_c, float rho, float lam, float *b,
+                                   void *stream) {
+  if (!plan || !atx || !w_c || !z_c || !b) return fail(UNIRES_ERR_NULL, "null argument");
+  launch_div(w_c, z_c, 1.f, -rho, plan->dy, plan->vx, -lam, atx, b, (hipStream_t)stream);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }

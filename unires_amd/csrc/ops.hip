@@ -169,10 +169,11 @@ __global__ void __launch_bounds__(kBlock)
   dst[2 * n + idx] = (zn - c) * ivz;
 }
 
-// dst = beta*dst_in + scale * Dt(u), u = a*src_a (+ b*src_b if src_b != NULL)
+// dst = [add +] scale * Dt(u), u = a*src_a (+ b*src_b if src_b != NULL)
 __global__ void __launch_bounds__(kBlock)
     k_div(const float *__restrict__ ua, const float *__restrict__ ub, float ca, float cb, Dim3i d,
-          float ivx, float ivy, float ivz, float scale, float *__restrict__ dst) {
+          float ivx, float ivy, float ivz, float scale, const float *__restrict__ add,
+          float *__restrict__ dst) {
   const int k = blockIdx.x * kWave + threadIdx.x;
   const int j = blockIdx.y * 4 + threadIdx.y;
   const int i = blockIdx.z;
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(kBlock)
   acc += ((i > 0 ? U(idx - sx) : 0.f) - U(idx)) * ivx;
   acc += ((j > 0 ? U(n + idx - sy) : 0.f) - U(n + idx)) * ivy;
   acc += ((k > 0 ? U(2 * n + idx - 1) : 0.f) - U(2 * n + idx)) * ivz;
-  dst[idx] = scale * acc;
+  dst[idx] = (add ? add[idx] : 0.f) + scale * acc;
 }
 
 // dst = a*src + c*DtD(src): 7-point stencil with Neumann row at 0 and Dirichlet
@@ -267,9 +268,9 @@ void launch_grad(const float *src, Dim3i d, const float vx[3], float *dst3, hipS
 }
 
 void launch_div(const float *ua, const float *ub, float ca, float cb, Dim3i d, const float vx[3],
-                float scale, float *dst, hipStream_t st) {
+                float scale, const float *add, float *dst, hipStream_t st) {
   hipLaunchKernelGGL(k_div, vol_grid(d), vol_block(), 0, st, ua, ub, ca, cb, d, 1.f / vx[0],
-                     1.f / vx[1], 1.f / vx[2], scale, dst);
+                     1.f / vx[1], 1.f / vx[2], scale, add, dst);
 }
 
 int dtd_num_blocks(Dim3i d) {

@@ -16,9 +16,9 @@ void launch_conv_down(const float *src, Dim3i gd, const Taps &T, const Scaling &
 void launch_conv_up(const float *xs, Dim3i xd, const Taps &T, const Scaling &S, float *dst,
                     Dim3i gd, hipStream_t st);
 void launch_grad(const float *src, Dim3i d, const float vx[3], float *dst3, hipStream_t st);
-// dst = scale * Dt(ca*ua + cb*ub)   (ub may be NULL)
+// dst = [add +] scale * Dt(ca*ua + cb*ub)   (ub, add may be NULL)
 void launch_div(const float *ua, const float *ub, float ca, float cb, Dim3i d, const float vx[3],
-                float scale, float *dst, hipStream_t st);
+                float scale, const float *add, float *dst, hipStream_t st);
 int dtd_num_blocks(Dim3i d);
 // dst = a*src + c*DtD(src); partials (nullable, dtd_num_blocks doubles) gets sum(src*dst) pieces
 void launch_dtd(const float *src, Dim3i d, const float vx[3], float a, float c, float *dst,

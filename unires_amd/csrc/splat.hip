@@ -332,7 +332,9 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
 int splat_blocks(Dim3i dd) {
   const long long nt = (long long)((dd.x + kSTX - 1) / kSTX) * ((dd.y + kSTY - 1) / kSTY) *
                        ((dd.z + kSTZ - 1) / kSTZ);
-  return (int)(nt < kMaxPartials ? nt : kMaxPartials);  // persistent: ~14 resident waves per CU
+  static const int cap = getenv("UNIRES_SPLAT_BLOCKS") ? atoi(getenv("UNIRES_SPLAT_BLOCKS")) : kMaxPartials;
+  const int lim = cap < kMaxPartials ? cap : kMaxPartials;
+  return (int)(nt < lim ? nt : lim);  // persistent grid
 }
 
 // Returns non-zero (nothing launched) when the operator is outside this kernel's domain;

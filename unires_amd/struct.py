@@ -81,3 +81,5 @@ class settings:
         self.cgs_stop = 'max_gain'
         # build-side knob: enqueue the (independent) channels of the y-update on separate HIP streams
         self.channel_streams = True
+        # build-side knob: keep sum_n tau_n At x_n across ADMM iterations (recomputed on change)
+        self.cache_atx = True
