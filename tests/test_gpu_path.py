@@ -260,9 +260,10 @@ def test_init_y_dat_matches_oracle(dev, case):
         assert rel_err(yg[c].dat.cpu(), yo[c].dat) < 2e-5
 
 
-def test_gather_push_variant_matches_oracle(dev):
-    """The alternative gather-form push (UNIRES_PUSH=gather, chosen at library load)
-    runs the same parity gate in a fresh process."""
+@pytest.mark.parametrize('variant', ['gather', 'gather2', 'tile'])
+def test_push_kernel_variants_match_oracle(dev, variant):
+    """The alternative push kernels (UNIRES_PUSH=gather|gather2|tile, chosen at library
+    load; default is the LDS splat) run the same parity gate in a fresh process."""
     import os
     import subprocess
     import sys
@@ -277,8 +278,8 @@ def test_gather_push_variant_matches_oracle(dev):
             "    for c in range(len(yr)):\n"
             "        assert ig[c][0] == ir[c][0]\n"
             "        assert rel_err(yg[c].cpu(), yr[c]) < 1e-4, case\n"
-            "print('gather OK')\n") % root
-    env = dict(os.environ, UNIRES_PUSH='gather')
+            "print('variant OK')\n") % root
+    env = dict(os.environ, UNIRES_PUSH=variant)
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
                          timeout=600)
-    assert out.returncode == 0 and 'gather OK' in out.stdout, out.stderr[-2000:]
+    assert out.returncode == 0 and 'variant OK' in out.stdout, out.stderr[-2000:]

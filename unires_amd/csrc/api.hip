@@ -247,6 +247,8 @@ struct Repeat {
   Affine Af, Afinv;
   Taps Tf;
   SplatSafety safe;  // of Af (the linear part is the same for A)
+  // device tables for the on-the-fly conv_up of k_gather2: [0] no scaling (AtA), [1] S(scl) (At)
+  float *ztab_dev[2] = {nullptr, nullptr};
 };
 
 struct unires_plan {
@@ -299,6 +301,30 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
   if (!invert_affine(out.Af, out.Afinv)) return fail(UNIRES_ERR_ARG, "singular affine");
   splat_safety(out.Af, out.safe.row_sep, out.safe.use_atomics);
   return UNIRES_OK;
+}
+
+// (re)build the device z tables of a super-resolution repeat
+static int upload_ztabs(unires_plan *pl, Repeat &R) {
+  if (pl->regime != UNIRES_REGIME_SUPERRES) return UNIRES_OK;
+  const int gz = R.dim_gf.z;
+  std::vector<float> host((size_t)gz * 4);
+  for (int v = 0; v < 2; ++v) {
+    if (!R.ztab_dev[v]) {
+      hipError_t e = hipMalloc((void **)&R.ztab_dev[v], host.size() * sizeof(float));
+      if (e != hipSuccess) return fail(UNIRES_ERR_ALLOC, "hipMalloc z table");
+    }
+    gather2_ztab(R.Tf, v ? make_scaling(R.scl, R.dim_thick) : Scaling{1.f, 1.f, -1}, gz,
+                 R.dim_x.z, host.data());
+    hipError_t e = hipMemcpy(R.ztab_dev[v], host.data(), host.size() * sizeof(float),
+                             hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(UNIRES_ERR_HIP, "hipMemcpy z table");
+  }
+  return UNIRES_OK;
+}
+
+static void free_ztabs(Repeat &R) {
+  for (int v = 0; v < 2; ++v)
+    if (R.ztab_dev[v]) (void)hipFree(R.ztab_dev[v]), R.ztab_dev[v] = nullptr;
 }
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -364,6 +390,15 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
     delete pl;
     return UNIRES_ERR_HIP;
   }
+  for (Repeat &R : pl->reps) {
+    int rc = upload_ztabs(pl, R);
+    if (rc) {
+      for (Repeat &Q : pl->reps) free_ztabs(Q);
+      (void)hipFree(pl->ws);
+      delete pl;
+      return rc;
+    }
+  }
   *plan = pl;
   return UNIRES_OK;
 }
@@ -371,6 +406,7 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
 extern "C" int unires_plan_destroy(unires_plan_t *plan) {
   if (!plan) return UNIRES_OK;
   if (plan->ws) (void)hipFree(plan->ws);
+  for (Repeat &R : plan->reps) free_ztabs(R);
   delete plan;
   return UNIRES_OK;
 }
@@ -385,8 +421,11 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   if (plan->regime != UNIRES_REGIME_IDENTITY &&
       (tmp.dim_g.numel() > plan->cap_g || tmp.dim_x.numel() > plan->cap_x))
     return fail(UNIRES_ERR_DIM, "new repeat exceeds the plan's workspace");
+  if (tmp.dim_gf.z != plan->reps[n].dim_gf.z) free_ztabs(plan->reps[n]);
+  tmp.ztab_dev[0] = plan->reps[n].ztab_dev[0];
+  tmp.ztab_dev[1] = plan->reps[n].ztab_dev[1];
   plan->reps[n] = tmp;
-  return UNIRES_OK;
+  return upload_ztabs(plan, plan->reps[n]);
 }
 
 extern "C" int64_t unires_plan_workspace_bytes(const unires_plan_t *plan) {
@@ -443,7 +482,15 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
     if (!launch_push_gather(g, src.gd, A, R.Afinv, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
       return ep.partials ? push_gather_blocks(pl->dy) : 0;
   }
-  static const bool use_tile = getenv("UNIRES_PUSH") && !strcmp(getenv("UNIRES_PUSH"), "tile");
+  static const char *mode = getenv("UNIRES_PUSH");
+  static const bool use_tile = mode && !strcmp(mode, "tile");
+  static const bool use_gather2 = mode && !strcmp(mode, "gather2");
+  // measured on config 3: k_splat 219 us, k_gather2 336 us, k_push_tile 470 us, k_push_gather 1030 us
+  if (use_gather2) {
+    const float4 *zt = src.convup ? (const float4 *)R.ztab_dev[src.S.dim >= 0 ? 1 : 0] : nullptr;
+    if (!launch_gather2(src, zt, A, R.Afinv, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
+      return ep.partials ? gather2_blocks(pl->dy) : 0;
+  }
   if (!use_tile &&
       !launch_splat(src, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
     return ep.partials ? splat_blocks(pl->dy) : 0;

@@ -14,7 +14,8 @@ namespace unires {
 static inline int vec_blocks(size_t n) {
   size_t b = (n / 4 + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
-  return (int)(b < (size_t)kMaxPartials ? b : (size_t)kMaxPartials);
+  const size_t cap = 4096;  // enough workgroups to saturate HBM
+  return (int)(b < cap ? b : cap);
 }
 
 #define GRID_STRIDE_VEC4(n)                                                   \

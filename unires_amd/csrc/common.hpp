@@ -9,7 +9,7 @@ namespace unires {
 
 constexpr int kWave = 64;           // CDNA wavefront
 constexpr int kBlock = 256;         // 4 waves, one per SIMD
-constexpr int kMaxPartials = 4096;  // blocks of a dot-producing kernel (<= this)
+constexpr int kMaxPartials = 8192;  // blocks of a dot-producing kernel (<= this)
 
 struct Dim3i {
   int x, y, z;

@@ -688,7 +688,9 @@ struct GatherArgs {
   double *partials;
 };
 
-__device__ __forceinline__ float hat(float d) { return __saturatef(1.f - fabsf(d)); }
+__device__ __forceinline__ float hat(float d) {
+  return __builtin_amdgcn_fmed3f(1.f - fabsf(d), 0.f, 1.f);  // one v_sub_f32 |d| clamp
+}
 
 __global__ void __launch_bounds__(kBlock)
     k_push_gather(GatherArgs G, const int *__restrict__ done) {

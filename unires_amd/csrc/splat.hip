@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
 int splat_blocks(Dim3i dd) {
   const long long nt = (long long)((dd.x + kSTX - 1) / kSTX) * ((dd.y + kSTY - 1) / kSTY) *
                        ((dd.z + kSTZ - 1) / kSTZ);
-  static const int cap = getenv("UNIRES_SPLAT_BLOCKS") ? atoi(getenv("UNIRES_SPLAT_BLOCKS")) : kMaxPartials;
+  static const int cap = getenv("UNIRES_SPLAT_BLOCKS") ? atoi(getenv("UNIRES_SPLAT_BLOCKS")) : 4096;
   const int lim = cap < kMaxPartials ? cap : kMaxPartials;
   return (int)(nt < lim ? nt : lim);  // persistent grid
 }
