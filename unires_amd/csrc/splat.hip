@@ -2,9 +2,9 @@
 // (same algorithm and race-freedom argument as k_push_tile in fused.hip, which stays
 // as the general fallback) for the two sources the headline configurations use:
 //
-//   CONVZ = false : grid-space source (denoising regime, op-level push)
-//   CONVZ = true  : thick slices along z: conv_up along z only, fan-in <= 2
-//                   (every rect profile), regenerated on the fly from x-space
+//   AXIS = -1    : grid-space source (denoising regime, op-level push)
+//   AXIS = 0,1,2 : thick slices along that axis: conv_up along ONE axis, fan-in <= 2
+//                  (every rect profile), regenerated on the fly from x-space
 //
 // Differences that matter for instruction count (this kernel is issue-bound, not
 // HBM-bound - DESIGN.md 4): one z table instead of three, the two x-space values of a
@@ -22,10 +22,10 @@ namespace unires {
 struct SplatArgs {
   const float *src;
   int gx, gy, gz;     // grid dims
-  int xdy, xdz;       // x-space dims (CONVZ)
-  int nkz, sz;        // z taps / stride (CONVZ)
+  int xdy, xdz, xdn;  // x-space dims y, z and along the thick axis (AXIS >= 0)
+  int nkz, sz;        // taps / stride along the thick axis
   float kz[UNIRES_MAX_TAPS];
-  float se, so;       // even/odd slice scaling along z (1,1 = none)
+  float se, so;       // even/odd slice scaling along the thick axis (1,1 = none)
   Affine A, Ainv;
   float alpha, tol;
   const float *p;
@@ -70,9 +70,10 @@ __device__ __forceinline__ float dpp_up1f(float v) {
 #define SPLAT_FENCE() asm volatile("" ::: "memory")
 #endif
 
-template <bool CONVZ>
+template <int AXIS>
 __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restrict__ done) {
   if (done && *done) return;
+  constexpr bool CONV = AXIS >= 0;
   constexpr int TX = kSTX, TY = kSTY, TZ = kSTZ;
   constexpr int SZ = TZ + 2, SY = TY + 2, SXd = TX + 2, N = SXd * SY * SZ;
   constexpr int XS = SY * SZ, YS = SZ;  // strides of the aproned accumulator (x, y; z = 1)
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
   const int slots = (gridDim.x + nxcd - 1 - xcd) / nxcd;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const float c0 = P.A.m[2], c1 = P.A.m[6], c2 = P.A.m[10];
-  const float inv_sz = CONVZ ? 1.f / (float)P.sz : 1.f;
+  const float inv_sz = CONV ? 1.f / (float)P.sz : 1.f;
   double dot = 0.0;
   for (int tl = slot; tl < per_xcd; tl += slots) {
     const int t = xcd * per_xcd + tl;
@@ -124,13 +125,16 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
     const int bz0 = max(0, (int)floorf(lo2 - 0.01f)), bz1 = min(P.gz - 1, (int)ceilf(hi2 + 0.01f));
     const int nby = by1 - by0 + 1;
     const int nrow_cand = max(bx1 - bx0 + 1, 0) * max(nby, 0);
-    if (CONVZ) {
-      // which x-space slices feed grid slice uz = bz0 + lane, packed for ONE 8-byte load
-      const int uz = min(bz0 + lane, P.gz - 1);
+    if (CONV) {
+      // which x-space slices feed grid slice u = (box start along AXIS) + lane; for AXIS 2 the
+      // pair is packed for ONE 8-byte load, else the second slice is one x/y stride away
+      const int b0 = AXIS == 0 ? bx0 : (AXIS == 1 ? by0 : bz0);
+      const int gn = AXIS == 0 ? P.gx : (AXIS == 1 ? P.gy : P.gz);
+      const int uz = min(b0 + lane, gn - 1);
       int khi = (int)(((float)uz + 0.5f) * inv_sz);
       if (khi * P.sz > uz) --khi;
       if ((khi + 1) * P.sz <= uz) ++khi;                  // khi = uz / sz exactly
-      khi = min(khi, P.xdz - 1);
+      khi = min(khi, P.xdn - 1);
       const int tt = uz - P.nkz + 1;
       int klo = 0;
       if (tt > 0) {
@@ -144,8 +148,8 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
       if (n >= 2) w1 = P.kz[uz - P.sz * (klo + 1)] * (((klo + 1) & 1) ? P.so : P.se);
       int koff = klo;
       if (n < 1) koff = 0;
-      if (koff > P.xdz - 2) {  // last slice: fetch the pair (xdz-2, xdz-1), weight on .y
-        koff = P.xdz - 2;
+      if (koff > P.xdn - 2) {  // last slice: fetch the pair (xdn-2, xdn-1), weight on the second
+        koff = P.xdn - 2;
         w1 = w0, w0 = 0.f;
       }
       ztab[lane] = make_float4(__int_as_float(koff), w0, w1, 0.f);
@@ -215,13 +219,25 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
           act[u] = p < npair && idx < nr && hl < R.len;
           solo[u] = R.solo && half;
           ui[u] = R.ui, uj[u] = R.uj, uk[u] = min(R.k0 + hl, P.gz - 1);
-          if (CONVZ) {
+          if (AXIS == 2) {
             const float4 tb = ztab[min(uk[u] - bz0, 63)];
             const unsigned base =
                 __umul24(__umul24((unsigned)ui[u], (unsigned)P.xdy) + (unsigned)uj[u],
                          (unsigned)P.xdz) + (unsigned)__float_as_int(tb.x);
             const float2 pr = ld2_u(src + base);
             val[u] = tb.y * pr.x + tb.z * pr.y;
+          } else if (AXIS == 0) {
+            const float4 tb = ztab[min(max(ui[u] - bx0, 0), 63)];
+            const unsigned base =
+                __umul24(__umul24((unsigned)__float_as_int(tb.x), (unsigned)P.xdy) + (unsigned)uj[u],
+                         (unsigned)P.xdz) + (unsigned)uk[u];
+            val[u] = tb.y * src[base] + tb.z * src[base + (unsigned)P.xdy * (unsigned)P.xdz];
+          } else if (AXIS == 1) {
+            const float4 tb = ztab[min(max(uj[u] - by0, 0), 63)];
+            const unsigned base =
+                __umul24(__umul24((unsigned)ui[u], (unsigned)P.xdy) + (unsigned)__float_as_int(tb.x),
+                         (unsigned)P.xdz) + (unsigned)uk[u];
+            val[u] = tb.y * src[base] + tb.z * src[base + (unsigned)P.xdz];
           } else {
             const unsigned base =
                 __umul24(__umul24((unsigned)ui[u], (unsigned)P.gy) + (unsigned)uj[u],
@@ -350,16 +366,25 @@ int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const 
   if (P.gx > 32000 || P.gy > 32000 || P.gz > 32000) return 1;
   P.xdy = src.xd.y, P.xdz = src.xd.z;
   P.nkz = 1, P.sz = 1, P.se = 1.f, P.so = 1.f;
+  int axis = -1;
   if (src.convup) {
-    // conv_up must act along z only, with at most two x-space slices per grid slice
-    if (src.T.n[0] != 1 || src.T.n[1] != 1 || src.T.s[0] != 1 || src.T.s[1] != 1) return 1;
-    if (src.T.t[0][0] != 1.f || src.T.t[1][0] != 1.f) return 1;
-    if ((src.T.n[2] + src.T.s[2] - 1) / src.T.s[2] > 2 || src.xd.z < 2) return 1;
-    if (src.S.dim >= 0 && src.S.dim != 2) return 1;
-    P.nkz = src.T.n[2], P.sz = src.T.s[2];
-    for (int i = 0; i < UNIRES_MAX_TAPS; ++i) P.kz[i] = src.T.t[2][i];
-    if (src.S.dim == 2) P.se = src.S.e, P.so = src.S.o;
+    // conv_up must act along ONE axis, with at most two x-space slices per grid slice
+    for (int d = 0; d < 3; ++d) {
+      const bool dirac = src.T.n[d] == 1 && src.T.s[d] == 1 && src.T.t[d][0] == 1.f;
+      if (dirac) continue;
+      if (axis >= 0) return 1;
+      axis = d;
+    }
+    if (axis < 0) axis = 2;  // all dirac: conv_up is the identity, any axis works
+    const int xdv[3] = {src.xd.x, src.xd.y, src.xd.z};
+    if ((src.T.n[axis] + src.T.s[axis] - 1) / src.T.s[axis] > 2 || xdv[axis] < 2) return 1;
+    if (src.S.dim >= 0 && src.S.dim != axis) return 1;
+    P.nkz = src.T.n[axis], P.sz = src.T.s[axis];
+    P.xdn = xdv[axis];
+    for (int i = 0; i < UNIRES_MAX_TAPS; ++i) P.kz[i] = src.T.t[axis][i];
+    if (src.S.dim == axis) P.se = src.S.e, P.so = src.S.o;
   } else {
+    P.xdn = 1;
     for (int i = 0; i < UNIRES_MAX_TAPS; ++i) P.kz[i] = 0.f;
   }
   P.A = A, P.Ainv = Ainv;
@@ -372,10 +397,14 @@ int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const 
   static const int dbg = getenv("UNIRES_DBG") ? atoi(getenv("UNIRES_DBG")) : 0;
   P.dbg = dbg;
   const dim3 grid(splat_blocks(dd));
-  if (src.convup)
-    hipLaunchKernelGGL(k_splat<true>, grid, dim3(kWave), 0, st, P, done);
+  if (axis == 0)
+    hipLaunchKernelGGL(k_splat<0>, grid, dim3(kWave), 0, st, P, done);
+  else if (axis == 1)
+    hipLaunchKernelGGL(k_splat<1>, grid, dim3(kWave), 0, st, P, done);
+  else if (axis == 2)
+    hipLaunchKernelGGL(k_splat<2>, grid, dim3(kWave), 0, st, P, done);
   else
-    hipLaunchKernelGGL(k_splat<false>, grid, dim3(kWave), 0, st, P, done);
+    hipLaunchKernelGGL(k_splat<-1>, grid, dim3(kWave), 0, st, P, done);
   return 0;
 }
 
