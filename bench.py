@@ -30,10 +30,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r01_traffic.json')  # PMC bytes of the same matvec
 
 WORKLOADS = {
     # name: dim_y, channels, thick ratio, thick axis per channel
     'cfg3_256c3_thick6z': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 2, 2)),
+    'cfg3_256c3_thick6xyz': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(0, 1, 2)),
     'cfg4_384c4_iso2': dict(dim_y=(384, 384, 384), C=4, thick=2, axes=None),
     'small_96c3_thick3': dict(dim_y=(96, 96, 96), C=3, thick=3, axes=(2, 2, 2)),
 }
@@ -110,6 +112,17 @@ def alg_bytes_matvec(x_c, dim_y):
     n_y = dim_y[0] * dim_y[1] * dim_y[2]
     n_x = sum(xn.po.dim_x[0] * xn.po.dim_x[1] * xn.po.dim_x[2] for xn in x_c)
     return 4 * (2 * n_y + 2 * n_x)
+
+
+def pmc_traffic(workload):
+    """HBM bytes per matvec launch from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE in separate runs; gfx950 FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes).  None if no profile of this workload is committed."""
+    try:
+        rec = json.load(open(TRAFFIC_JSON))
+        return rec['bytes_per_launch'] if rec.get('workload') == workload else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def time_matvec(x, y, rho, sett, reps=50):
@@ -253,7 +266,7 @@ def main():
                                      % (t_admm * 1e3),
             'roofline': {'bound': 'hbm', 'kernel': 'ata_matvec (one channel)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.workload),
                          'alg_bytes_per_launch': b_mv, 'us_per_launch': t_mv * 1e6},
         }
         if not args.no_cpu_baseline and world == 1:

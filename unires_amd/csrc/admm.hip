@@ -121,8 +121,9 @@ __global__ void __launch_bounds__(kBlock)
 
 static inline dim3 vblock() { return dim3(kWave, kBlock / kWave, 1); }
 static inline int tile_blocks(Dim3i d) {
+  // <= 1024 workgroups: each ends with ONE float64 atomic on a single accumulator
   const long long nt = (long long)((d.z + kWave - 1) / kWave) * ((d.y + 3) / 4) * d.x;
-  return (int)(nt < kMaxPartials ? nt : kMaxPartials);
+  return (int)(nt < 1024 ? nt : 1024);
 }
 
 int launch_jtv_scale(const float *const *y, const float *lam, int nc, const float *w,
@@ -147,7 +148,7 @@ void launch_zw_update(const float *y, float lam, const float *scale, float *z, f
 
 int launch_masked_sse(const float *x, const float *ay, size_t n, double *partials, hipStream_t st) {
   size_t b = (n + kBlock - 1) / kBlock;
-  if (b > (size_t)kMaxPartials) b = kMaxPartials;
+  if (b > 512) b = 512;  // one float64 atomic per workgroup on a single accumulator
   if (b < 1) b = 1;
   hipLaunchKernelGGL(k_masked_sse, dim3((int)b), dim3(kBlock), 0, st, x, ay, n, partials);
   return (int)b;

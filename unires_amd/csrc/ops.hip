@@ -181,15 +181,19 @@ __global__ void __launch_bounds__(kBlock)
   const size_t n = d.numel();
   const size_t idx = ((size_t)i * d.y + j) * d.z + k;
   const size_t sx = (size_t)d.y * d.z, sy = d.z;
-  auto U = [&](size_t off) -> float {
-    float v = ca * ua[off];
-    if (ub) v += cb * ub[off];
-    return v;
-  };
-  float acc = 0.f;
-  acc += ((i > 0 ? U(idx - sx) : 0.f) - U(idx)) * ivx;
-  acc += ((j > 0 ? U(n + idx - sy) : 0.f) - U(n + idx)) * ivy;
-  acc += ((k > 0 ? U(2 * n + idx - 1) : 0.f) - U(2 * n + idx)) * ivz;
+  // unconditional (clamped) loads so all of them are in flight together
+  const bool lx = i > 0, ly = j > 0, lz = k > 0;
+  const size_t ox = idx, oy = n + idx, oz = 2 * n + idx;
+  const size_t oxm = lx ? ox - sx : ox, oym = ly ? oy - sy : oy, ozm = lz ? oz - 1 : oz;
+  float vx = ca * ua[ox], vxm = ca * ua[oxm], vy = ca * ua[oy], vym = ca * ua[oym];
+  float vz = ca * ua[oz], vzm = ca * ua[ozm];
+  if (ub) {
+    vx += cb * ub[ox], vxm += cb * ub[oxm], vy += cb * ub[oy], vym += cb * ub[oym];
+    vz += cb * ub[oz], vzm += cb * ub[ozm];
+  }
+  float acc = ((lx ? vxm : 0.f) - vx) * ivx;
+  acc += ((ly ? vym : 0.f) - vy) * ivy;
+  acc += ((lz ? vzm : 0.f) - vz) * ivz;
   dst[idx] = (add ? add[idx] : 0.f) + scale * acc;
 }
 
