@@ -35,6 +35,7 @@ TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r01_traffic.json')  # PMC bytes o
 WORKLOADS = {
     # name: dim_y, channels, thick ratio, thick axis per channel
     'cfg3_256c3_thick6z': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 2, 2)),
+    'cfg3_256c3_thick6z_aligned': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 2, 2), rigid='identity'),
     'cfg3_256c3_thick6xyz': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(0, 1, 2)),
     'cfg4_384c4_iso2': dict(dim_y=(384, 384, 384), C=4, thick=2, axes=None),
     'small_96c3_thick3': dict(dim_y=(96, 96, 96), C=3, thick=3, axes=(2, 2, 2)),
@@ -91,6 +92,8 @@ def build_subject(wl, device, seed):
         dim_x = tuple(int(math.floor(d / s)) for d, s in zip(dim_y, scale))
         u = torch.rand(6, generator=gen) * 2 - 1
         rigid = rigid_matrix((u[:3] * 5.0).tolist(), (u[3:] * 0.1).tolist())
+        if wl.get('rigid') == 'identity':  # grid-aligned observations (no motion between scans)
+            rigid = torch.eye(4, dtype=torch.float64)
         po = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=0, prof_tp=0,
                           device=device)
         clean = U._proj_apply('A', truth[None, None], po)[0, 0]

@@ -22,6 +22,8 @@ CASES = {
     'sr_iso2_gauss': dict(dim_y=(16, 14, 12), n_channels=2, thick=2, regime='sr', iso=True, prof_ip=2,
                           prof_tp=0, vx_y=0.5),
     'sr_iso3_rect': dict(dim_y=(15, 15, 12), n_channels=1, thick=3, regime='sr', iso=True, rot=0.02),
+    'sr_aligned': dict(dim_y=(16, 14, 24), n_channels=2, thick=3, regime='sr', thick_axes=[2, 2], rot=0.0,
+                       trans=0.0, scl=0.1),
     'dn_2ch': dict(dim_y=(15, 13, 11), n_channels=2, regime='dn', rot=0.1, trans=1.5),
     'dn_2rep': dict(dim_y=(12, 12, 10), n_channels=1, regime='dn', n_repeats=2),
     'id_1ch': dict(dim_y=(18, 17, 13), n_channels=1, regime='id'),

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "admm.hpp"
+#include "aligned.hpp"
 #include "cg.hpp"
 #include "fused.hpp"
 #include "ops.hpp"
@@ -560,8 +561,19 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
     launch_dtd(p, pl->dy, pl->vx, a0, c, q, part, done, st);
     return part ? dtd_num_blocks(pl->dy) : 0;
   }
-  // regimes 1/2: two kernels per repeat; the last one also adds c DtD p and the dot
   const size_t nrep = pl->reps.size();
+  static const bool no_aligned = getenv("UNIRES_NO_ALIGNED") != nullptr;
+  if (nrep == 1 && !no_aligned) {
+    // grid-aligned observation (identity + integer shift, z slice profile): one streaming kernel
+    const Repeat &R = pl->reps[0];
+    const float ivx = 1.f / (pl->vx[0] * pl->vx[0]), ivy = 1.f / (pl->vx[1] * pl->vx[1]),
+                ivz = 1.f / (pl->vx[2] * pl->vx[2]);
+    if (!launch_ata_aligned(p, q, pl->dy, R.dim_gf, R.dim_x, R.Tf,
+                            make_scaling(2.f * R.scl, R.dim_thick), R.Af, R.tau, 0.f, c * ivx,
+                            c * ivy, c * ivz, part, done, st))
+      return part ? aligned_blocks(pl->dy) : 0;
+  }
+  // regimes 1/2: two kernels per repeat; the last one also adds c DtD p and the dot
   int npart = 0;
   for (size_t n = 0; n < nrep; ++n) {
     const Repeat &R = pl->reps[n];

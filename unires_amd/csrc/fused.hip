@@ -516,8 +516,11 @@ static void pick_out_tile(const Taps &T, const Dim3i &xd, Dim3i &ot, size_t &lds
   // z: as many outputs as keep the pulled row within two 64-lane passes (a dirac axis:
   // one pass); x,y: 4x4 rows, halved until the pulled tile fits ~24 KB of LDS.
   const int xdv[3] = {xd.x, xd.y, xd.z};
-  int t[3] = {4, 4, 1};
-  t[2] = (T.s[2] == 1 && T.n[2] == 1) ? 64 : std::max(1, (128 - T.n[2]) / T.s[2] + 1);
+  static const int ex = getenv("UNIRES_PC_TX") ? atoi(getenv("UNIRES_PC_TX")) : 4;
+  static const int ey = getenv("UNIRES_PC_TY") ? atoi(getenv("UNIRES_PC_TY")) : 4;
+  static const int ez = getenv("UNIRES_PC_PZ") ? atoi(getenv("UNIRES_PC_PZ")) : 128;
+  int t[3] = {ex, ey, 1};
+  t[2] = (T.s[2] == 1 && T.n[2] == 1) ? 64 : std::max(1, (ez - T.n[2]) / T.s[2] + 1);
   for (int d = 0; d < 3; ++d)
     if (t[d] > xdv[d]) t[d] = xdv[d];
   auto pt = [&](int d) { return (size_t)(t[d] - 1) * T.s[d] + T.n[d]; };
