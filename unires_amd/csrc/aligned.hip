@@ -27,6 +27,7 @@ struct AlignedArgs {
   float se2, so2;     // even/odd slice scaling squared (S(2 scl)), 1,1 = none
   float tau, a0, cx, cy, cz;
   double *partials;
+  const float *objb;  // objective mode (see matvec_emit)
   int tab_pad;  // floats of padding so that the z table is 16-byte aligned in LDS
 };
 
@@ -125,8 +126,7 @@ __global__ void __launch_bounds__(kBlock) k_ata_aligned(AlignedArgs A, const int
       const float yf = (hy ? vyp : 0.f) - c, yb = ly ? c - vym : 0.f;
       const float zf = vzp - c, zb = z > 0 ? c - vzm : 0.f;
       const float out = A.tau * h + A.a0 * c + (A.cx * (xb - xf) + A.cy * (yb - yf) + A.cz * (zb - zf));
-      q[idx] = out;
-      if (A.partials) dot += (double)__fmul_rn(c, out);
+      matvec_emit(q, idx, out, c, A.objb, A.partials != nullptr, dot);
     };
     if (NP > 0) {
 #pragma unroll
@@ -166,7 +166,8 @@ bool affine_is_integer_shift(const Affine &A, int off[3]) {
 // Non-zero return (nothing launched): outside this kernel's domain.
 int launch_ata_aligned(const float *p, float *q, Dim3i dd, Dim3i gd, Dim3i xd, const Taps &T,
                        const Scaling &S2, const Affine &A, float tau, float a0, float cx,
-                       float cy, float cz, double *partials, const int *done, hipStream_t st) {
+                       float cy, float cz, double *partials, const float *objb, const int *done,
+                       hipStream_t st) {
   int off[3];
   if (!affine_is_integer_shift(A, off)) return 1;
   for (int d = 0; d < 2; ++d)
@@ -187,6 +188,7 @@ int launch_ata_aligned(const float *p, float *q, Dim3i dd, Dim3i gd, Dim3i xd, c
   G.se2 = S2.dim == 2 ? S2.e : 1.f, G.so2 = S2.dim == 2 ? S2.o : 1.f;
   G.tau = tau, G.a0 = a0, G.cx = cx, G.cy = cy, G.cz = cz;
   G.partials = partials;
+  G.objb = objb;
   G.tab_pad = pad;
   const dim3 grid(aligned_blocks(dd)), block(kWave, kLinesPerBlock);
   const int np = (dd.z + kWave - 1) / kWave;

@@ -228,7 +228,7 @@ extern "C" int unires_dtd(const float *src, const int32_t dim[3], const float vx
   if (!dims_ok(dim)) return fail(UNIRES_ERR_DIM, "bad dimensions");
   if (!vx_ok(vx)) return fail(UNIRES_ERR_ARG, "voxel size must be positive");
   if (src == dst) return fail(UNIRES_ERR_ARG, "dtd cannot run in place");
-  launch_dtd(src, mk(dim), vx, a, c, dst, nullptr, nullptr, (hipStream_t)stream);
+  launch_dtd(src, mk(dim), vx, a, c, dst, nullptr, nullptr, nullptr, (hipStream_t)stream);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -551,14 +551,16 @@ extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, con
 }
 
 // q = sum_n tau_n AtA_n p + rho lam^2 DtD p ; optional dot partials of sum(p*q).
+// With objb (and part): the partials hold sum (q - 2 objb) * p instead and the final q is not
+// stored (q is still scratch for the partial sums of a multi-repeat operator).
 // Returns the number of partials written (0 if none requested).
 static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *q, double *part,
-                  const int *done, hipStream_t st) {
+                  const int *done, hipStream_t st, const float *objb = nullptr) {
   const float c = rho * (lam * lam);
   if (pl->regime == UNIRES_REGIME_IDENTITY) {
     float a0 = 0.f;
     for (const Repeat &R : pl->reps) a0 += R.tau;
-    launch_dtd(p, pl->dy, pl->vx, a0, c, q, part, done, st);
+    launch_dtd(p, pl->dy, pl->vx, a0, c, q, part, objb, done, st);
     return part ? dtd_num_blocks(pl->dy) : 0;
   }
   const size_t nrep = pl->reps.size();
@@ -570,7 +572,7 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
                 ivz = 1.f / (pl->vx[2] * pl->vx[2]);
     if (!launch_ata_aligned(p, q, pl->dy, R.dim_gf, R.dim_x, R.Tf,
                             make_scaling(2.f * R.scl, R.dim_thick), R.Af, R.tau, 0.f, c * ivx,
-                            c * ivy, c * ivz, part, done, st))
+                            c * ivy, c * ivz, part, objb, done, st))
       return part ? aligned_blocks(pl->dy) : 0;
   }
   // regimes 1/2: two kernels per repeat; the last one also adds c DtD p and the dot
@@ -586,7 +588,7 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
       ep.cy = c / (pl->vx[1] * pl->vx[1]);
       ep.cz = c / (pl->vx[2] * pl->vx[2]);
     }
-    if (n + 1 == nrep) ep.partials = part;
+    if (n + 1 == nrep) ep.partials = part, ep.objb = objb;
     npart = push_any(pl, src, R, R.tau, ep, q, done, st);
   }
   return npart;
@@ -684,9 +686,9 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
     launch_sc_beta(S, pl->part0, pl->part1, gv, k, obj_kind, tol, st);
     launch_update_p(S, pl->r, pl->p, ny, st);
     if (check && stop_mode == UNIRES_STOP_MAXGAIN) {
-      matvec(pl, rho, lam, x, pl->ax, nullptr, done, st);
-      launch_obj(pl->ax, b, x, ny, pl->part1, done, st);
-      launch_sc_obj(S, pl->part1, gv, k, tol, st);
+      // objective sum x (Ax - 2b) folded into the matvec epilogue: A(x) is never stored
+      const int go = matvec(pl, rho, lam, x, pl->ax, pl->part1, done, st, b);
+      launch_sc_obj(S, pl->part1, go, k, tol, st);
     }
   }
   CHECK_LAUNCH();

@@ -31,10 +31,6 @@ __device__ __forceinline__ void st4(float *p, size_t i, float4 v) {
 }
 
 // obj term of nitorch cg for stop != 'e': (A(x) - 2b) * x, rounded like
-// A(x).sub_(2*b).mul_(x)
-__device__ __forceinline__ float obj_term(float ax, float b, float x) {
-  return __fmul_rn(__fsub_rn(ax, __fmul_rn(2.f, b)), x);
-}
 
 // r = b - A(x); p = r; partial[0..G) = sum r*r; partial2 = sum (Ax-2b)*x (optional)
 __global__ void __launch_bounds__(kBlock)
@@ -88,23 +84,6 @@ __global__ void __launch_bounds__(kBlock)
            (double)__fmul_rn(va.z, vb.z) + (double)__fmul_rn(va.w, vb.w);
   }
   for (size_t i = n4 * 4 + tid0; i < n; i += stride) acc += (double)__fmul_rn(a[i], b[i]);
-  const double t = block_sum(acc);
-  if (threadIdx.x == 0) part[blockIdx.x] = t;
-}
-
-// partial = sum (Ax - 2b) * x
-__global__ void __launch_bounds__(kBlock)
-    k_obj(const float *__restrict__ ax, const float *__restrict__ b, const float *__restrict__ x,
-          size_t n, double *__restrict__ part, const int *__restrict__ done) {
-  if (done && *done) return;
-  GRID_STRIDE_VEC4(n);
-  double acc = 0.0;
-  for (size_t i = tid0; i < n4; i += stride) {
-    const float4 va = ld4(ax, i), vb = ld4(b, i), vx = ld4(x, i);
-    acc += (double)obj_term(va.x, vb.x, vx.x) + (double)obj_term(va.y, vb.y, vx.y) +
-           (double)obj_term(va.z, vb.z, vx.z) + (double)obj_term(va.w, vb.w, vx.w);
-  }
-  for (size_t i = n4 * 4 + tid0; i < n; i += stride) acc += (double)obj_term(ax[i], b[i], x[i]);
   const double t = block_sum(acc);
   if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
@@ -273,10 +252,6 @@ void launch_residual_init(const float *b, const float *ax, const float *x, float
 void launch_dot(const float *a, const float *b, size_t n, double *part, const int *done,
                 hipStream_t st) {
   hipLaunchKernelGGL(k_dot, dim3(vec_blocks(n)), dim3(kBlock), 0, st, a, b, n, part, done);
-}
-void launch_obj(const float *ax, const float *b, const float *x, size_t n, double *part,
-                const int *done, hipStream_t st) {
-  hipLaunchKernelGGL(k_obj, dim3(vec_blocks(n)), dim3(kBlock), 0, st, ax, b, x, n, part, done);
 }
 void launch_update_xr(const CgState *s, const float *p, const float *ap, float *x, float *r,
                       const float *b, size_t n, double *part_rr, double *part_obj,

@@ -17,8 +17,6 @@ void launch_residual_init(const float *b, const float *ax, const float *x, float
                           size_t n, double *part_rr, double *part_obj, hipStream_t st);
 void launch_dot(const float *a, const float *b, size_t n, double *part, const int *done,
                 hipStream_t st);
-void launch_obj(const float *ax, const float *b, const float *x, size_t n, double *part,
-                const int *done, hipStream_t st);
 void launch_update_xr(const CgState *s, const float *p, const float *ap, float *x, float *r,
                       const float *b, size_t n, double *part_rr, double *part_obj, hipStream_t st);
 void launch_update_p(const CgState *s, const float *r, float *p, size_t n, hipStream_t st);

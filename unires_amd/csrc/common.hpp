@@ -193,6 +193,26 @@ __device__ __forceinline__ float pull_sample(const float *__restrict__ src, cons
   return pull_finish(L);
 }
 
+// One term of the CG objective sum x (Ax - 2b): A(x).sub_(2*b).mul_(x), nitorch
+// optim.py cg() stop='max_gain' (rounded like the reference's three elementwise ops).
+__device__ __forceinline__ float obj_term(float ax, float b, float x) {
+  return __fmul_rn(__fsub_rn(ax, __fmul_rn(2.f, b)), x);
+}
+
+// Epilogue of every matvec kernel.  Normal mode: store q, partial += p*q.  Objective mode
+// (objb != nullptr): partial += (q - 2 b) * p and q is NOT stored - the CG objective needs
+// A(x) only inside this sum, so the vector never goes to HBM.
+__device__ __forceinline__ void matvec_emit(float *__restrict__ dst, size_t idx, float q, float pc,
+                                            const float *__restrict__ objb, bool want_dot,
+                                            double &dot) {
+  if (objb) {
+    dot += (double)obj_term(q, objb[idx], pc);
+  } else {
+    dst[idx] = q;
+    if (want_dot) dot += (double)__fmul_rn(pc, q);
+  }
+}
+
 // (c . DtD p)[i,j,k] with per-axis weights cx,cy,cz = c/vx^2: forward differences, zero
 // bound -> rows [1,-1] at 0, [-1,2,-1] inside, [-1,2] at n-1.  Loads are unconditional
 // (clamped addresses) so the 7 of them issue together; `pc` returns the centre value.

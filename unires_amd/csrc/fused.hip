@@ -131,6 +131,7 @@ struct PushArgs {
   Dim3i dd;
   int accumulate;    // dst += instead of dst =
   double *partials;  // nullptr: no dot; else partial of sum(p * dst) per block
+  const float *objb;
   int dbg;           // ablation bitmask (UNIRES_DBG env; 0 in production)
   int row_sep;       // min |d(ui,uj)|_inf for two grid rows to be splatted together
   int use_atomics;   // grid-z step too short for the plain read-add-write splat
@@ -496,8 +497,7 @@ __global__ void __launch_bounds__(kPushThreads)
         q += P.a0 * pc + st;
       }
       if (P.accumulate) q += dst[idx];
-      dst[idx] = q;
-      if (P.partials) dot += (double)__fmul_rn(pc, q);
+      matvec_emit(dst, idx, q, pc, P.objb, P.partials != nullptr, dot);
     }
     PROF_T(t_e1);
     PROF_ADD(5, t_e0, t_e1);
@@ -626,6 +626,7 @@ int launch_push_tile(const PushSrc &src, const Affine &A, const Affine &Ainv,
   P.dd = dd;
   P.accumulate = ep.accumulate;
   P.partials = ep.partials;
+  P.objb = ep.objb;
   static const int dbg = getenv("UNIRES_DBG") ? atoi(getenv("UNIRES_DBG")) : 0;
   P.dbg = dbg;
   P.row_sep = safe.row_sep;
@@ -689,6 +690,7 @@ struct GatherArgs {
   Dim3i dd;
   int accumulate;
   double *partials;
+  const float *objb;
 };
 
 __device__ __forceinline__ float hat(float d) {
@@ -765,8 +767,7 @@ __global__ void __launch_bounds__(kBlock)
       q += G.a0 * pc + st;
     }
     if (G.accumulate) q += dst[idx];
-    dst[idx] = q;
-    if (G.partials) dot += (double)__fmul_rn(pc, q);
+    matvec_emit(dst, idx, q, pc, G.objb, G.partials != nullptr, dot);
   }
   if (G.partials) {
     const double tot = block_sum(dot);
@@ -803,6 +804,7 @@ int launch_push_gather(const float *src, Dim3i gd, const Affine &A, const Affine
   G.dd = dd;
   G.accumulate = ep.accumulate;
   G.partials = ep.partials;
+  G.objb = ep.objb;
   hipLaunchKernelGGL(k_push_gather, dim3(push_gather_blocks(dd)), dim3(kWave, kBlock / kWave), 0, st,
                      G, done);
   return 0;

@@ -18,6 +18,7 @@ struct PushEpilogue {
   float a0 = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
   int accumulate = 0;          // dst += instead of dst =
   double *partials = nullptr;  // push_tile_blocks(dd) doubles: pieces of sum(p * dst)
+  const float *objb = nullptr; // objective mode: partials = sum (dst - 2 objb) * p, dst not stored
 };
 
 // xs = S conv_down pull_A(src).  Returns non-zero if the tile does not fit LDS

@@ -39,6 +39,7 @@ struct G2Args {
   Dim3i dd;
   int accumulate;
   double *partials;
+  const float *objb;
 };
 
 // max(0, 1-|d|) in ONE instruction: fmed3(x,0,1) folds into v_sub_f32 |d| clamp
@@ -223,8 +224,7 @@ __global__ void __launch_bounds__(kBlock) k_gather2(G2Args G, const int *__restr
         q += G.a0 * pc + st;
       }
       if (G.accumulate) q += dst[idx];
-      dst[idx] = q;
-      if (G.partials) dot += (double)__fmul_rn(pc, q);
+      matvec_emit(dst, idx, q, pc, G.objb, G.partials != nullptr, dot);
     }
   }
   if (G.partials) {
@@ -303,6 +303,7 @@ int launch_gather2(const PushSrc &src, const float4 *ztab_dev, const Affine &A, 
   G.dst = dst, G.dd = dd;
   G.accumulate = ep.accumulate;
   G.partials = ep.partials;
+  G.objb = ep.objb;
   const dim3 grid(gather2_blocks(dd)), block(kWave, kBlock / kWave);
   const size_t tab_bytes = src.convup ? (size_t)G.gz * sizeof(float4) : 0;
   G.ztab_in_lds = tab_bytes > 0 && tab_bytes <= 16 * 1024;

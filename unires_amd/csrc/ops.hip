@@ -203,7 +203,7 @@ template <bool DOT>
 __global__ void __launch_bounds__(kBlock)
     k_dtd(const float *__restrict__ src, Dim3i d, float cx, float cy, float cz, float a,
           float *__restrict__ dst, double *__restrict__ partials,
-          const int *__restrict__ done) {
+          const float *__restrict__ objb, const int *__restrict__ done) {
   if (done && *done) return;
   // tiles of 4 y-rows x 64 z; a bounded grid (<= kMaxPartials blocks) strides over them
   const int tz = (d.z + kWave - 1) / kWave, ty = (d.y + 3) / 4;
@@ -221,8 +221,7 @@ __global__ void __launch_bounds__(kBlock)
       float c;
       const float st = dtd_at(src, idx, i, j, k, d, cx, cy, cz, c);
       const float q = a * c + st;
-      dst[idx] = q;
-      if (DOT) prod += (double)__fmul_rn(c, q);
+      matvec_emit(dst, idx, q, c, DOT ? objb : nullptr, DOT, prod);
     }
   }
   if (DOT) {
@@ -284,15 +283,15 @@ int dtd_num_blocks(Dim3i d) {
 
 // partials (nullable) must hold dtd_num_blocks(d) doubles.
 void launch_dtd(const float *src, Dim3i d, const float vx[3], float a, float c, float *dst,
-                double *partials, const int *done, hipStream_t st) {
+                double *partials, const float *objb, const int *done, hipStream_t st) {
   const float cx = c / (vx[0] * vx[0]), cy = c / (vx[1] * vx[1]), cz = c / (vx[2] * vx[2]);
   const dim3 grid(dtd_num_blocks(d));
   if (partials)
     hipLaunchKernelGGL(k_dtd<true>, grid, vol_block(), 0, st, src, d, cx, cy, cz, a, dst,
-                       partials, done);
+                       partials, objb, done);
   else
     hipLaunchKernelGGL(k_dtd<false>, grid, vol_block(), 0, st, src, d, cx, cy, cz, a, dst,
-                       partials, done);
+                       partials, nullptr, done);
 }
 
 }  // namespace unires

@@ -20,8 +20,9 @@ void launch_grad(const float *src, Dim3i d, const float vx[3], float *dst3, hipS
 void launch_div(const float *ua, const float *ub, float ca, float cb, Dim3i d, const float vx[3],
                 float scale, const float *add, float *dst, hipStream_t st);
 int dtd_num_blocks(Dim3i d);
-// dst = a*src + c*DtD(src); partials (nullable, dtd_num_blocks doubles) gets sum(src*dst) pieces
+// dst = a*src + c*DtD(src); partials (nullable, dtd_num_blocks doubles) gets sum(src*dst) pieces;
+// with objb (needs partials): partials = sum (dst - 2 objb) * src and dst is not stored.
 void launch_dtd(const float *src, Dim3i d, const float vx[3], float a, float c, float *dst,
-                double *partials, const int *done, hipStream_t st);
+                double *partials, const float *objb, const int *done, hipStream_t st);
 
 }  // namespace unires

@@ -34,6 +34,7 @@ struct SplatArgs {
   Dim3i dd;
   int accumulate;
   double *partials;
+  const float *objb;
   int row_sep;
   int dbg;
 };
@@ -335,8 +336,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
         q += P.a0 * pc + st;
       }
       if (P.accumulate) q += dst[idx];
-      dst[idx] = q;
-      if (P.partials) dot += (double)__fmul_rn(pc, q);
+      matvec_emit(dst, idx, q, pc, P.objb, P.partials != nullptr, dot);
     }
   }
   if (P.partials) {
@@ -393,6 +393,7 @@ int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const 
   P.dst = dst, P.dd = dd;
   P.accumulate = ep.accumulate;
   P.partials = ep.partials;
+  P.objb = ep.objb;
   P.row_sep = safe.row_sep;
   static const int dbg = getenv("UNIRES_DBG") ? atoi(getenv("UNIRES_DBG")) : 0;
   P.dbg = dbg;
