@@ -181,6 +181,58 @@ def cpu_baseline(wl, seconds_budget=25.0):
                        % (n_it, dim_y[0], dim_y[1], dim_y[2], t_mv))
 
 
+def time_steps(step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def variants(name, x, y, z, w, rho, tmp, sett, device):
+    """Secondary records of the same y-update (rank 0, N = 1; never the headline value):
+    (1) reference-faithful CG: tolerance 1e-3, stop 'max_gain' (objective every iteration,
+        early stop on device) with the realised iteration counts (SURVEY 8(d));
+    (2) the same subject with rigid = identity (SURVEY 8(d) allows "small random rigid or
+        identity"): observations on the reconstruction grid take the one-kernel matvec."""
+    import unires_amd as U
+    out = {}
+
+    def run(xs, ys, zs, ws, r, t, st):
+        def step():
+            for yc in ys:
+                yc.dat.zero_()
+            U._update_y(xs, ys, zs, ws, r, t, st)
+        return step
+
+    tol0 = sett.cgs_tol
+    sett.cgs_tol = 1e-3
+    for yc in y:
+        yc.dat.zero_()
+    info = []
+    U._update_y(x, y, z, w, rho, tmp, sett, info=info)
+    iters = [int(r[0]) for r in info]
+    t = time_steps(run(x, y, z, w, rho, tmp, sett), 3, 1)
+    out['cg_tol1e-3_max_gain'] = {'cg_iters_realised': iters, 'cg_iters_per_sec': sum(iters) / t,
+                                  'ms_per_step': t * 1e3}
+    sett.cgs_tol = tol0
+    alt = name + '_aligned'
+    if alt in WORKLOADS:
+        del info
+        xa, ya, za, wa, rhoa, setta = build_subject(WORKLOADS[alt], device, seed=1234)
+        ta = torch.zeros_like(ya[0].dat)
+        t = time_steps(run(xa, ya, za, wa, rhoa, ta, setta), 3, 1)
+        t_mv = time_matvec(xa, ya, rhoa, setta)
+        b_mv = alg_bytes_matvec(xa[0], WORKLOADS[alt]['dim_y'])
+        out[alt] = {'cg_iters_per_sec': len(xa) * setta.cgs_max_iter / t, 'ms_per_step': t * 1e3,
+                    'matvec_us': t_mv * 1e6, 'matvec_GBps': b_mv / t_mv / 1e9,
+                    'matvec_frac_of_peak': b_mv / t_mv / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -188,6 +240,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='cfg3_256c3_thick6z', choices=list(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-variants', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=25.0)
     args = ap.parse_args()
 
@@ -272,6 +325,8 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.workload),
                          'alg_bytes_per_launch': b_mv, 'us_per_launch': t_mv * 1e6},
         }
+        if world == 1 and not args.no_variants:
+            out['variants'] = variants(args.workload, x, y, z, w, rho, tmp, sett, device)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(wl, args.cpu_seconds)
         print(json.dumps(out))

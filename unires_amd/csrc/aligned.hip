@@ -9,11 +9,28 @@
 //     (AtA p)[z] = sum_{k : 0 <= z-oz-6k < K} kz[z - oz - 6k] * xs[k]
 // One wave owns one output z line: the line is read once into LDS, its x-space line is built
 // in LDS (it never goes to HBM), and q is written once with the DtD stencil and the float64
-// dot fused.  HBM traffic = read p + write q: this is the kernel that can sit on the HBM
-// roofline; the general kernels (fused.hip, splat.hip) are instruction-issue bound.
+// dot fused.  HBM traffic = read p + write q.
+//
+// What bounds it: a wave64 VALU instruction occupies its SIMD for 4 clocks, so the chip issues
+// 6.1e11 wave-instructions/s; the first version spent 325 VALU instructions per line (35 us of
+// issue time for 65 536 lines - its whole run time), mostly per-lane copies of wave-uniform
+// index arithmetic.  Here everything uniform across the wave lives in SGPRs (the wave index
+// goes through readfirstlane; loads and stores are scalar base + lane offset), everything that
+// depends on the lane but not on the line is hoisted out of the line loop, and the LDS line
+// carries a zero apron so that no tap needs a bounds check.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "aligned.hpp"
 
 namespace unires {
+
+constexpr int kAlignedMaxTaps = 16;
+#ifndef UNIRES_ALIGNED_PF
+#define UNIRES_ALIGNED_PF 1
+#endif
 
 struct AlignedArgs {
   const float *p;
@@ -23,123 +40,179 @@ struct AlignedArgs {
   int xdz;            // x-space z length
   int ox, oy, oz;     // output voxel = grid voxel + o
   int nk, s;          // taps / stride along z
-  float kz[UNIRES_MAX_TAPS];
+  float kz[kAlignedMaxTaps];
   float se2, so2;     // even/odd slice scaling squared (S(2 scl)), 1,1 = none
   float tau, a0, cx, cy, cz;
   double *partials;
   const float *objb;  // objective mode (see matvec_emit)
-  int tab_pad;  // floats of padding so that the z table is 16-byte aligned in LDS
+  int padl, padr;     // zero apron of the LDS line (floats)
+  int wave_floats;    // LDS floats per wave: padl + nz + padr + xdz + 1
+  unsigned long long *prof;
 };
 
 constexpr int kLinesPerBlock = kBlock / kWave;
 
+#ifdef UNIRES_ALIGNED_PROF  // debug builds: per-phase wall-clock sums (100 MHz s_memrealtime ticks)
+#define AP_T(var) const unsigned long long var = wall_clock64()
+#define AP_ADD(slot, t0, t1) \
+  if (A.prof && lane == 0) atomicAdd(A.prof + (slot), (t1) - (t0))
+#else
+#define AP_T(var)
+#define AP_ADD(slot, t0, t1)
+#endif
+
 // NP = ceil(nz / 64) z-passes per line, known at compile time so that ALL global loads of a
-// line (its own values and its four x/y neighbours) are issued before anything is consumed:
-// one memory round trip per line.  NP = 0: generic loop version for longer lines.
-template <int NP>
-__global__ void __launch_bounds__(kBlock) k_ata_aligned(AlignedArgs A, const int *__restrict__ done) {
+// line (its own values and its four x/y neighbours) are issued before anything is consumed.
+template <int NP, bool DOT, bool OBJ>
+__global__ void __launch_bounds__(kBlock)
+    k_ata_aligned(AlignedArgs A, const int *__restrict__ done) {
+  AP_T(t_entry);
   if (done && *done) return;
   extern __shared__ float smem[];
-  const int lane = threadIdx.x, w = threadIdx.y;
+  const unsigned lane = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform -> SGPR
   const Dim3i dd = A.dd;
   const int nz = dd.z;
-  float *kz = smem;                                          // taps (per-lane indexed below)
-  float *pl = smem + UNIRES_MAX_TAPS + w * (nz + A.xdz);     // this wave's copy of the p line
-  float *xs = pl + nz;                                       // and its x-space line
-  // per-output-z table of the transposed conv: (AtA p)[z] = w0 * xs[koff] + w1 * xs[koff+1]
-  float4 *ztab = reinterpret_cast<float4 *>(smem + UNIRES_MAX_TAPS + kLinesPerBlock * (nz + A.xdz) +
-                                            A.tab_pad);
-  if (w == 0 && lane < UNIRES_MAX_TAPS) kz[lane] = A.kz[lane];
+  // block-shared: per-output-z table of the transposed conv, (AtA p)[z] = w0 xs[ko] + w1 xs[ko+1]
+  float4 *ztab = reinterpret_cast<float4 *>(smem);
+  float *kzs = smem + 4 * NP * kWave;
+  float *buf = kzs + kAlignedMaxTaps + w * A.wave_floats;
+  float *pl = buf + A.padl;          // pl[-padl, nz + padr): this wave's copy of the p line
+  float *xs = pl + nz + A.padr;      // xs[0, xdz]: its x-space line (+ one zero pad)
+  if (w == 0 && lane < kAlignedMaxTaps) kzs[lane] = A.kz[lane];
+  for (int i = lane; i < A.wave_floats; i += kWave) buf[i] = 0.f;  // aprons stay zero
   __syncthreads();
-  for (int z = w * kWave + lane; z < nz; z += kBlock) {
+  for (int z = w * kWave + (int)lane; z < NP * kWave; z += kBlock) {
     const int uz = z - A.oz;
     float w0 = 0.f, w1 = 0.f;
     int koff = 0;
-    if (uz >= 0 && uz < A.gz) {
+    if (uz >= 0 && uz < A.gz && z < nz) {
       int klo, khi;
       up_range(uz, A.nk, A.s, A.xdz, klo, khi);
       const int n = khi - klo + 1;
-      if (n >= 1) w0 = kz[uz - A.s * klo];
-      if (n >= 2) w1 = kz[uz - A.s * (klo + 1)];
-      koff = n >= 1 ? klo : 0;
-      if (koff > A.xdz - 2) {  // last slice: use the pair (xdz-2, xdz-1), weight on the second
-        koff = A.xdz - 2;
-        w1 = w0, w0 = 0.f;
-      }
+      if (n >= 1) w0 = kzs[uz - A.s * klo], koff = klo;
+      if (n >= 2) w1 = kzs[uz - A.s * (klo + 1)];
     }
     ztab[z] = make_float4(__int_as_float(koff), w0, w1, 0.f);
   }
   __syncthreads();
+  // ---- lane constants (independent of the line) ----
+  float ew0[NP], ew1[NP];
+  const float *exs[NP];
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    const float4 tb = ztab[u * kWave + lane];
+    ew0[u] = tb.y, ew1[u] = tb.z, exs[u] = xs + __float_as_int(tb.x);  // xs[xdz] is a zero pad
+  }
+
   const float *__restrict__ p = A.p;
   float *__restrict__ q = A.q;
   const int nlines = dd.x * dd.y;
   const size_t sx = (size_t)dd.y * nz, sy = nz;
-  constexpr int MAXP = NP > 0 ? NP : 1;
   double dot = 0.0;
-  for (int line = blockIdx.x * kLinesPerBlock + w; line < nlines;
-       line += gridDim.x * kLinesPerBlock) {
+  const int lb = xcd_chunked_block(blockIdx.x, gridDim.x);  // x/y halo lines stay in one L2
+  const int line_step = gridDim.x * kLinesPerBlock;
+  AP_T(t_loop);
+  AP_ADD(0, t_entry, t_loop);
+  for (int line = lb * kLinesPerBlock + w; line < nlines; line += line_step) {
+    AP_T(t0);
+    // everything down to the loads is scalar (SGPR) arithmetic
     const int vx = line / dd.y, vy = line - vx * dd.y;
     const size_t base = (size_t)line * nz;
     const bool hx = vx + 1 < dd.x, lx = vx > 0, hy = vy + 1 < dd.y, ly = vy > 0;
-    const size_t bxp = hx ? base + sx : base, bxm = lx ? base - sx : base;
-    const size_t byp = hy ? base + sy : base, bym = ly ? base - sy : base;
-    float rc[MAXP], rxp[MAXP], rxm[MAXP], ryp[MAXP], rym[MAXP];
-    if (NP > 0) {
+    const float *pc = p + base;
+    const float *pxp = hx ? pc + sx : pc, *pxm = lx ? pc - sx : pc;
+    const float *pyp = hy ? pc + sy : pc, *pym = ly ? pc - sy : pc;
+    const float *ob = OBJ ? A.objb + base : pc;
+    float rc[NP], rxp[NP], rxm[NP], ryp[NP], rym[NP], rb[NP];
 #pragma unroll
-      for (int u = 0; u < MAXP; ++u) {
-        const int z = min(u * kWave + lane, nz - 1);
-        rc[u] = p[base + z], rxp[u] = p[bxp + z], rxm[u] = p[bxm + z], ryp[u] = p[byp + z],
-        rym[u] = p[bym + z];
-      }
-#pragma unroll
-      for (int u = 0; u < MAXP; ++u)
-        if (u * kWave + lane < nz) pl[u * kWave + lane] = rc[u];
-    } else {
-      for (int z = lane; z < nz; z += kWave) pl[z] = p[base + z];
+    for (int u = 0; u < NP; ++u) {
+      const unsigned z = min(u * kWave + lane, (unsigned)nz - 1u);
+      rc[u] = pc[z], rxp[u] = pxp[z], rxm[u] = pxm[z], ryp[u] = pyp[z], rym[u] = pym[z];
+      if (OBJ) rb[u] = ob[z];
     }
+#pragma unroll
+    for (int u = 0; u < NP; ++u)
+      if (u * kWave + (int)lane < nz) pl[u * kWave + lane] = rc[u];
     asm volatile("" ::: "memory");  // single wave: LDS ops execute in order
+    AP_T(t1);
+    AP_ADD(1, t0, t1);
     const int ux = vx - A.ox, uy = vy - A.oy;
     const bool has = ux >= 0 && ux < A.gx && uy >= 0 && uy < A.gy;  // wave-uniform
     if (has) {
-      for (int k = lane; k < A.xdz; k += kWave) {
-        float acc = 0.f;
-        const int z0 = k * A.s + A.oz;
-        for (int t = 0; t < A.nk; ++t) {
-          const int z = z0 + t;
-          const float v = (z >= 0 && z < nz) ? pl[min(max(z, 0), nz - 1)] : 0.f;
-          acc = fmaf(kz[t], v, acc);
+      for (int k0 = 0; k0 < A.xdz; k0 += kWave) {
+        const int k = k0 + (int)lane;
+        if (k < A.xdz) {
+          const float *in = pl + (k * A.s + A.oz);  // apron: no bounds checks on the taps
+          float acc = 0.f;
+          for (int t = 0; t < A.nk; ++t) acc = fmaf(kzs[t], in[t], acc);  // taps: LDS broadcast
+          xs[k] = acc * ((k & 1) ? A.so2 : A.se2);
         }
-        xs[k] = acc * ((k & 1) ? A.so2 : A.se2);
       }
       asm volatile("" ::: "memory");
     }
-    auto emit = [&](int z, float c, float vxp, float vxm, float vyp, float vym) {
-      float h = 0.f;
-      if (has) {
-        const float4 tb = ztab[z];
-        const int ko = __float_as_int(tb.x);
-        h = tb.y * xs[ko] + tb.z * xs[ko + 1];
-      }
-      const size_t idx = base + z;
-      const float vzp = z + 1 < nz ? pl[z + 1] : 0.f, vzm = z > 0 ? pl[z - 1] : c;
-      const float xf = (hx ? vxp : 0.f) - c, xb = lx ? c - vxm : 0.f;
-      const float yf = (hy ? vyp : 0.f) - c, yb = ly ? c - vym : 0.f;
-      const float zf = vzp - c, zb = z > 0 ? c - vzm : 0.f;
-      const float out = A.tau * h + A.a0 * c + (A.cx * (xb - xf) + A.cy * (yb - yf) + A.cz * (zb - zf));
-      matvec_emit(q, idx, out, c, A.objb, A.partials != nullptr, dot);
-    };
-    if (NP > 0) {
+    AP_T(t2);
+    AP_ADD(2, t1, t2);
+    // All NP outputs are computed BEFORE the first store.  gfx9 counts loads and stores in
+    // one in-order-per-kind counter, so after a store the compiler must drain it completely
+    // (vmcnt(0)) to be sure of an older load: interleaving stores and load uses cost one
+    // store round trip per pass.
+    float out[NP];
+    auto compute = [&](auto edge_tag, auto has_tag) {
+      constexpr bool EDGE = decltype(edge_tag)::value, HAS = decltype(has_tag)::value;
 #pragma unroll
-      for (int u = 0; u < MAXP; ++u) {
-        const int z = u * kWave + lane;
-        if (z < nz) emit(z, rc[u], rxp[u], rxm[u], ryp[u], rym[u]);
+      for (int u = 0; u < NP; ++u) {
+        const unsigned z = u * kWave + lane;
+        const float c = rc[u];
+        float h = 0.f;
+        if (HAS) h = ew0[u] * exs[u][0] + ew1[u] * exs[u][1];
+        const float vzp = pl[z + 1];            // zero apron at z = nz
+        float vzm = pl[(int)z - 1];
+        if (u == 0) vzm = lane == 0 ? c : vzm;  // Neumann row at z = 0
+        float xf, xb, yf, yb;
+        if (EDGE) {
+          xf = (hx ? rxp[u] : 0.f) - c, xb = lx ? c - rxm[u] : 0.f;
+          yf = (hy ? ryp[u] : 0.f) - c, yb = ly ? c - rym[u] : 0.f;
+        } else {
+          xf = rxp[u] - c, xb = c - rxm[u], yf = ryp[u] - c, yb = c - rym[u];
+        }
+        const float zf = vzp - c, zb = c - vzm;
+        out[u] = A.tau * h + A.a0 * c + (A.cx * (xb - xf) + A.cy * (yb - yf) + A.cz * (zb - zf));
       }
-    } else {
-      for (int z = lane; z < nz; z += kWave) emit(z, pl[z], p[bxp + z], p[bxm + z], p[byp + z], p[bym + z]);
-    }
+    };
+    const bool edge = !(hx && lx && hy && ly);
+    if (!edge && has)
+      compute(std::false_type{}, std::true_type{});
+    else if (!edge)
+      compute(std::false_type{}, std::false_type{});
+    else if (has)
+      compute(std::true_type{}, std::true_type{});
+    else
+      compute(std::true_type{}, std::false_type{});
     asm volatile("" ::: "memory");  // the line buffers are reused by the next line
+    AP_T(t3);
+    AP_ADD(3, t2, t3);
+    float *qc = q + base;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const unsigned z = u * kWave + lane;
+      if ((int)z < nz) {
+        if (OBJ) {
+          dot += (double)obj_term(out[u], rb[u], rc[u]);
+        } else {
+          qc[z] = out[u];
+          if (DOT) dot += (double)__fmul_rn(rc[u], out[u]);
+        }
+      }
+    }
+    AP_T(t4);
+    AP_ADD(4, t3, t4);
+    AP_ADD(5, 0ull, 1ull);
   }
-  if (A.partials) {
+  AP_T(t_end);
+  AP_ADD(6, t_entry, t_end);
+  AP_ADD(7, 0ull, 1ull);
+  if (DOT) {
     const double tot = block_sum(dot);
     if (threadIdx.x == 0 && threadIdx.y == 0) A.partials[blockIdx.x] = tot;
   }
@@ -147,7 +220,12 @@ __global__ void __launch_bounds__(kBlock) k_ata_aligned(AlignedArgs A, const int
 
 int aligned_blocks(Dim3i dd) {
   const long long nb = ((long long)dd.x * dd.y + kLinesPerBlock - 1) / kLinesPerBlock;
-  return (int)(nb < kMaxPartials ? nb : kMaxPartials);
+  // 4096 workgroups = 4 lines per wave: amortises the per-wave set-up (table, LDS aprons) and
+  // still load-balances (measured: 2048 38.8 us, 4096 35.2 us, 8192 39.0 us)
+  static const int cap =
+      getenv("UNIRES_ALIGNED_BLOCKS") ? atoi(getenv("UNIRES_ALIGNED_BLOCKS")) : 4096;
+  const long long lim = cap < kMaxPartials ? cap : kMaxPartials;
+  return (int)(nb < lim ? nb : lim);
 }
 
 // True iff A is the identity plus an integer translation, bit for bit (then every trilinear
@@ -174,32 +252,68 @@ int launch_ata_aligned(const float *p, float *q, Dim3i dd, Dim3i gd, Dim3i xd, c
     if (T.n[d] != 1 || T.s[d] != 1 || T.t[d][0] != 1.f) return 1;
   if (S2.dim >= 0 && S2.dim != 2) return 1;
   if (xd.z < 2 || (T.n[2] + T.s[2] - 1) / T.s[2] > 2) return 1;  // fan-in <= 2 (rect profiles)
-  const size_t nf = (size_t)kLinesPerBlock * (dd.z + xd.z) + UNIRES_MAX_TAPS;
-  const int pad = (int)((4 - nf % 4) % 4);
-  const size_t lds = (nf + pad + (size_t)dd.z * 4) * sizeof(float);
-  if (lds > 48 * 1024) return 1;
+  if (T.n[2] > kAlignedMaxTaps || dd.z > 8 * kWave) return 1;
+  if (objb && !partials) return 1;
+  // taps of slice k read output voxels [k s + oz, k s + oz + nk): zero apron for the part
+  // outside the line (bound 'zero'; in this geometry the in-FOV mask is the in-bounds test)
+  const int lo = off[2], hi = (xd.z - 1) * T.s[2] + off[2] + T.n[2] - 1;
+  const int padl = lo < -1 ? -lo : 1, padr = hi > dd.z ? hi - dd.z + 1 : 1;
+  if (padl > 256 || padr > 256) return 1;
+  const int np = (dd.z + kWave - 1) / kWave;
+  const int npt = np <= 2 ? 2 : (np <= 4 ? 4 : (np <= 6 ? 6 : 8));
   AlignedArgs G;
+  G.padl = padl, G.padr = padr;
+  G.wave_floats = padl + dd.z + padr + xd.z + 1;
+  const size_t lds =
+      ((size_t)4 * npt * kWave + kAlignedMaxTaps + (size_t)kLinesPerBlock * G.wave_floats) * sizeof(float);
+  if (lds > 64 * 1024) return 1;
   G.p = p, G.q = q, G.dd = dd;
   G.gx = gd.x, G.gy = gd.y, G.gz = gd.z;
   G.xdz = xd.z;
   G.ox = off[0], G.oy = off[1], G.oz = off[2];
   G.nk = T.n[2], G.s = T.s[2];
-  for (int i = 0; i < UNIRES_MAX_TAPS; ++i) G.kz[i] = T.t[2][i];
+  for (int i = 0; i < kAlignedMaxTaps; ++i) G.kz[i] = T.t[2][i];
   G.se2 = S2.dim == 2 ? S2.e : 1.f, G.so2 = S2.dim == 2 ? S2.o : 1.f;
   G.tau = tau, G.a0 = a0, G.cx = cx, G.cy = cy, G.cz = cz;
   G.partials = partials;
   G.objb = objb;
-  G.tab_pad = pad;
+  G.prof = nullptr;
+#ifdef UNIRES_ALIGNED_PROF
+  static unsigned long long *prof = nullptr;
+  if (!prof) (void)hipMalloc((void **)&prof, 8 * sizeof(unsigned long long));
+  (void)hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), st);
+  G.prof = prof;
+#endif
   const dim3 grid(aligned_blocks(dd)), block(kWave, kLinesPerBlock);
-  const int np = (dd.z + kWave - 1) / kWave;
-  if (np <= 2)
-    hipLaunchKernelGGL(k_ata_aligned<2>, grid, block, lds, st, G, done);
-  else if (np <= 4)
-    hipLaunchKernelGGL(k_ata_aligned<4>, grid, block, lds, st, G, done);
-  else if (np <= 6)
-    hipLaunchKernelGGL(k_ata_aligned<6>, grid, block, lds, st, G, done);
+#define LAUNCH_ALIGNED(NPV)                                                                  \
+  do {                                                                                       \
+    if (objb)                                                                                \
+      hipLaunchKernelGGL((k_ata_aligned<NPV, true, true>), grid, block, lds, st, G, done);   \
+    else if (partials)                                                                       \
+      hipLaunchKernelGGL((k_ata_aligned<NPV, true, false>), grid, block, lds, st, G, done);  \
+    else                                                                                     \
+      hipLaunchKernelGGL((k_ata_aligned<NPV, false, false>), grid, block, lds, st, G, done); \
+  } while (0)
+  if (npt == 2)
+    LAUNCH_ALIGNED(2);
+  else if (npt == 4)
+    LAUNCH_ALIGNED(4);
+  else if (npt == 6)
+    LAUNCH_ALIGNED(6);
   else
-    hipLaunchKernelGGL(k_ata_aligned<0>, grid, block, lds, st, G, done);
+    LAUNCH_ALIGNED(8);
+#undef LAUNCH_ALIGNED
+#ifdef UNIRES_ALIGNED_PROF
+  {
+    unsigned long long h[8];
+    (void)hipMemcpyAsync(h, prof, sizeof(h), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    const double nl = h[5] ? (double)h[5] : 1.0, nw = h[7] ? (double)h[7] : 1.0;
+    fprintf(stderr, "[aligned prof] waves %llu lines %llu | ns per wave: setup %.0f total %.0f | ns per line: "
+            "load+lds %.0f  xs %.0f  compute %.0f  store %.0f\n", h[7], h[5], 10 * h[0] / nw, 10 * h[6] / nw,
+            10 * h[1] / nl, 10 * h[2] / nl, 10 * h[3] / nl, 10 * h[4] / nl);
+  }
+#endif
   return 0;
 }
 

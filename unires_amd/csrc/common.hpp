@@ -193,6 +193,14 @@ __device__ __forceinline__ float pull_sample(const float *__restrict__ src, cons
   return pull_finish(L);
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with its own
+// L2.  For kernels whose neighbouring blocks share halo lines, renumber so that every XCD
+// works on ONE contiguous chunk of the volume: halos are then re-read from that XCD's L2
+// instead of crossing the fabric (measured on k_ata_aligned: fetch 98 MB -> see DESIGN 4).
+__device__ __forceinline__ int xcd_chunked_block(int b, int nb) {
+  return (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+}
+
 // One term of the CG objective sum x (Ax - 2b): A(x).sub_(2*b).mul_(x), nitorch
 // optim.py cg() stop='max_gain' (rounded like the reference's three elementwise ops).
 __device__ __forceinline__ float obj_term(float ax, float b, float x) {

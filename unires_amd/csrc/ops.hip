@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(kBlock)
   const int tz = (d.z + kWave - 1) / kWave, ty = (d.y + 3) / 4;
   const long long ntiles = (long long)tz * ty * d.x;
   double prod = 0.0;
-  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  for (long long t = xcd_chunked_block(blockIdx.x, gridDim.x); t < ntiles; t += gridDim.x) {
     const int kc = (int)(t % tz);
     const long long t2 = t / tz;
     const int jq = (int)(t2 % ty);

@@ -37,6 +37,7 @@ struct SplatArgs {
   const float *objb;
   int row_sep;
   int dbg;
+  unsigned long long *prof;  // UNIRES_SPLAT_PROF builds only: per-phase tick sums
 };
 
 #ifndef UNIRES_STX
@@ -71,6 +72,15 @@ __device__ __forceinline__ float dpp_up1f(float v) {
 #define SPLAT_FENCE() asm volatile("" ::: "memory")
 #endif
 
+#ifdef UNIRES_SPLAT_PROF  // per-phase timer sums (debug builds only)
+#define SP_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define SP_ADD(slot, t0, t1) \
+  if (P.prof && lane == 0) atomicAdd(P.prof + (slot), (t1) - (t0))
+#else
+#define SP_T(var)
+#define SP_ADD(slot, t0, t1)
+#endif
+
 template <int AXIS>
 __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restrict__ done) {
   if (done && *done) return;
@@ -103,6 +113,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
     const int tzi = t % ntz, tyi = (t / ntz) % nty, txi = t / (ntz * nty);
     const int x0 = txi * TX, y0 = tyi * TY, z0 = tzi * TZ;
     const int ex = min(TX, dd.x - x0), ey = min(TY, dd.y - y0), ez = min(TZ, dd.z - z0);
+    SP_T(t_start);
     SPLAT_FENCE();
     for (int i = lane; i < N / 4; i += kWave)
       reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -155,10 +166,13 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
       }
       ztab[lane] = make_float4(__int_as_float(koff), w0, w1, 0.f);
     }
+    SP_T(t_setup);
+    SP_ADD(0, t_start, t_setup);
     // ---- phase A: rows (ui,uj) -> exact grid-z intervals -> <=32-long segments ----
     const int segs_per_row = (max(bz1 - bz0 + 1, 1) + 31) / 32;
     int nseg = 0;
     for (int rc0 = 0;;) {
+      SP_T(t_a0);
       if (rc0 < nrow_cand) {
         const int rc = rc0 + lane;
         int ui = 0, uj = 0, k0 = 0, k1 = -1;
@@ -206,9 +220,12 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
         if (max(abs(a.ui - b.ui), abs(a.uj - b.uj)) < P.row_sep) rows[p + npair].solo = 1;
       }
       SPLAT_FENCE();
+      SP_T(t_a1);
+      SP_ADD(1, t_a0, t_a1);
       // ---- phase B: half-wave per segment, lanes along grid z, kU pairs per batch ----
       constexpr int kU = 4;
       for (int p0 = 0; p0 < npair; p0 += kU) {
+        SP_T(t_b0);
         float val[kU];
         int ui[kU], uj[kU], uk[kU];
         bool act[kU], solo[kU];
@@ -246,6 +263,8 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
             val[u] = src[base];
           }
         }
+        SP_T(t_b1);
+        SP_ADD(2, t_b0, t_b1);
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           float gx, gy, gz;
@@ -316,11 +335,14 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
             }
           }
         }
+        SP_T(t_b2);
+        SP_ADD(3, t_b1, t_b2);
       }
       nseg = 0;
       if (last) break;
     }
     SPLAT_FENCE();
+    SP_T(t_e0);
     // ---- epilogue: q = [q +] acc + a0 p + c DtD p ; dot += p*q  (one row per half-wave) ----
     static_assert(TZ <= 32, "epilogue maps one row to a half-wave");
 #pragma unroll 4
@@ -338,6 +360,10 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
       if (P.accumulate) q += dst[idx];
       matvec_emit(dst, idx, q, pc, P.objb, P.partials != nullptr, dot);
     }
+    SP_T(t_e1);
+    SP_ADD(4, t_e0, t_e1);
+    SP_ADD(5, t_start, t_e1);
+    SP_ADD(6, 0ull, 1ull);
   }
   if (P.partials) {
     const double tot = wave_sum(dot);
@@ -397,6 +423,13 @@ int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const 
   P.row_sep = safe.row_sep;
   static const int dbg = getenv("UNIRES_DBG") ? atoi(getenv("UNIRES_DBG")) : 0;
   P.dbg = dbg;
+  P.prof = nullptr;
+#ifdef UNIRES_SPLAT_PROF
+  static unsigned long long *prof = nullptr;
+  if (!prof) (void)hipMalloc((void **)&prof, 8 * sizeof(unsigned long long));
+  (void)hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), st);
+  P.prof = prof;
+#endif
   const dim3 grid(splat_blocks(dd));
   if (axis == 0)
     hipLaunchKernelGGL(k_splat<0>, grid, dim3(kWave), 0, st, P, done);
@@ -406,6 +439,16 @@ int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const 
     hipLaunchKernelGGL(k_splat<2>, grid, dim3(kWave), 0, st, P, done);
   else
     hipLaunchKernelGGL(k_splat<-1>, grid, dim3(kWave), 0, st, P, done);
+#ifdef UNIRES_SPLAT_PROF
+  {
+    unsigned long long h[8];
+    (void)hipMemcpyAsync(h, prof, sizeof(h), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    const double nt = h[6] ? (double)h[6] : 1.0;
+    fprintf(stderr, "[splat prof] tiles %llu  ticks/tile: setup %.0f  phaseA %.0f  B-issue %.0f  B-rmw %.0f  "
+            "epilogue %.0f  total %.0f\n", h[6], h[0] / nt, h[1] / nt, h[2] / nt, h[3] / nt, h[4] / nt, h[5] / nt);
+  }
+#endif
   return 0;
 }
 
