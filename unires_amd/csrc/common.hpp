@@ -193,6 +193,22 @@ __device__ __forceinline__ float pull_sample(const float *__restrict__ src, cons
   return pull_finish(L);
 }
 
+// Buffer addressing (buffer_load/store_dword v, voffset, s[rsrc], soffset): a 128-bit resource
+// in SGPRs + a scalar byte offset + a 32-bit per-lane byte offset.  Wave-uniform row/tile bases
+// go into soffset and cost no VALU instruction (global_load needs a 64-bit VGPR address unless
+// the compiler can prove the scalar-base form, which it loses across loop back-edges).
+// Volumes must be < 4 GB; reads beyond num_records return 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, unsigned voff,
+                                          unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
 // Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with its own
 // L2.  For kernels whose neighbouring blocks share halo lines, renumber so that every XCD
 // works on ONE contiguous chunk of the volume: halos are then re-read from that XCD's L2

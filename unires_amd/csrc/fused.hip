@@ -76,9 +76,14 @@ __global__ void __launch_bounds__(kBlock)
       // all 8 corners of every lane's sample inside the volume (then the FOV mask is 1 too):
       // decided per wave-pass, so only the thin boundary shell takes the general path
       const bool inside = gx >= 0.f && gx < bx && gy >= 0.f && gy < by && gz >= 0.f && gz < bz;
+      // ... and passes whose samples are ALL outside the field of view are exact zeros
+      const bool outside = gx <= -tol || gx >= bx + tol || gy <= -tol || gy >= by + tol ||
+                           gz <= -tol || gz >= bz + tol;
       float v;
       if (__all(inside) && sd.z >= 2)
         v = pull_interior(src, ny, nz, nynz, gx, gy, gz);
+      else if (__all(outside))
+        v = 0.f;
       else
         v = pull_sample(src, sd, gx, gy, gz, tol);
       if (c < ptz) trow[c] = (row_in && p0z + c < gd.z) ? v : 0.f;
