@@ -58,7 +58,9 @@ enum unires_cg_stop {
 };
 
 enum unires_precond {
-  UNIRES_PRECOND_IDENTITY = 0 /* the reference's only live mode (_update.py:136-137) */
+  UNIRES_PRECOND_IDENTITY = 0, /* the reference's only live mode (_update.py:136-137) */
+  UNIRES_PRECOND_JACOBI = 1    /* _precond (_update.py:80-102), commented out at :136:
+                                  z = r / (tau AtA(1) + 2 rho lam^2 sum_d 1/vx_d^2)         */
 };
 
 const char *unires_last_error(void);
@@ -170,7 +172,15 @@ int unires_atx_assemble(unires_plan_t *plan, const float *const *x_ptrs, float *
 int unires_rhs_from_atx(unires_plan_t *plan, const float *atx, const float *w_c,
                         const float *z_c, float rho, float lam, float *b, void *stream);
 
-/* nitorch cg(A=lhs, b, x, precond=identity, max_iter, tolerance, stop,
+/* Builds the diagonal of _precond (_update.py:80-102) for (rho, lam) into plan-owned memory
+ * (allocated on the first call): M = tau AtA(1) + 2 rho lam^2 sum_d 1/vx_d^2.  Like the
+ * reference it supports one repeat per channel only.  If m_out != NULL the diagonal is also
+ * copied there (device, dim_y floats).  Needed before unires_cg_solve(precond_mode = JACOBI)
+ * with the same rho and lam. */
+int unires_precond_build(unires_plan_t *plan, int32_t precond_mode, float rho, float lam,
+                         float *m_out, void *stream);
+
+/* nitorch cg(A=lhs, b, x, precond, max_iter, tolerance, stop,
  * inplace=True, sum_dtype=float64)  (_update.py:142-148): x is updated in place.
  * tol == 0 runs exactly max_iter iterations with no objective evaluation.
  * If iters_out != NULL the call synchronises the stream and returns the realised

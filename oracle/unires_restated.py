@@ -213,18 +213,34 @@ def y_rhs(xc, yc, zc, wc, rho, vx_y, method, do_proj):
     return tmp
 
 
+def precond(xc, yc, rho, method):
+    """Jacobi preconditioner x -> x / M  (unires/_update.py:80-102; commented out at :136):
+    M = tau * AtA(1) + 2 rho lam^2 sum(1 / vx^2), one repeat per contrast only."""
+    if len(xc) != 1:
+        raise ValueError('CG pre-conditioning only supports one repeat per contrast.')   # :84-85
+    lam = yc.lam
+    vx = voxel_size(yc.mat).float()                                                    # :90
+    M = xc[0].tau * proj_apply('AtA', torch.ones(tuple(yc.dim), dtype=torch.float32)[None, None],
+                               xc[0].po, method=method)                                # :92-95
+    M += 2 * rho * lam ** 2 * vx.square().reciprocal().sum()                            # :97
+    M = M[0, 0]
+    return lambda v: v / M                                                              # :100
+
+
 def update_y(x, y, z, w, rho, method, do_proj, cgs_max_iter=20, cgs_tol=1e-3,
-             return_info=False):
+             return_info=False, jacobi=False):
     """In-place CG update of every y[c].dat; identity preconditioner (:136-137),
-    stop='max_gain' (:145)."""
+    stop='max_gain' (:145).  ``jacobi`` enables the line the reference keeps commented
+    out (:136)."""
     vx_y = voxel_size(y[0].mat).float()                                   # :111
     info = []
     for c in range(len(x)):
         tmp = y_rhs(x[c], y[c], z[c], w[c], rho, vx_y, method, do_proj)
         lhs = lambda dat, c=c: proj('AtA', dat, x[c], y[c], method=method, do=do_proj,
                                     rho=rho, vx_y=vx_y)                   # :140-141
+        pre = precond(x[c], y[c], rho, method) if jacobi else (lambda r: r)   # :136-137
         _, n_it, obj = cg(A=lhs, b=tmp, x=y[c].dat, max_iter=cgs_max_iter, stop='max_gain',
-                          inplace=True, precond=lambda r: r, tolerance=cgs_tol,
+                          inplace=True, precond=pre, tolerance=cgs_tol,
                           return_info=True)                               # :142-148
         info.append((n_it, obj))
     return (y, info) if return_info else y

@@ -145,11 +145,12 @@ def oracle_structs(prob):
     return x, y
 
 
-def run_oracle_update_y(prob, max_iter=20, tol=1e-3):
+def run_oracle_update_y(prob, max_iter=20, tol=1e-3, jacobi=False):
     x, y = oracle_structs(prob)
     rho = torch.tensor(prob['rho'])
     y, info = O.update_y(x, y, prob['z'].clone(), prob['w'].clone(), rho, prob['method'],
-                         prob['do_proj'], cgs_max_iter=max_iter, cgs_tol=tol, return_info=True)
+                         prob['do_proj'], cgs_max_iter=max_iter, cgs_tol=tol, return_info=True,
+                         jacobi=jacobi)
     return [yc.dat for yc in y], info
 
 
@@ -175,10 +176,11 @@ def gpu_structs(prob, device):
     return x, y, sett
 
 
-def run_gpu_update_y(prob, device='cuda:0', max_iter=20, tol=1e-3, stop='max_gain'):
+def run_gpu_update_y(prob, device='cuda:0', max_iter=20, tol=1e-3, stop='max_gain', precond='none'):
     import unires_amd as U
     x, y, sett = gpu_structs(prob, device)
     sett.cgs_max_iter, sett.cgs_tol, sett.cgs_stop = max_iter, tol, stop
+    sett.cgs_precond = precond
     z, w = prob['z'].to(device), prob['w'].to(device)
     tmp = torch.zeros_like(y[0].dat)
     info = []

@@ -118,6 +118,54 @@ def test_update_y_matches_oracle(dev, case, tol):
             assert torch.allclose(o_gpu, o_ref, rtol=1e-5, atol=0)
 
 
+@pytest.mark.parametrize('case', ['sr_z_1ch', 'sr_3ch_axes', 'sr_aligned', 'dn_2ch', 'id_1ch'])
+def test_jacobi_preconditioner_matches_oracle(dev, case):
+    """_precond (unires/_update.py:80-102, commented out at :136): diagonal and PCG iterates."""
+    import unires_amd as U
+    prob = make_problem(seed=21, **CASES[case])
+    xo, yo = oracle_structs(prob)
+    xg, yg, sett = gpu_structs(prob, dev)
+    rho = torch.tensor(prob['rho'])
+    if prob['do_proj']:  # the reference's _precond always applies AtA (no `do` switch)
+        for c in range(len(xo)):
+            pre_o = O.precond(xo[c], yo[c], rho, prob['method'])
+            pre_g = U._precond(xg[c], yg[c], float(rho), sett)
+            v = torch.rand(prob['dim_y']) + 0.5
+            assert rel_err(pre_g(v.to(dev)).cpu(), pre_o(v)) < 2e-5
+    for tol in (0.0, 1e-3):
+        if not prob['do_proj']:
+            break
+        y_ref, info_ref = run_oracle_update_y(prob, max_iter=12, tol=tol, jacobi=True)
+        y_gpu, info_gpu = run_gpu_update_y(prob, dev, max_iter=12, tol=tol, precond='jacobi')
+        for c in range(len(y_ref)):
+            assert info_gpu[c][0] == info_ref[c][0], 'realised PCG iterations differ'
+            assert rel_err(y_gpu[c].cpu(), y_ref[c]) < GATE
+
+
+def test_jacobi_identity_regime_and_errors(dev):
+    import unires_amd as U
+    from unires_amd._project import _channel_plan
+    prob = make_problem(seed=22, **CASES['id_1ch'])
+    xg, yg, sett = gpu_structs(prob, dev)
+    plan = _channel_plan(xg[0], yg[0], sett.method, sett.do_proj)
+    M = torch.empty(prob['dim_y'], device=dev)
+    rho, lam = 0.7, float(yg[0].lam)
+    plan.precond_build(rho, lam, out=M)
+    vx = N.voxel_size(prob['mat_y']).float()
+    want = float(xg[0][0].tau) + 2 * rho * lam ** 2 * float(vx.square().reciprocal().sum())
+    assert torch.allclose(M.cpu(), torch.full(prob['dim_y'], want), rtol=1e-6)
+    b = torch.rand(prob['dim_y'], device=dev)
+    x = torch.zeros_like(b)
+    with pytest.raises(ValueError, match="unires_precond_build"):  # built for another rho
+        plan.cg(b, x, rho + 0.1, lam, precond='jacobi')
+    with pytest.raises(ValueError):
+        plan.cg(b, x, rho, lam, precond='fft')
+    prob2 = make_problem(seed=23, **CASES['dn_2rep'])
+    x2, y2, sett2 = gpu_structs(prob2, dev)
+    with pytest.raises(ValueError, match='one repeat per contrast'):
+        U._precond(x2[0], y2[0], 1.0, sett2)
+
+
 def test_recurred_objective_stops_at_the_same_iteration(dev):
     prob = make_problem(seed=14, **CASES['sr_3ch_axes'])
     _, info_a = run_gpu_update_y(prob, dev, tol=1e-3, stop='max_gain')

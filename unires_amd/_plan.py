@@ -163,9 +163,25 @@ class ChannelPlan:
                                            float(rho), float(lam), _ptr(out), _stream()))
         return out
 
-    def cg(self, b, x, rho, lam, max_iter=20, tolerance=1e-3, stop='max_gain', sync=True):
+    def precond_build(self, rho, lam, mode='jacobi', out=None):
+        """Diagonal of unires/_update.py:80-102 for this channel, kept in the plan for
+        ``cg(precond='jacobi')``; ``out`` (dim_y tensor) optionally receives a copy."""
+        if mode not in _lib.PRECOND:
+            raise ValueError('Undefined preconditioner')
+        if out is not None:
+            out = self._y(out, 'out')
+        check(self.lib.unires_precond_build(self._h, _lib.PRECOND[mode], float(rho), float(lam),
+                                            _ptr(out) if out is not None else None, _stream()))
+        return out
+
+    def cg(self, b, x, rho, lam, max_iter=20, tolerance=1e-3, stop='max_gain', sync=True,
+           precond='none'):
         """In-place CG on x (must be contiguous (X,Y,Z)).  Returns (iters, obj) when
-        ``sync`` (one stream sync), else None with everything left enqueued."""
+        ``sync`` (one stream sync), else None with everything left enqueued.
+        ``precond='jacobi'`` needs :meth:`precond_build` with the same rho, lam first."""
+        if precond not in _lib.PRECOND:
+            raise ValueError('Undefined preconditioner')
+        pm = _lib.PRECOND[precond]
         b = self._y(b, 'b')
         if not x.is_contiguous():
             raise ValueError('unires_amd: cg updates x in place and needs it contiguous')
@@ -176,11 +192,11 @@ class ChannelPlan:
             it = C.c_int32(0)
             obj = (C.c_double * (max_iter + 1))()
             check(self.lib.unires_cg_solve(self._h, float(rho), float(lam), _ptr(b), _ptr(x),
-                                           int(max_iter), float(tolerance), mode, 0, C.byref(it),
+                                           int(max_iter), float(tolerance), mode, pm, C.byref(it),
                                            obj, _stream()))
             trace = list(obj)[:it.value + 1] if tolerance else None
             return it.value, trace
         check(self.lib.unires_cg_solve(self._h, float(rho), float(lam), _ptr(b), _ptr(x),
-                                       int(max_iter), float(tolerance), mode, 0, None, None,
+                                       int(max_iter), float(tolerance), mode, pm, None, None,
                                        _stream()))
         return None

@@ -32,6 +32,28 @@ def _step_size(x, y, sett, verbose=False):
     return sett.rho_scl * torch.sqrt(torch.mean(all_tau)) / torch.mean(all_lam)
 
 
+class _Precond:
+    """Callable x -> x / M like the lambda unires/_update.py:100 returns; carries the plan
+    that holds the device copy of M so cg() can run the preconditioned iteration on device."""
+
+    def __init__(self, plan, M, mode):
+        self.plan, self.M, self.mode = plan, M, mode
+
+    def __call__(self, v):
+        return v if self.M is None else v / self.M
+
+
+def _precond(x, y, rho, sett):
+    """Compute CG preconditioner (unires/_update.py:80-102): Jacobi,
+    M = tau AtA(1) + 2 rho lam^2 sum(1/vx^2) for one channel (x = x[c], y = y[c])."""
+    if len(x) != 1:
+        raise ValueError('CG pre-conditioning only supports one repeat per contrast.')
+    plan = _channel_plan(x, y, sett.method, sett.do_proj, voxel_size(y.mat).float())
+    M = torch.empty(tuple(y.dim), dtype=torch.float32, device=y.dat.device)
+    plan.precond_build(float(rho), float(y.lam), mode='jacobi', out=M)
+    return _Precond(plan, M, 'jacobi')
+
+
 def _update_y(x, y, z, w, rho, tmp, sett, info=None):
     """UPDATE: y  (unires/_update.py:118-152).  Per channel: assemble
     b = sum_n tau_n At x_n - lam Dt(w - rho z) and solve
@@ -48,13 +70,16 @@ def _update_y(x, y, z, w, rho, tmp, sett, info=None):
     sync = info is not None
     C = len(x)
     concurrent = C > 1 and not sync and getattr(sett, 'channel_streams', True)
+    pre = getattr(sett, 'cgs_precond', 'none')
     if not concurrent:
         for c in range(C):
             plan = _channel_plan(x[c], y[c], sett.method, sett.do_proj, vx_y)
             lam = float(y[c].lam)
             plan.rhs([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=tmp)
+            if pre == 'jacobi':
+                plan.precond_build(rho, lam, mode='jacobi')
             res = plan.cg(tmp, y[c].dat, rho, lam, max_iter=sett.cgs_max_iter,
-                          tolerance=sett.cgs_tol, stop=sett.cgs_stop, sync=sync)
+                          tolerance=sett.cgs_tol, stop=sett.cgs_stop, sync=sync, precond=pre)
             if sync:
                 info.append(res)
         return y
@@ -72,8 +97,10 @@ def _update_y(x, y, z, w, rho, tmp, sett, info=None):
                 plan.rhs_cached([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=b)
             else:
                 plan.rhs([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=b)
+            if pre == 'jacobi':
+                plan.precond_build(rho, lam, mode='jacobi')
             plan.cg(b, y[c].dat, rho, lam, max_iter=sett.cgs_max_iter, tolerance=sett.cgs_tol,
-                    stop=sett.cgs_stop, sync=False)
+                    stop=sett.cgs_stop, sync=False, precond=pre)
     for c in range(C):
         main.wait_stream(streams[c])
     return y

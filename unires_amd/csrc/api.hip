@@ -267,6 +267,9 @@ struct unires_plan {
   double *part0 = nullptr, *part1 = nullptr;                       // kMaxPartials each
   CgState *state = nullptr;
   size_t cap_g = 0, cap_x = 0;
+  float *precM = nullptr;  // Jacobi diagonal (own allocation, made by unires_precond_build)
+  float prec_rho = 0.f, prec_lam = 0.f;
+  bool prec_ready = false;
 };
 
 static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat &out) {
@@ -407,6 +410,7 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
 extern "C" int unires_plan_destroy(unires_plan_t *plan) {
   if (!plan) return UNIRES_OK;
   if (plan->ws) (void)hipFree(plan->ws);
+  if (plan->precM) (void)hipFree(plan->precM);
   for (Repeat &R : plan->reps) free_ztabs(R);
   delete plan;
   return UNIRES_OK;
@@ -605,6 +609,39 @@ extern "C" int unires_ata_matvec(unires_plan_t *plan, float rho, float lam, cons
   return UNIRES_OK;
 }
 
+extern "C" int unires_precond_build(unires_plan_t *plan, int32_t precond_mode, float rho,
+                                    float lam, float *m_out, void *stream) {
+  if (!plan) return fail(UNIRES_ERR_NULL, "null plan");
+  if (precond_mode == UNIRES_PRECOND_IDENTITY) {
+    plan->prec_ready = false;
+    return UNIRES_OK;
+  }
+  if (precond_mode != UNIRES_PRECOND_JACOBI)
+    return fail(UNIRES_ERR_UNSUPPORTED, "preconditioner modes: identity (0), Jacobi (1)");
+  if (plan->reps.size() != 1)  // the reference raises ValueError here (_update.py:84-85)
+    return fail(UNIRES_ERR_ARG, "CG pre-conditioning only supports one repeat per contrast.");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t ny = plan->dy.numel();
+  if (!plan->precM) HIP_TRY(hipMalloc((void **)&plan->precM, ny * sizeof(float)));
+  const Repeat &R = plan->reps[0];
+  float c = 0.f;  // 2 rho lam^2 sum_d 1/vx_d^2, float32 like the reference's 0-d tensors
+  for (int d = 0; d < 3; ++d) c += 1.f / (plan->vx[d] * plan->vx[d]);
+  c = 2.f * rho * (lam * lam) * c;
+  if (plan->regime == UNIRES_REGIME_IDENTITY) {
+    launch_fill(R.tau + c, plan->precM, ny, st);
+  } else {
+    launch_fill(1.f, plan->ax, ny, st);
+    const PushSrc src = ata_forward(plan, R, plan->ax, nullptr, st);
+    push_any(plan, src, R, 1.f, PushEpilogue(), plan->precM, nullptr, st);
+    launch_scale_shift(R.tau, c, plan->precM, ny, st);
+  }
+  if (m_out)
+    HIP_TRY(hipMemcpyAsync(m_out, plan->precM, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
+  CHECK_LAUNCH();
+  plan->prec_rho = rho, plan->prec_lam = lam, plan->prec_ready = true;
+  return UNIRES_OK;
+}
+
 extern "C" int unires_rhs_assemble(unires_plan_t *plan, const float *const *x_ptrs,
                                    const float *w_c, const float *z_c, float rho, float lam,
                                    float *b, void *stream) {
@@ -656,8 +693,12 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
   if (b == x) return fail(UNIRES_ERR_ARG, "b and x must not alias");
   if (max_iter < 0 || max_iter > kMaxCgIter) return fail(UNIRES_ERR_ARG, "max_iter out of range");
   if (stop_mode < 0 || stop_mode > 2) return fail(UNIRES_ERR_ARG, "bad stop mode");
-  if (precond_mode != UNIRES_PRECOND_IDENTITY)
-    return fail(UNIRES_ERR_UNSUPPORTED, "only the identity preconditioner is built");
+  if (precond_mode != UNIRES_PRECOND_IDENTITY && precond_mode != UNIRES_PRECOND_JACOBI)
+    return fail(UNIRES_ERR_UNSUPPORTED, "preconditioner modes: identity (0), Jacobi (1)");
+  if (precond_mode == UNIRES_PRECOND_JACOBI &&
+      (!plan->prec_ready || plan->prec_rho != rho || plan->prec_lam != lam))
+    return fail(UNIRES_ERR_ARG, "call unires_precond_build with this rho and lam first");
+  const float *M = precond_mode == UNIRES_PRECOND_JACOBI ? plan->precM : nullptr;
   if (!(tol >= 0.0)) return fail(UNIRES_ERR_ARG, "tolerance must be >= 0");
   hipStream_t st = (hipStream_t)stream;
   unires_plan *pl = plan;
@@ -672,19 +713,20 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
   matvec(pl, rho, lam, x, pl->ap, nullptr, nullptr, st);
   const bool want_obj0 = check && stop_mode != UNIRES_STOP_RESIDUAL;
   launch_residual_init(b, pl->ap, x, pl->r, pl->p, ny, pl->part0, want_obj0 ? pl->part1 : nullptr,
-                       st);
+                       M, st);
   launch_sc_init(S, pl->part0, pl->part1, gv, stop_mode, check ? 1 : 0, st);
 
   for (int k = 1; k <= max_iter; ++k) {
     const int g = matvec(pl, rho, lam, pl->p, pl->ap, pl->part0, done, st);
     launch_sc_alpha(S, pl->part0, g, st);
     const bool recur = check && stop_mode == UNIRES_STOP_MAXGAIN_RECURRED;
-    launch_update_xr(S, pl->p, pl->ap, x, pl->r, b, ny, pl->part0, recur ? pl->part1 : nullptr, st);
+    launch_update_xr(S, pl->p, pl->ap, x, pl->r, b, ny, pl->part0, recur ? pl->part1 : nullptr, M,
+                     st);
     int obj_kind = 0;
     if (check && stop_mode == UNIRES_STOP_RESIDUAL) obj_kind = 1;
     if (recur) obj_kind = 2;
     launch_sc_beta(S, pl->part0, pl->part1, gv, k, obj_kind, tol, st);
-    launch_update_p(S, pl->r, pl->p, ny, st);
+    launch_update_p(S, pl->r, pl->p, ny, M, st);
     if (check && stop_mode == UNIRES_STOP_MAXGAIN) {
       // objective sum x (Ax - 2b) folded into the matvec epilogue: A(x) is never stored
       const int go = matvec(pl, rho, lam, x, pl->ax, pl->part1, done, st, b);

@@ -32,11 +32,23 @@ __device__ __forceinline__ void st4(float *p, size_t i, float4 v) {
 
 // obj term of nitorch cg for stop != 'e': (A(x) - 2b) * x, rounded like
 
-// r = b - A(x); p = r; partial[0..G) = sum r*r; partial2 = sum (Ax-2b)*x (optional)
+// z = precond(r): identity (M == nullptr) or Jacobi r / M (unires/_update.py:80-102: x / M)
+__device__ __forceinline__ float4 zval4(float4 r, const float *__restrict__ M, size_t i) {
+  if (!M) return r;
+  const float4 m = ld4(M, i);
+  return make_float4(__fdiv_rn(r.x, m.x), __fdiv_rn(r.y, m.y), __fdiv_rn(r.z, m.z),
+                     __fdiv_rn(r.w, m.w));
+}
+__device__ __forceinline__ float zval1(float r, const float *__restrict__ M, size_t i) {
+  return M ? __fdiv_rn(r, M[i]) : r;
+}
+
+// r = b - A(x); z = precond(r); p = z; partial[0..G) = sum r*z; partial2 = sum (Ax-2b)*x (optional)
 __global__ void __launch_bounds__(kBlock)
     k_residual_init(const float *__restrict__ b, const float *__restrict__ ax,
                     const float *__restrict__ x, float *__restrict__ r, float *__restrict__ p,
-                    size_t n, double *__restrict__ part_rr, double *__restrict__ part_obj) {
+                    size_t n, double *__restrict__ part_rr, double *__restrict__ part_obj,
+                    const float *__restrict__ M) {
   GRID_STRIDE_VEC4(n);
   double rr = 0.0, ob = 0.0;
   for (size_t i = tid0; i < n4; i += stride) {
@@ -47,9 +59,10 @@ __global__ void __launch_bounds__(kBlock)
     vr.z = __fsub_rn(vb.z, va.z);
     vr.w = __fsub_rn(vb.w, va.w);
     st4(r, i, vr);
-    st4(p, i, vr);
-    rr += (double)__fmul_rn(vr.x, vr.x) + (double)__fmul_rn(vr.y, vr.y) +
-          (double)__fmul_rn(vr.z, vr.z) + (double)__fmul_rn(vr.w, vr.w);
+    const float4 vz = zval4(vr, M, i);
+    st4(p, i, vz);
+    rr += (double)__fmul_rn(vr.x, vz.x) + (double)__fmul_rn(vr.y, vz.y) +
+          (double)__fmul_rn(vr.z, vz.z) + (double)__fmul_rn(vr.w, vz.w);
     if (part_obj) {
       const float4 vx = ld4(x, i);
       ob += (double)obj_term(va.x, vb.x, vx.x) + (double)obj_term(va.y, vb.y, vx.y) +
@@ -59,8 +72,9 @@ __global__ void __launch_bounds__(kBlock)
   for (size_t i = n4 * 4 + tid0; i < n; i += stride) {  // tail
     const float vr = __fsub_rn(b[i], ax[i]);
     r[i] = vr;
-    p[i] = vr;
-    rr += (double)__fmul_rn(vr, vr);
+    const float vz = zval1(vr, M, i);
+    p[i] = vz;
+    rr += (double)__fmul_rn(vr, vz);
     if (part_obj) ob += (double)obj_term(ax[i], b[i], x[i]);
   }
   const double t = block_sum(rr);
@@ -94,7 +108,7 @@ __global__ void __launch_bounds__(kBlock)
     k_update_xr(const CgState *__restrict__ st, const float *__restrict__ p,
                 const float *__restrict__ ap, float *__restrict__ x, float *__restrict__ r,
                 const float *__restrict__ b, size_t n, double *__restrict__ part_rr,
-                double *__restrict__ part_obj) {
+                double *__restrict__ part_obj, const float *__restrict__ M) {
   if (st->done) return;
   const float alpha = (float)st->alpha;
   GRID_STRIDE_VEC4(n);
@@ -112,8 +126,9 @@ __global__ void __launch_bounds__(kBlock)
     vr.w = __fsub_rn(vr.w, __fmul_rn(alpha, va.w));
     st4(x, i, vx);
     st4(r, i, vr);
-    rr += (double)__fmul_rn(vr.x, vr.x) + (double)__fmul_rn(vr.y, vr.y) +
-          (double)__fmul_rn(vr.z, vr.z) + (double)__fmul_rn(vr.w, vr.w);
+    const float4 vz = zval4(vr, M, i);
+    rr += (double)__fmul_rn(vr.x, vz.x) + (double)__fmul_rn(vr.y, vz.y) +
+          (double)__fmul_rn(vr.z, vz.z) + (double)__fmul_rn(vr.w, vz.w);
     if (part_obj) {
       const float4 vb = ld4(b, i);
       ob += (double)__fmul_rn(vx.x, __fadd_rn(vb.x, vr.x)) +
@@ -127,7 +142,7 @@ __global__ void __launch_bounds__(kBlock)
     const float vr = __fsub_rn(r[i], __fmul_rn(alpha, ap[i]));
     x[i] = vx;
     r[i] = vr;
-    rr += (double)__fmul_rn(vr, vr);
+    rr += (double)__fmul_rn(vr, zval1(vr, M, i));
     if (part_obj) ob += (double)__fmul_rn(vx, __fadd_rn(b[i], vr));
   }
   const double t = block_sum(rr);
@@ -141,12 +156,12 @@ __global__ void __launch_bounds__(kBlock)
 // p = beta*p + r   (p *= beta; p += z with z = r)
 __global__ void __launch_bounds__(kBlock)
     k_update_p(const CgState *__restrict__ st, const float *__restrict__ r, float *__restrict__ p,
-               size_t n) {
+               size_t n, const float *__restrict__ M) {
   if (st->done) return;
   const float beta = (float)st->beta;
   GRID_STRIDE_VEC4(n);
   for (size_t i = tid0; i < n4; i += stride) {
-    const float4 vr = ld4(r, i);
+    const float4 vr = zval4(ld4(r, i), M, i);
     float4 vp = ld4(p, i);
     vp.x = __fadd_rn(__fmul_rn(beta, vp.x), vr.x);
     vp.y = __fadd_rn(__fmul_rn(beta, vp.y), vr.y);
@@ -154,7 +169,8 @@ __global__ void __launch_bounds__(kBlock)
     vp.w = __fadd_rn(__fmul_rn(beta, vp.w), vr.w);
     st4(p, i, vp);
   }
-  for (size_t i = n4 * 4 + tid0; i < n; i += stride) p[i] = __fadd_rn(__fmul_rn(beta, p[i]), r[i]);
+  for (size_t i = n4 * 4 + tid0; i < n; i += stride)
+    p[i] = __fadd_rn(__fmul_rn(beta, p[i]), zval1(r[i], M, i));
 }
 
 // y = a*x + y (generic axpy; used by the identity regime's RHS)
@@ -245,9 +261,10 @@ __global__ void __launch_bounds__(kBlock) k_sum_to(const double *part, int g, do
 int vec_num_blocks(size_t n) { return vec_blocks(n); }
 
 void launch_residual_init(const float *b, const float *ax, const float *x, float *r, float *p,
-                          size_t n, double *part_rr, double *part_obj, hipStream_t st) {
+                          size_t n, double *part_rr, double *part_obj, const float *M,
+                          hipStream_t st) {
   hipLaunchKernelGGL(k_residual_init, dim3(vec_blocks(n)), dim3(kBlock), 0, st, b, ax, x, r, p, n,
-                     part_rr, part_obj);
+                     part_rr, part_obj, M);
 }
 void launch_dot(const float *a, const float *b, size_t n, double *part, const int *done,
                 hipStream_t st) {
@@ -255,12 +272,31 @@ void launch_dot(const float *a, const float *b, size_t n, double *part, const in
 }
 void launch_update_xr(const CgState *s, const float *p, const float *ap, float *x, float *r,
                       const float *b, size_t n, double *part_rr, double *part_obj,
-                      hipStream_t st) {
+                      const float *M, hipStream_t st) {
   hipLaunchKernelGGL(k_update_xr, dim3(vec_blocks(n)), dim3(kBlock), 0, st, s, p, ap, x, r, b, n,
-                     part_rr, part_obj);
+                     part_rr, part_obj, M);
 }
-void launch_update_p(const CgState *s, const float *r, float *p, size_t n, hipStream_t st) {
-  hipLaunchKernelGGL(k_update_p, dim3(vec_blocks(n)), dim3(kBlock), 0, st, s, r, p, n);
+void launch_update_p(const CgState *s, const float *r, float *p, size_t n, const float *M,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(k_update_p, dim3(vec_blocks(n)), dim3(kBlock), 0, st, s, r, p, n, M);
+}
+// y = a*y + c  (preconditioner diagonal: tau * AtA(1) + const)
+__global__ void __launch_bounds__(kBlock) k_scale_shift(float a, float c, float *__restrict__ y, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = __fadd_rn(__fmul_rn(a, y[i]), c);
+}
+void launch_scale_shift(float a, float c, float *y, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_scale_shift, dim3(vec_blocks(n) * 4 > 4096 ? 4096 : vec_blocks(n) * 4),
+                     dim3(kBlock), 0, st, a, c, y, n);
+}
+__global__ void __launch_bounds__(kBlock) k_fill(float v, float *__restrict__ y, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = v;
+}
+void launch_fill(float v, float *y, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_fill, dim3(vec_blocks(n) * 4 > 4096 ? 4096 : vec_blocks(n) * 4), dim3(kBlock), 0,
+                     st, v, y, n);
 }
 void launch_axpy(float a, const float *x, float *y, size_t n, hipStream_t st) {
   hipLaunchKernelGGL(k_axpy, dim3(vec_blocks(n) * 4 > 4096 ? 4096 : vec_blocks(n) * 4),

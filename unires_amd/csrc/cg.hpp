@@ -14,12 +14,18 @@ struct CgState {  // lives in device memory, owned by the plan
 
 int vec_num_blocks(size_t n);  // grid (= number of partials) of the vector kernels
 void launch_residual_init(const float *b, const float *ax, const float *x, float *r, float *p,
-                          size_t n, double *part_rr, double *part_obj, hipStream_t st);
+                          size_t n, double *part_rr, double *part_obj, const float *M,
+                          hipStream_t st);
 void launch_dot(const float *a, const float *b, size_t n, double *part, const int *done,
                 hipStream_t st);
 void launch_update_xr(const CgState *s, const float *p, const float *ap, float *x, float *r,
-                      const float *b, size_t n, double *part_rr, double *part_obj, hipStream_t st);
-void launch_update_p(const CgState *s, const float *r, float *p, size_t n, hipStream_t st);
+                      const float *b, size_t n, double *part_rr, double *part_obj, const float *M,
+                      hipStream_t st);
+void launch_update_p(const CgState *s, const float *r, float *p, size_t n, const float *M,
+                     hipStream_t st);
+// M = nullptr: identity preconditioner; else z = r / M (Jacobi)
+void launch_scale_shift(float a, float c, float *y, size_t n, hipStream_t st);
+void launch_fill(float v, float *y, size_t n, hipStream_t st);
 void launch_axpy(float a, const float *x, float *y, size_t n, hipStream_t st);
 void launch_sc_init(CgState *s, const double *part_rr, const double *part_obj, int g, int mode,
                     int check, hipStream_t st);

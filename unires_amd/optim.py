@@ -21,9 +21,15 @@ def cg(A, b, x=None, precond=None, max_iter=None, tolerance=1e-5, verbose=False,
     the whole iteration - matvec, float64 dots, alpha/beta, objective and the
     ``|gain| < tolerance`` test - is enqueued without host round trips.
     """
+    mode = 'none'
     if precond is not None:
-        raise NotImplementedError('the reference runs with the identity preconditioner '
-                                  '(unires/_update.py:136-137)')
+        # only the objects made by unires_amd._update._precond are device-resident
+        mode = getattr(precond, 'mode', None)
+        if mode not in ('none', 'jacobi'):
+            raise NotImplementedError('precond must come from unires_amd._update._precond '
+                                      '(identity or Jacobi, unires/_update.py:80-102,136-137)')
+        if mode == 'jacobi' and precond.plan is not A:
+            raise ValueError('preconditioner was built for another channel plan')
     if sum_dtype != torch.float64:
         raise NotImplementedError('dot products accumulate in float64')
     if max_iter is None:
@@ -32,5 +38,6 @@ def cg(A, b, x=None, precond=None, max_iter=None, tolerance=1e-5, verbose=False,
         x = torch.zeros_like(b)
     elif not inplace:
         x = x.clone()
-    A.cg(b, x, rho, lam, max_iter=max_iter, tolerance=tolerance, stop=stop, sync=True)
+    A.cg(b, x, rho, lam, max_iter=max_iter, tolerance=tolerance, stop=stop, sync=True,
+         precond=mode)
     return x
