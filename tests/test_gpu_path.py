@@ -333,3 +333,42 @@ def test_push_kernel_variants_match_oracle(dev, variant):
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and 'variant OK' in out.stdout, out.stderr[-2000:]
+
+
+def test_aligned_kernel_agrees_with_general_kernels_at_256(dev, tmp_path):
+    """Full-size cross-check of two independent implementations: config 3 with rigid = I runs
+    the one-kernel aligned matvec; a fresh process with UNIRES_NO_ALIGNED=1 runs the general
+    pull_conv + splat kernels on the same input.  Both also run 5 CG iterations."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "import unires_amd as U\n"
+            "from unires_amd._project import _channel_plan\n"
+            "dev = torch.device('cuda:0'); dim_y = (256, 256, 256)\n"
+            "eye = torch.eye(4, dtype=torch.float64)\n"
+            "D = torch.diag(torch.tensor([1, 1, 6, 1.], dtype=torch.float64))\n"
+            "po = U._proj_info(dim_y, eye, (256, 256, 42), eye @ D, device=dev)\n"
+            "g = torch.Generator().manual_seed(3)\n"
+            "x = [U._input(torch.rand((256, 256, 42), generator=g).to(dev), eye @ D, 1.8e-4, po)]\n"
+            "x[0].po.scl = 0.1\n"
+            "y = U._output(torch.zeros(dim_y, device=dev), eye, 0.006)\n"
+            "plan = _channel_plan(x, y, 'super-resolution', True)\n"
+            "p = torch.rand(dim_y, generator=g).to(dev)\n"
+            "q = plan.matvec(p, 0.9, 0.006)\n"
+            "b = plan.rhs([x[0].dat], torch.zeros((3,) + dim_y, device=dev),\n"
+            "             torch.zeros((3,) + dim_y, device=dev), 0.9, 0.006)\n"
+            "n_it, obj = plan.cg(b, y.dat, 0.9, 0.006, max_iter=5, tolerance=1e-9)\n"
+            "torch.save({'q': q.cpu(), 'y': y.dat.cpu(), 'obj': obj}, sys.argv[1])\n") % root
+    res = {}
+    for name, extra in (('aligned', {}), ('general', {'UNIRES_NO_ALIGNED': '1'})):
+        path = str(tmp_path / (name + '.pt'))
+        out = subprocess.run([sys.executable, '-c', code, path], env=dict(os.environ, **extra),
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[name] = torch.load(path)
+    assert rel_err(res['aligned']['q'], res['general']['q']) < 2e-6
+    assert rel_err(res['aligned']['y'], res['general']['y']) < 2e-5
+    assert torch.allclose(torch.tensor(res['aligned']['obj']), torch.tensor(res['general']['obj']),
+                          rtol=1e-6)
