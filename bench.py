@@ -128,21 +128,33 @@ def pmc_traffic(workload):
         return None
 
 
-def time_matvec(x, y, rho, sett, reps=50):
-    """Average duration of one channel's CG matvec, HIP events on the launch stream."""
+def time_matvec(x, y, rho, sett, reps=16, ring=2):
+    """Average duration of one CG matvec (mean over the subject's channels, whose rigid
+    transforms - and therefore kernel costs - differ), HIP events on the launch stream.
+    The launches cycle through channels and ``ring`` distinct (p, q) pairs per channel
+    (12 x 67 MB at 256^3 x 3, more than the 256 MB Infinity Cache), as inside CG where p was
+    just rewritten and other vectors were streamed in between: timing one p/q pair back to
+    back reads p from the cache and comes out faster than the same kernel does in the solver
+    (aligned kernel: 35.7 us hot, 42 us cold)."""
     from unires_amd._project import _channel_plan
-    plan = _channel_plan(x[0], y[0], sett.method, sett.do_proj)
-    p = torch.rand(y[0].dim, device=y[0].dat.device)
-    q = torch.empty_like(p)
-    for _ in range(5):
-        plan.matvec(p, rho, y[0].lam, out=q)
+    dev = y[0].dat.device
+    C = len(x)
+    plans = [_channel_plan(x[c], y[c], sett.method, sett.do_proj) for c in range(C)]
+    ps = [[torch.rand(y[c].dim, device=dev) for _ in range(ring)] for c in range(C)]
+    qs = [[torch.empty_like(ps[c][0]) for _ in range(ring)] for c in range(C)]
+
+    def sweep(n):
+        for i in range(n):
+            for c in range(C):
+                plans[c].matvec(ps[c][i % ring], rho, y[c].lam, out=qs[c][i % ring])
+
+    sweep(ring + 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        plan.matvec(p, rho, y[0].lam, out=q)
+    sweep(reps)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / reps
+    return e0.elapsed_time(e1) * 1e-3 / (reps * C)
 
 
 def cpu_baseline(wl, seconds_budget=25.0):
@@ -241,6 +253,9 @@ def main():
     ap.add_argument('--workload', default='cfg3_256c3_thick6z', choices=list(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-variants', action='store_true')
+    ap.add_argument('--serial-channels', action='store_true',
+                    help='run the channels of the y-update one after the other on one stream '
+                         '(profiling aid: per-kernel durations then carry no overlap)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0)
     args = ap.parse_args()
 
@@ -262,6 +277,8 @@ def main():
 
     wl = WORKLOADS[args.workload]
     x, y, z, w, rho, sett = build_subject(wl, device, seed=1234 + rank)
+    if args.serial_channels:
+        sett.channel_streams = False
     tmp = torch.zeros_like(y[0].dat)
 
     def step():
@@ -315,12 +332,13 @@ def main():
                        'thick_ratio': wl['thick'], 'cg_iters_per_channel': sett.cgs_max_iter,
                        'cg_mode': 'fixed-iteration (tol=0), identity preconditioner',
                        'step': 'one y-update of one subject: C x (RHS + 20 CG iterations)',
+                       'channel_streams': bool(getattr(sett, 'channel_streams', True)),
                        'parallelism': 'one subject per GPU, no data-path collective'},
             'subjects_per_sec': world / (50.0 * t_admm),
             'subjects_per_sec_note': 'subject = 50 full ADMM iterations (y-update C x 20 CG, objective, '
                                      'z- and w-update); ADMM iteration timed on rank 0: %.2f ms'
                                      % (t_admm * 1e3),
-            'roofline': {'bound': 'hbm', 'kernel': 'ata_matvec (one channel)',
+            'roofline': {'bound': 'hbm', 'kernel': 'ata_matvec (per launch, mean over channels, cold operands)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.workload),
                          'alg_bytes_per_launch': b_mv, 'us_per_launch': t_mv * 1e6},
