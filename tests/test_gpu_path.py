@@ -310,10 +310,11 @@ def test_init_y_dat_matches_oracle(dev, case):
         assert rel_err(yg[c].dat.cpu(), yo[c].dat) < 2e-5
 
 
-@pytest.mark.parametrize('variant', ['gather', 'gather2', 'tile'])
+@pytest.mark.parametrize('variant', ['gather', 'gather2', 'tile', 'splat_short'])
 def test_push_kernel_variants_match_oracle(dev, variant):
-    """The alternative push kernels (UNIRES_PUSH=gather|gather2|tile, chosen at library
-    load; default is the LDS splat) run the same parity gate in a fresh process."""
+    """The alternative push kernels (UNIRES_PUSH=gather|gather2|tile, or the short splat tile
+    UNIRES_SPLAT_CFG=short; chosen at library load, default is the long-tile LDS splat) run
+    the same parity gate in a fresh process."""
     import os
     import subprocess
     import sys
@@ -329,7 +330,8 @@ def test_push_kernel_variants_match_oracle(dev, variant):
             "        assert ig[c][0] == ir[c][0]\n"
             "        assert rel_err(yg[c].cpu(), yr[c]) < 1e-4, case\n"
             "print('variant OK')\n") % root
-    env = dict(os.environ, UNIRES_PUSH=variant)
+    env = dict(os.environ, **({'UNIRES_SPLAT_CFG': 'short'} if variant == 'splat_short'
+                              else {'UNIRES_PUSH': variant}))
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and 'variant OK' in out.stdout, out.stderr[-2000:]

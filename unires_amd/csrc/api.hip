@@ -498,7 +498,7 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
   }
   if (!use_tile &&
       !launch_splat(src, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
-    return ep.partials ? splat_blocks(pl->dy) : 0;
+    return ep.partials ? splat_blocks(pl->dy, A) : 0;
   if (launch_push_tile(src, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st)) {
     launch_conv_up(src.data, src.xd, src.T, src.S, pl->gbuf, src.gd, st);
     PushSrc d = src;

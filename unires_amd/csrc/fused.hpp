@@ -42,7 +42,7 @@ int launch_push_tile(const PushSrc &src, const Affine &A, const Affine &Ainv,
 
 // Lean specialisation of the tile push (splat.hip): grid-space source, or conv_up along z
 // with fan-in <= 2.  Non-zero return: not applicable, nothing launched.
-int splat_blocks(Dim3i dd);
+int splat_blocks(Dim3i dd, const Affine &A);  // the tile shape depends on the operator
 int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const SplatSafety &safe,
                  float alpha, float tol, const PushEpilogue &ep, float *dst, Dim3i dd,
                  const int *done, hipStream_t st);

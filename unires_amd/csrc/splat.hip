@@ -42,13 +42,23 @@ struct SplatArgs {
   unsigned long long *prof;  // UNIRES_SPLAT_PROF builds only: per-phase tick sums
 };
 
-#ifndef UNIRES_STX
-#define UNIRES_STX 8  // measured on config 3: 8x4 218 us, 6x6 230, 4x8 249, 8x8 297, 4x4 329
-#define UNIRES_STY 4
-#endif
-constexpr int kSTX = UNIRES_STX, kSTY = UNIRES_STY, kSTZ = 30;
+// Tile shapes.  A wave-instruction of the splat carries G = 64 / L row segments of up to L
+// lanes along grid z.  Measured on config 3 (k_splat, channels with 0.06 / 0.096 / 0.094 rad of
+// tilt out of the z axis; a tilted z line leaves a tile column through its sides, so the
+// number of segments grows ~1.5x and so does the run time):
+//   Long  8 x 4 x 30, L = 32 : 169 / 236 / 208 us   <- used
+//   Short 8 x 8 x 14, L = 16 : 219 / 239 / 234 us   (less apron, but per-tile set-up doubles)
+//         8 x 8 x 30, L = 32 : 219 / 281 / 267 us   (fewer segments, but 12 instead of 16 waves/CU)
+//   earlier sweeps of the long form: 6x6 230, 4x8 249, 4x4 329 (vs 8x4 218)
+// UNIRES_SPLAT_CFG=short selects the short tile (kept as a tested variant).
+struct SplatLong {
+  static constexpr int TX = 8, TY = 4, TZ = 30, L = 32;
+};
+struct SplatShort {
+  static constexpr int TX = 8, TY = 8, TZ = 14, L = 16;
+};
 
-struct Seg {  // one <=32-long run of a grid row (ui,uj)
+struct Seg {  // one <=L-long run of a grid row (ui,uj)
   short ui, uj, k0;
   unsigned char len, solo;  // solo: its partner row is too close -> splat in its own turn
 };
@@ -83,18 +93,20 @@ __device__ __forceinline__ float dpp_up1f(float v) {
 #define SP_ADD(slot, t0, t1)
 #endif
 
-template <int AXIS>
+template <int AXIS, class CFG>
 __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restrict__ done) {
   if (done && *done) return;
   constexpr bool CONV = AXIS >= 0;
-  constexpr int TX = kSTX, TY = kSTY, TZ = kSTZ;
+  constexpr int TX = CFG::TX, TY = CFG::TY, TZ = CFG::TZ;
+  constexpr int L = CFG::L, G = kWave / L;  // lanes per segment, segments per instruction
+  static_assert(TZ + 2 <= L && (L == 16 || L == 32) && TY % G == 0, "tile / lane-group shape");
   constexpr int SZ = TZ + 2, SY = TY + 2, SXd = TX + 2, N = SXd * SY * SZ;
   constexpr int XS = SY * SZ, YS = SZ;  // strides of the aproned accumulator (x, y; z = 1)
   constexpr int kSegs = 128;
   __shared__ __align__(16) float acc[N];
   __shared__ __align__(8) Seg rows[kSegs];
   __shared__ __align__(16) float4 ztab[64];  // {bits(k offset), w0, w1, -}
-  const int lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
+  const int lane = threadIdx.x, grp = lane / L, gl = lane & (L - 1);
   const Dim3i dd = P.dd;
   const float *__restrict__ src = P.src;
   const float *__restrict__ pin = P.p;
@@ -171,7 +183,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
     SP_T(t_setup);
     SP_ADD(0, t_start, t_setup);
     // ---- phase A: rows (ui,uj) -> exact grid-z intervals -> <=32-long segments ----
-    const int segs_per_row = (max(bz1 - bz0 + 1, 1) + 31) / 32;
+    const int segs_per_row = (max(bz1 - bz0 + 1, 1) + L - 1) / L;
     int nseg = 0;
     for (int rc0 = 0;;) {
       if (P.dbg & 16) break;
@@ -205,9 +217,9 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
           const unsigned long long m = __ballot(has);
           const int pos = nseg + __popcll(m & lt_mask);
           if (has && pos < kSegs)
-            rows[pos] = Seg{(short)ui, (short)uj, (short)k0, (unsigned char)min(32, k1 - k0 + 1), 0};
+            rows[pos] = Seg{(short)ui, (short)uj, (short)k0, (unsigned char)min(L, k1 - k0 + 1), 0};
           nseg += __popcll(m);
-          k0 += 32;
+          k0 += L;
           has = has && k1 >= k0;
         }
         rc0 += kWave;
@@ -216,16 +228,23 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
       if (!last && nseg + kWave * segs_per_row <= kSegs) continue;
       SPLAT_FENCE();
       const int nr = min(nseg, kSegs);
-      const int npair = (nr + 1) / 2;
-      // partner rows (p, p + npair) closer than row_sep cannot share an instruction
-      for (int p = lane; p + npair < nr; p += kWave) {
-        const Seg a = rows[p], b = rows[p + npair];
-        if (max(abs(a.ui - b.ui), abs(a.uj - b.uj)) < P.row_sep) rows[p + npair].solo = 1;
+      const int npair = (nr + G - 1) / G;  // instruction p carries rows p, p + npair, ... (G of them)
+      // a row closer than row_sep to a row of a LOWER group in its instruction cannot be
+      // splat together with it: it gets a turn of its own
+      for (int idx = npair + lane; idx < nr; idx += kWave) {
+        const int p = idx % npair, g = idx / npair;
+        const Seg b = rows[idx];
+        bool solo = false;
+        for (int g2 = 0; g2 < g; ++g2) {
+          const Seg a = rows[p + g2 * npair];
+          solo = solo || max(abs(a.ui - b.ui), abs(a.uj - b.uj)) < P.row_sep;
+        }
+        if (solo) rows[idx].solo = 1;
       }
       SPLAT_FENCE();
       SP_T(t_a1);
       SP_ADD(1, t_a0, t_a1);
-      // ---- phase B: half-wave per segment, lanes along grid z, kU pairs per batch ----
+      // ---- phase B: one lane group per segment, lanes along grid z, kU instructions per batch ----
       constexpr int kU = 4;
       for (int p0 = 0; p0 < ((P.dbg & 8) ? 0 : npair); p0 += kU) {
         SP_T(t_b0);
@@ -235,11 +254,11 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           const int p = p0 + u;
-          const int idx = half ? p + npair : p;
+          const int idx = p + grp * npair;
           const Seg R = rows[min(idx, nr - 1)];
-          act[u] = p < npair && idx < nr && hl < R.len;
-          solo[u] = R.solo && half;
-          ui[u] = R.ui, uj[u] = R.uj, uk[u] = min(R.k0 + hl, P.gz - 1);
+          act[u] = p < npair && idx < nr && gl < R.len;
+          solo[u] = R.solo && grp > 0;
+          ui[u] = R.ui, uj[u] = R.uj, uk[u] = min(R.k0 + gl, P.gz - 1);
           if (AXIS == 2) {
             const float4 tb = ztab[min(uk[u] - bz0, 63)];
             const unsigned base =
@@ -291,7 +310,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
           // group: replay it in a later turn (rare: |dz/dk| < 1 by a hair)
           const int prev_lz = dpp_up1(lzk);  // executed by ALL lanes: a DPP read of a lane that
                                              // is masked off returns the reader's own value
-          const bool dup = ok && hl > 0 && lzk == prev_lz;
+          const bool dup = ok && gl > 0 && lzk == prev_lz;
           const bool slow = __any(dup) || __any(ok && solo[u]) || (P.dbg & 1);
           if (!slow) {
             // common case, straight line: z-adjacent lanes hand their shared plane over in
@@ -300,8 +319,8 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
             const int below = dpp_up1(cell), above = dpp_dn1(cell);
             const float p00 = dpp_up1f(u00), p01 = dpp_up1f(u01), p10 = dpp_up1f(u10),
                         p11 = dpp_up1f(u11);
-            const bool recv = ok && hl > 0 && below + 1 == cell;
-            const bool sent = ok && hl < 31 && above == cell + 1;
+            const bool recv = ok && gl > 0 && below + 1 == cell;
+            const bool sent = ok && gl < L - 1 && above == cell + 1;
             if (recv) l00 += p00, l01 += p01, l10 += p10, l11 += p11;
             float *q = acc + (ok ? cell : 0);
             SPLAT_FENCE();
@@ -319,8 +338,8 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
           } else {
             // turn schedule: (row B of a too-close pair) x (replayed same-plane neighbour);
             // within a turn no hand-over, each lane updates both of its planes
-            const int myturn = (solo[u] ? 2 : 0) + (dup ? 1 : 0);
-            for (int turn = 0; turn < 4; ++turn) {
+            const int myturn = (solo[u] ? 2 * grp : 0) + (dup ? 1 : 0);
+            for (int turn = 0; turn < 2 * G; ++turn) {
               if (!__any(ok && myturn == turn)) continue;
               SPLAT_FENCE();
               if (ok && myturn == turn) {
@@ -347,41 +366,44 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
     }
     SPLAT_FENCE();
     SP_T(t_e0);
-    // ---- epilogue: q = [q +] acc + a0 p + c DtD p ; dot += p*q  (one row per half-wave) ----
-    static_assert(TZ <= 32, "epilogue maps one row to a half-wave");
+    // ---- epilogue: q = [q +] acc + a0 p + c DtD p ; dot += p*q  (one row per lane group) ----
+    // one output row (lx, ly, all z) per lane group
     // Fast form for tiles whose x/y stencil neighbours are all inside the volume (91 % of the
     // tiles of a 256^3 volume): the row base is a scalar, the lane offset is computed once per
     // tile, and every load/store is "scalar base + lane offset" - no per-row index arithmetic.
     // (A wave64 VALU instruction occupies the SIMD for 4 clocks; the generic form below spends
     // ~125 of them per pair of rows, this one ~25.)
     if (P.dbg & 2) continue;
-    const bool fast_xy = TY == 4 && pin != nullptr && !P.accumulate && x0 > 0 && y0 > 0 &&
+    constexpr int RPX = TY / G;  // instructions per x slab of the tile
+    static_assert((TX * RPX) % 4 == 0, "fast epilogue unrolls four instructions");
+    const bool fast_xy = pin != nullptr && !P.accumulate && x0 > 0 && y0 > 0 &&
                          x0 + TX < dd.x && y0 + TY < dd.y && dd.numel() < (1ull << 29);
     if (fast_xy) {
       const size_t sxe = (size_t)dd.y * dd.z, sye = dd.z;
-      const int kc = min(z0 + hl, dd.z - 1);
-      const bool act = hl < ez, lzf = kc > 0, hzf = kc + 1 < dd.z;
+      const int kc = min(z0 + gl, dd.z - 1);
+      const bool act = gl < ez, lzf = kc > 0, hzf = kc + 1 < dd.z;
       // buffer addressing: per-lane byte offset (once per tile) + scalar row offset
       // (soffset is added as an unsigned value: the lane offset is taken relative to the
       // (x0-1, y0-1) row so that every scalar row offset below is non-negative)
-      const unsigned e0 = 4u * (unsigned)(((x0 - 1) * dd.y + y0 - 1 + half) * dd.z + kc);
+      const unsigned e0 = 4u * (unsigned)(((x0 - 1) * dd.y + y0 - 1 + grp) * dd.z + kc);
       const unsigned em = lzf ? e0 - 4u : e0, ep = hzf ? e0 + 4u : e0;
       const unsigned sxb = 4u * (unsigned)sxe, syb = 4u * (unsigned)sye;
       const __amdgpu_buffer_rsrc_t rp = make_rsrc(pin, dd.numel() * 4),
                                    rd = make_rsrc(dst, dd.numel() * 4),
                                    rb = make_rsrc(P.objb ? P.objb : pin, dd.numel() * 4);
-      const float *arow = acc + (SY + 1 + half) * SZ + hl + 1;
+      const float *arow = acc + (SY + 1 + grp) * SZ + gl + 1;
       auto rows = [&](auto obj_tag) {
         constexpr bool OBJ = decltype(obj_tag)::value;
 #pragma unroll 1
-        for (int it = 0; it < TX * TY / 2; it += 4) {
+        for (int it = 0; it < TX * RPX; it += 4) {
           // readfirstlane: keeps the row base in SGPRs and hides the induction variable from
           // loop strength reduction (which would turn every address into a 64-bit VGPR pointer)
           const int it0 = __builtin_amdgcn_readfirstlane(it);
           float c[4], vxp[4], vxm[4], vyp[4], vym[4], vzp[4], vzm[4], ob[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {  // all 28 loads of four row pairs in flight together
-            const unsigned ro = (unsigned)(it0 / 2 + j / 2 + 1) * sxb + (unsigned)((j % 2) * 2 + 1) * syb;
+            const unsigned ro = (unsigned)((it0 + j) / RPX + 1) * sxb +
+                                (unsigned)(((it0 + j) % RPX) * G + 1) * syb;
             c[j] = buf_load(rp, e0, ro);
             vxp[j] = buf_load(rp, e0, ro + sxb), vxm[j] = buf_load(rp, e0, ro - sxb);
             vyp[j] = buf_load(rp, e0, ro + syb), vym[j] = buf_load(rp, e0, ro - syb);
@@ -390,7 +412,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int lx = it0 / 2 + j / 2, ly2 = (j % 2) * 2;  // this half's row: (lx, ly2 + half)
+            const int lx = (it0 + j) / RPX, ly2 = ((it0 + j) % RPX) * G;  // this group's row: (lx, ly2 + grp)
             const unsigned ro = (unsigned)(lx + 1) * sxb + (unsigned)(ly2 + 1) * syb;
             float q = arow[(lx * SY + ly2) * SZ];
             const float xf = vxp[j] - c[j], xb = c[j] - vxm[j], yf = vyp[j] - c[j], yb = c[j] - vym[j];
@@ -414,8 +436,8 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
         rows(std::false_type{});
     } else {
 #pragma unroll 4
-      for (int r = half; r < TX * TY; r += 2) {
-        const int lx = r / TY, ly = r % TY, lz = hl;
+      for (int r = grp; r < TX * TY; r += G) {
+        const int lx = r / TY, ly = r % TY, lz = gl;
         if (lx >= ex || ly >= ey || lz >= ez) continue;
         const int i = x0 + lx, j = y0 + ly, k = z0 + lz;
         const size_t idx = ((size_t)i * dd.y + j) * dd.z + k;
@@ -440,9 +462,24 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
   }
 }
 
-int splat_blocks(Dim3i dd) {
-  const long long nt = (long long)((dd.x + kSTX - 1) / kSTX) * ((dd.y + kSTY - 1) / kSTY) *
-                       ((dd.z + kSTZ - 1) / kSTZ);
+// Tile shape for this operator: the short tile when a grid z line drifts sideways by more than
+// ~1 voxel over a long tile column (UNIRES_SPLAT_CFG=long|short forces one).
+static bool splat_use_short(const Affine &A) {
+  static const char *force = getenv("UNIRES_SPLAT_CFG");
+  if (force && force[0] == 'l') return false;
+  if (force && force[0] == 's') return true;
+  (void)A;  // measured on config 3 (channels with 0.06 / 0.096 / 0.094 rad tilt): the short tile
+  return false;  // loses everywhere (219/239/234 us vs 169/236/208 us) - per-tile set-up dominates
+}
+
+template <class CFG>
+static long long splat_tiles(Dim3i dd) {
+  return (long long)((dd.x + CFG::TX - 1) / CFG::TX) * ((dd.y + CFG::TY - 1) / CFG::TY) *
+         ((dd.z + CFG::TZ - 1) / CFG::TZ);
+}
+
+int splat_blocks(Dim3i dd, const Affine &A) {
+  const long long nt = splat_use_short(A) ? splat_tiles<SplatShort>(dd) : splat_tiles<SplatLong>(dd);
   static const int cap = getenv("UNIRES_SPLAT_BLOCKS") ? atoi(getenv("UNIRES_SPLAT_BLOCKS")) : 4096;
   const int lim = cap < kMaxPartials ? cap : kMaxPartials;
   return (int)(nt < lim ? nt : lim);  // persistent grid
@@ -499,15 +536,23 @@ int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const 
   (void)hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), st);
   P.prof = prof;
 #endif
-  const dim3 grid(splat_blocks(dd));
-  if (axis == 0)
-    hipLaunchKernelGGL(k_splat<0>, grid, dim3(kWave), 0, st, P, done);
-  else if (axis == 1)
-    hipLaunchKernelGGL(k_splat<1>, grid, dim3(kWave), 0, st, P, done);
-  else if (axis == 2)
-    hipLaunchKernelGGL(k_splat<2>, grid, dim3(kWave), 0, st, P, done);
+  const dim3 grid(splat_blocks(dd, A));
+#define LAUNCH_SPLAT(CFG)                                                              \
+  do {                                                                                 \
+    if (axis == 0)                                                                     \
+      hipLaunchKernelGGL((k_splat<0, CFG>), grid, dim3(kWave), 0, st, P, done);        \
+    else if (axis == 1)                                                                \
+      hipLaunchKernelGGL((k_splat<1, CFG>), grid, dim3(kWave), 0, st, P, done);        \
+    else if (axis == 2)                                                                \
+      hipLaunchKernelGGL((k_splat<2, CFG>), grid, dim3(kWave), 0, st, P, done);        \
+    else                                                                               \
+      hipLaunchKernelGGL((k_splat<-1, CFG>), grid, dim3(kWave), 0, st, P, done);       \
+  } while (0)
+  if (splat_use_short(A))
+    LAUNCH_SPLAT(SplatShort);
   else
-    hipLaunchKernelGGL(k_splat<-1>, grid, dim3(kWave), 0, st, P, done);
+    LAUNCH_SPLAT(SplatLong);
+#undef LAUNCH_SPLAT
 #ifdef UNIRES_SPLAT_PROF
   {
     unsigned long long h[8];
