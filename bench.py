@@ -30,7 +30,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy
-TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r01_traffic.json')  # PMC bytes of the same matvec
 
 WORKLOADS = {
     # name: dim_y, channels, thick ratio, thick axis per channel
@@ -121,11 +120,14 @@ def pmc_traffic(workload):
     """HBM bytes per matvec launch from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE in separate runs; gfx950 FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes).  None if no profile of this workload is committed."""
-    try:
-        rec = json.load(open(TRAFFIC_JSON))
-        return rec['bytes_per_launch'] if rec.get('workload') == workload else None
-    except (OSError, ValueError, KeyError):
-        return None
+    for name in ('r01_traffic.json', 'r01_traffic_aligned.json'):
+        try:
+            rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            if rec.get('workload') == workload:
+                return rec['bytes_per_launch']
+        except (OSError, ValueError, KeyError):
+            pass
+    return None
 
 
 def time_matvec(x, y, rho, sett, reps=16, ring=2):
