@@ -213,6 +213,16 @@ int unires_nll_prior(const float *const *y_ptrs, const float *lam, int32_t n_cha
 /* sum_{x != 0} (x - ay)^2 in float64  (_update.py:414-417; the caller multiplies by tau/2). */
 int unires_masked_sse(const float *x, const float *ay, int64_t n, double *out_dev, void *stream);
 
+/* The masked sums of one Gauss-Newton step on the even/odd slice scaling
+ * (_update_scaling, _update.py:310-336); x, ay: x-space volumes `dim`, ay = A y with the
+ * current scaling; slices alternate along dim_thick ('odd' = [::2], 'even' = [1::2], :430-445).
+ *   out_dev[0] = sum_{x!=0} (x-ay)^2          (ll = 0.5 tau out[0])
+ *   out_dev[1] = sum_even ay (x-ay)   out_dev[2] = sum_odd ay (x-ay)   (gr  = tau (out[1]-out[2]))
+ *   out_dev[3] = sum_even ay^2        out_dev[4] = sum_odd ay^2        (Hes = tau (out[3]+out[4]))
+ * float32 terms, float64 sums; out_dev: 5 doubles on the device. */
+int unires_scaling_sums(const float *x, const float *ay, const int32_t dim[3], int32_t dim_thick,
+                        double *out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

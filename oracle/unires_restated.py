@@ -247,6 +247,72 @@ def update_y(x, y, z, w, rho, method, do_proj, cgs_max_iter=20, cgs_tol=1e-3,
 
 
 # --------------------------------------------------------------------------
+# unires/_update.py:270-393, 430-445  (even/odd slice-scaling Gauss-Newton)
+# --------------------------------------------------------------------------
+def even_odd(dat, which, dim):
+    """'odd' = [::2], 'even' = [1::2] along ``dim`` (:430-445)."""
+    sl = [slice(None)] * 3
+    sl[dim] = slice(0, None, 2) if which == 'odd' else slice(1, None, 2)
+    return dat[tuple(sl)]
+
+
+def update_scaling(x, y, method='super-resolution', max_niter_gn=1, num_linesearch=4):
+    """_update_scaling, restated line by line - including the line search that rescales the
+    already rescaled ``dat_y`` after a rejected step (:362-366).  ``rigid`` is read from
+    ``po.rigid`` (the reference recomputes it from rigid_q, :301; same matrix).  Returns
+    (x, sll); ``x[c][n].po.scl`` is updated (float64 0-d tensor after the first step)."""
+    from .nitorch_restated import affine_grid, grid_pull
+    import torch.nn.functional as F
+    sll = torch.tensor(0, dtype=torch.float64)
+    ll = torch.tensor(0, dtype=torch.float64)
+    for c in range(len(x)):
+        for n_x in range(len(x[c])):
+            xn = x[c][n_x]
+            if getattr(xn, 'ct', False):
+                continue                                                          # :288-290
+            po = xn.po
+            dim_thick, tau = po.dim_thick, xn.tau
+            scl = torch.as_tensor(po.scl)
+            mat = torch.linalg.solve(po.mat_y, po.rigid.mm(po.mat_yx))            # :302
+            dat_x = xn.dat
+            msk = dat_x != 0
+            xo = even_odd(dat_x, 'odd', dim_thick)[even_odd(msk, 'odd', dim_thick)]
+            xe = even_odd(dat_x, 'even', dim_thick)[even_odd(msk, 'even', dim_thick)]
+            mo, me = even_odd(msk, 'odd', dim_thick), even_odd(msk, 'even', dim_thick)
+            grid = affine_grid(mat.type(torch.float32), po.dim_yx)
+            dat_y = grid_pull(y[c].dat[None, None], grid[None], bound='zero',
+                              interpolation='linear', extrapolate=False)
+            dat_y = F.conv3d(dat_y, po.smo_ker, stride=po.ratio)[0, 0]           # :320
+            dat_y = apply_scaling(dat_y[None, None], scl, dim_thick)[0, 0]       # :322
+            for _ in range(max_niter_gn):
+                ll = 0.5 * tau * torch.sum((dat_x[msk] - dat_y[msk]) ** 2, dtype=torch.float64)
+                yo = even_odd(dat_y, 'odd', dim_thick)[mo]
+                ye = even_odd(dat_y, 'even', dim_thick)[me]
+                gr = tau * (torch.sum(ye * (xe - ye), dtype=torch.float64)
+                            - torch.sum(yo * (xo - yo), dtype=torch.float64))   # :340-341
+                Hes = tau * (torch.sum(ye ** 2, dtype=torch.float64)
+                             + torch.sum(yo ** 2, dtype=torch.float64))          # :344-345
+                Update = gr / Hes
+                old_scl, old_ll = scl.clone(), ll.clone()
+                armijo = torch.tensor(1.0, dtype=old_scl.dtype)
+                if num_linesearch == 0:
+                    scl = old_scl - armijo * Update
+                else:
+                    for _ls in range(num_linesearch):
+                        scl = old_scl - armijo * Update
+                        dat_y = apply_scaling(dat_y[None, None], scl - old_scl, dim_thick)[0, 0]
+                        ll = 0.5 * tau * torch.sum((dat_x[msk] - dat_y[msk]) ** 2,
+                                                   dtype=torch.float64)
+                        if ll < old_ll:
+                            break
+                        scl, ll = old_scl, old_ll
+                        armijo = armijo * 0.5
+            po.scl = scl                                                          # :389
+            sll = sll + ll
+    return x, sll
+
+
+# --------------------------------------------------------------------------
 # unires/_update.py:160-193  (z- and w-updates; SURVEY 8(f) next-1)
 # --------------------------------------------------------------------------
 def update_zw(y, z, w, rho, alpha=1.0):

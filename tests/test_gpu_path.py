@@ -374,3 +374,41 @@ def test_aligned_kernel_agrees_with_general_kernels_at_256(dev, tmp_path):
     assert rel_err(res['aligned']['y'], res['general']['y']) < 2e-5
     assert torch.allclose(torch.tensor(res['aligned']['obj']), torch.tensor(res['general']['obj']),
                           rtol=1e-6)
+
+
+@pytest.mark.parametrize('case', ['sr_3ch_axes', 'sr_2rep', 'sr_aligned'])
+@pytest.mark.parametrize('n_ls', [0, 4])
+def test_update_scaling_matches_oracle(dev, case, n_ls):
+    """SURVEY 8(f) next-3, even/odd slice-scaling Gauss-Newton (unires/_update.py:270-393):
+    observations generated with a scaling the operator does not know yet."""
+    import unires_amd as U
+    prob = make_problem(seed=31, **CASES[case])
+    xo, yo = oracle_structs(prob)
+    xg, yg, sett = gpu_structs(prob, dev)
+    g = torch.Generator().manual_seed(5)
+    for c in range(len(xo)):
+        yo[c].dat = torch.rand(prob['dim_y'], generator=g) * 100 + 20
+        yg[c].dat = yo[c].dat.clone().to(dev)
+        for n in range(len(xo[c])):
+            po = xo[c][n].po
+            true_scl = 0.12 if (c + n) % 2 == 0 else -0.08
+            keep = po.scl
+            po.scl = torch.tensor(true_scl)
+            dat = O.proj_apply('A', yo[c].dat[None, None], po, method=prob['method'])[0, 0]
+            po.scl = keep
+            dat = dat + torch.randn(dat.shape, generator=g)
+            dat[0, 0, :] = 0  # some masked-out voxels
+            xo[c][n].dat = dat
+            xg[c][n].dat = dat.clone().to(dev)
+    xo, sll_o = O.update_scaling(xo, yo, method=prob['method'], max_niter_gn=2, num_linesearch=n_ls)
+    xg, sll_g = U._update_scaling(xg, yg, sett, max_niter_gn=2, num_linesearch=n_ls)
+    assert abs(sll_g.item() - sll_o.item()) < 2e-5 * abs(sll_o.item())
+    for c in range(len(xo)):
+        for n in range(len(xo[c])):
+            so, sg = float(xo[c][n].po.scl), float(xg[c][n].po.scl)
+            assert abs(sg - so) < 1e-5, (c, n, so, sg)
+            assert abs(so - float(prob['chans'][c]['reps'][n].get('scl', 0.0))) > 1e-3  # it moved
+    # the rebuilt operator uses the new scaling
+    Ay_o = O.proj('A', yo[0].dat, xo[0], yo[0], method=prob['method'], do=True, n=0)
+    Ay_g = U._proj('A', yg[0].dat, xg[0], yg[0], method=prob['method'], do=True, n=0)
+    assert rel_err(Ay_g.cpu(), Ay_o) < 2e-5

@@ -68,6 +68,8 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p]),
     'unires_nll_prior': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int32, c_i32x3,
                                    c_f32x3, C.c_void_p, C.c_void_p]),
+    'unires_scaling_sums': (C.c_int, [C.c_void_p, C.c_void_p, c_i32x3, C.c_int32, C.c_void_p,
+                                      C.c_void_p]),
     'unires_masked_sse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }
 

@@ -163,6 +163,64 @@ def _compute_nll(x, y, sett, rho, sum_dtype=torch.float64):
     return nll_xy + nll_y, nll_xy, nll_y
 
 
+def _update_scaling(x, y, sett, max_niter_gn=1, num_linesearch=4, verbose=0):
+    """Updates the even/odd slice scaling parameter of every observation by Gauss-Newton
+    (unires/_update.py:270-393).  ``A y`` comes from the fused pull+conv kernel, the five masked
+    float64 sums of a step (ll, gradient and Hessian terms) from ONE reduction kernel instead
+    of ten masked-index passes; the step logic - including the reference's line search, which
+    rescales the already rescaled ``dat_y`` after a rejected step (:362-366) - runs on the host
+    with one 40-byte read-back per evaluation.  ``po.rigid`` is used where the reference
+    recomputes the same matrix from ``rigid_q`` (:301).  Returns (x, sll)."""
+    from ._project import _apply_scaling
+    if sett.method != 'super-resolution':
+        raise ValueError('_update_scaling needs the super-resolution projection '
+                         '(slice profile + slice scaling)')
+    lib = _lib.load()
+    dev = y[0].dat.device
+    sll = torch.zeros((), dtype=torch.float64, device=dev)
+    sums = torch.empty(5, dtype=torch.float64, device=dev)
+    for c in range(len(x)):
+        for n_x in range(len(x[c])):
+            xn = x[c][n_x]
+            if xn.ct:  # do not optimise scaling for CT data (:288-290)
+                continue
+            po = xn.po
+            dim_thick, tau, scl = int(po.dim_thick), float(xn.tau), float(po.scl)
+            plan = _channel_plan(x[c], y[c], sett.method, sett.do_proj)
+            dat_x = xn.dat.contiguous()
+            dat_y = plan.proj_apply(n_x, 'A', y[c].dat)  # pull + conv + S(scl)  (:316-322)
+
+            def evaluate(ay):
+                check(lib.unires_scaling_sums(_ptr(dat_x), _ptr(ay), i3(dat_x.shape), dim_thick,
+                                              _ptr(sums), _stream()))
+                return sums.tolist()  # one small device-to-host copy
+
+            ll = 0.0
+            for _ in range(max_niter_gn):
+                s = evaluate(dat_y)
+                ll = 0.5 * tau * s[0]
+                gr = tau * (s[1] - s[2])
+                hes = tau * (s[3] + s[4])
+                update = gr / hes
+                old_scl, old_ll, armijo = scl, ll, 1.0
+                if num_linesearch == 0:
+                    scl = old_scl - armijo * update
+                else:
+                    for _ls in range(num_linesearch):
+                        scl = old_scl - armijo * update
+                        dat_y = _apply_scaling(dat_y, scl - old_scl, dim_thick)
+                        ll = 0.5 * tau * evaluate(dat_y)[0]
+                        if ll < old_ll:
+                            break
+                        scl, ll = old_scl, old_ll
+                        armijo *= 0.5
+                if verbose >= 1:
+                    print('c={}, n={} | exp(s)={:.5f} ll={:.2f}'.format(c, n_x, torch.tensor(scl).exp(), ll))
+            po.scl = scl  # the next _channel_plan() call rebuilds the operator with it
+            sll = sll + ll
+    return x, sll
+
+
 def _update_admm(x, y, z, w, rho, tmp, obj, n_iter, sett, info=None):
     """One ADMM iteration (unires/_update.py:105-195): y-update (CG), objective,
     z-update, w-update - same order, same in-place semantics, `tmp` returned as the

@@ -119,6 +119,42 @@ __global__ void __launch_bounds__(kBlock)
   if (threadIdx.x == 0) atomicAdd(partials, s);
 }
 
+// The five masked sums of the even/odd slice-scaling Gauss-Newton step
+// (unires/_update.py:310-336): msk = x != 0, slices split along dim_thick as the reference's
+// _even_odd does ('odd' = dat[::2], 'even' = dat[1::2], _update.py:430-445);
+// out[0] = sum (x-y)^2, out[1] = sum_even y(x-y), out[2] = sum_odd y(x-y),
+// out[3] = sum_even y^2, out[4] = sum_odd y^2  - float32 terms, float64 sums.
+__global__ void __launch_bounds__(kBlock)
+    k_scaling_sums(const float *__restrict__ x, const float *__restrict__ y, Dim3i d, int dim_thick,
+                   double *__restrict__ out) {
+  const size_t n = d.numel(), stride = (size_t)gridDim.x * blockDim.x;
+  const size_t div = dim_thick == 2 ? 1 : (dim_thick == 1 ? (size_t)d.z : (size_t)d.y * d.z);
+  const int len = dim_thick == 2 ? d.z : (dim_thick == 1 ? d.y : d.x);
+  double s0 = 0.0, ge = 0.0, go = 0.0, he = 0.0, ho = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float xv = x[i];
+    if (xv == 0.f) continue;
+    const float yv = y[i], r = __fsub_rn(xv, yv);
+    const bool even = ((i / div) % (size_t)len) & 1;  // index 1::2 along dim_thick
+    s0 += (double)__fmul_rn(r, r);
+    const double g = (double)__fmul_rn(yv, r), h = (double)__fmul_rn(yv, yv);
+    if (even)
+      ge += g, he += h;
+    else
+      go += g, ho += h;
+  }
+  const double v[5] = {block_sum(s0), block_sum(ge), block_sum(go), block_sum(he), block_sum(ho)};
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 5; ++k) atomicAdd(out + k, v[k]);
+}
+
+void launch_scaling_sums(const float *x, const float *y, Dim3i d, int dim_thick, double *out,
+                         hipStream_t st) {
+  size_t b = (d.numel() + kBlock - 1) / kBlock;
+  if (b > 256) b = 256;
+  hipLaunchKernelGGL(k_scaling_sums, dim3((int)b), dim3(kBlock), 0, st, x, y, d, dim_thick, out);
+}
+
 static inline dim3 vblock() { return dim3(kWave, kBlock / kWave, 1); }
 static inline int tile_blocks(Dim3i d) {
   // <= 1024 workgroups: each ends with ONE float64 atomic on a single accumulator

@@ -11,6 +11,8 @@ int launch_jtv_scale(const float *const *y, const float *lam, int nc, const floa
                      float *scale, double *partials, int norm_only, hipStream_t st);
 void launch_zw_update(const float *y, float lam, const float *scale, float *z, float *w, Dim3i d,
                       const float vx[3], float rho, float alpha, hipStream_t st);
+void launch_scaling_sums(const float *x, const float *y, Dim3i d, int dim_thick, double *out,
+                         hipStream_t st);
 int launch_masked_sse(const float *x, const float *ay, size_t n, double *partials, hipStream_t st);
 
 }  // namespace unires

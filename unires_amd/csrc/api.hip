@@ -794,6 +794,18 @@ extern "C" int unires_nll_prior(const float *const *y_ptrs, const float *lam, in
   return UNIRES_OK;
 }
 
+extern "C" int unires_scaling_sums(const float *x, const float *ay, const int32_t dim[3],
+                                   int32_t dim_thick, double *out_dev, void *stream) {
+  if (!x || !ay || !dim || !out_dev) return fail(UNIRES_ERR_NULL, "null argument");
+  if (!dims_ok(dim)) return fail(UNIRES_ERR_DIM, "bad dims");
+  if (dim_thick < 0 || dim_thick > 2) return fail(UNIRES_ERR_ARG, "bad dim_thick");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(out_dev, 0, 5 * sizeof(double), st));
+  launch_scaling_sums(x, ay, mk(dim), dim_thick, out_dev, st);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
 extern "C" int unires_masked_sse(const float *x, const float *ay, int64_t n, double *out_dev,
                                  void *stream) {
   if (!x || !ay || !out_dev) return fail(UNIRES_ERR_NULL, "null argument");
