@@ -213,6 +213,12 @@ int unires_nll_prior(const float *const *y_ptrs, const float *lam, int32_t n_cha
 /* sum_{x != 0} (x - ay)^2 in float64  (_update.py:414-417; the caller multiplies by tau/2). */
 int unires_masked_sse(const float *x, const float *ay, int64_t n, double *out_dev, void *stream);
 
+/* fit()'s clean_fov post-processing (run.py:150-164): y[v] = 0 where the voxel M v of the
+ * low-resolution image lies outside [0, dim_x) on any axis; M (12 floats, row-major 3x4) =
+ * float32 of inv(mat_y^-1 rigid mat_x).  Call once per observation. */
+int unires_clean_fov(float *y, const int32_t dim_y[3], const float M[12], const int32_t dim_x[3],
+                     void *stream);
+
 /* The masked sums of one Gauss-Newton step on the even/odd slice scaling
  * (_update_scaling, _update.py:310-336); x, ay: x-space volumes `dim`, ay = A y with the
  * current scaling; slices alternate along dim_thick ('odd' = [::2], 'even' = [1::2], :430-445).

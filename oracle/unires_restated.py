@@ -386,3 +386,64 @@ def init_y_dat(x, y):
         sm[sm == 0] = 1.0
         y[c].dat = dat_y / sm
     return y
+
+
+# --------------------------------------------------------------------------
+# unires/run.py:24-207 (fit) and unires/_core.py:288-307 (_get_sched)
+# --------------------------------------------------------------------------
+def get_sched(N, reg_scl=4.0, sched_num=3):
+    """Coarse-to-fine schedule of the regularisation scaling: 4 -> [32, 16, 8, 4]; [4] if N == 1."""
+    if sched_num < 0 or N == 1:
+        sched_num = 0
+    scl = torch.as_tensor(reg_scl, dtype=torch.float32).reshape(1)
+    sched = (torch.tensor(2.0) ** torch.arange(0, 32, step=1, dtype=torch.float32)).flip(dims=(0,))
+    ix = torch.min((sched - scl).abs(), dim=0)[1]
+    return torch.cat((sched[ix - sched_num:ix], scl))
+
+
+def fit(x, y, method, do_proj, max_iter=512, tolerance=1e-4, reg_scl=4.0, sched_num=3,
+        scaling=False, cgs_max_iter=20, cgs_tol=1e-3, alpha=1.0):
+    """The iteration loop of fit() (run.py:56-143) on in-memory structs: lambda scaling,
+    rho, ADMM iterations, convergence countdowns, optional scaling update, coarse-to-fine
+    switch.  y[c].lam0 must hold the unscaled regularisation.  Returns (y, obj, n_iter, sched)."""
+    from .nitorch_restated import get_gain
+    N = sum(len(xn) for xn in x)
+    sched = get_sched(N, reg_scl, sched_num)
+    cnt_scl = 0
+    for c in range(len(x)):
+        y[c].lam = sched[cnt_scl] * y[c].lam0                                     # :60-61
+    rho = step_size(x, y)                                                         # :65
+    z = torch.zeros((len(y), 3) + tuple(y[0].dat.shape), dtype=torch.float32)
+    w = torch.zeros_like(z)
+    obj = torch.zeros(max_iter, 3, dtype=torch.float64)
+    cnt_scl_iter = 0
+    countdown0 = countdown1 = 6
+    n_done = 0
+    for n_iter in range(max_iter):
+        y = update_y(x, y, z, w, rho, method, do_proj, cgs_max_iter=cgs_max_iter, cgs_tol=cgs_tol)
+        if tolerance > 0:
+            obj[n_iter, 0], obj[n_iter, 1], obj[n_iter, 2] = compute_nll(x, y, method, do_proj)
+        z, w, _ = update_zw(y, z, w, rho, alpha=alpha)
+        n_done = n_iter + 1
+        gain = get_gain(obj[:n_iter + 1, 0], monotonicity='decreasing')            # :100
+        if cnt_scl >= (sched.numel() - 1) and cnt_scl_iter > 20 \
+                and ((gain.abs() < tolerance) or (n_iter >= (max_iter - 1))):      # :103-104
+            countdown0 -= 1
+            if countdown0 == 0:
+                break
+        else:
+            countdown0 = 6
+        if scaling:
+            x, _ = update_scaling(x, y, method=method, max_niter_gn=1, num_linesearch=6)  # :119
+        if cnt_scl + 1 < len(sched) and cnt_scl_iter > 16 and gain.abs() < 1e-3:   # :139
+            countdown1 -= 1
+            if countdown1 == 0:
+                cnt_scl_iter = 0
+                cnt_scl += 1
+                for c in range(len(x)):
+                    y[c].lam = sched[cnt_scl] * y[c].lam0
+                rho = step_size(x, y)
+        else:
+            countdown1 = 6
+        cnt_scl_iter += 1
+    return y, obj[:n_done], n_done, sched

@@ -412,3 +412,36 @@ def test_update_scaling_matches_oracle(dev, case, n_ls):
     Ay_o = O.proj('A', yo[0].dat, xo[0], yo[0], method=prob['method'], do=True, n=0)
     Ay_g = U._proj('A', yg[0].dat, xg[0], yg[0], method=prob['method'], do=True, n=0)
     assert rel_err(Ay_g.cpu(), Ay_o) < 2e-5
+
+
+def test_fit_loop_matches_oracle(dev):
+    """The iteration loop of fit() (unires/run.py:56-143): regularisation schedule, rho,
+    ADMM iterations, convergence countdowns, coarse-to-fine switch - GPU driver vs oracle."""
+    import unires_amd as U
+    prob = make_problem(seed=41, **CASES['sr_2rep'])
+    xo, yo = oracle_structs(prob)
+    xg, yg, sett = gpu_structs(prob, dev)
+    for c in range(len(yo)):
+        yo[c].lam0 = yo[c].lam / 4.0
+        yg[c].lam0 = float(yg[c].lam) / 4.0
+    sett.max_iter, sett.tolerance, sett.reg_scl, sett.sched_num = 25, 1e-4, 4.0, 3
+    sett.clean_fov = True
+    y_ref, obj_ref, n_ref, sched = O.fit(xo, yo, prob['method'], prob['do_proj'], max_iter=25)
+    y_pre = None
+    dat, mat, R, info = U.fit(xg, yg, sett)
+    assert info['n_iter'] == n_ref
+    assert torch.equal(info['reg_scl'].cpu(), sched) and sched.tolist() == [32.0, 16.0, 8.0, 4.0]
+    assert torch.allclose(info['obj'], obj_ref, rtol=5e-4)
+    assert dat.shape == prob['dim_y'] + (len(yo),) and R.shape == (4, 4, 4)
+    # clean_fov (run.py:150-164) restated with torch ops on the oracle result
+    for c in range(len(yo)):
+        keep = torch.ones(prob['dim_y'], dtype=torch.bool)
+        for n, xn in enumerate(xo[c]):
+            M = torch.linalg.solve(prob['mat_y'], xn.po.rigid.mm(xn.mat)).inverse()
+            g = N.affine_grid(M.float(), prob['dim_y'])
+            for d in range(3):
+                keep &= (g[..., d] >= 0) & (g[..., d] < xn.dat.shape[d])
+        ref = y_ref[c].dat.clone()
+        ref[~keep] = 0
+        assert (~keep).any()
+        assert rel_err(dat[..., c].cpu(), ref) < 2e-3

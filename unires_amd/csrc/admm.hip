@@ -155,7 +155,26 @@ void launch_scaling_sums(const float *x, const float *y, Dim3i d, int dim_thick,
   hipLaunchKernelGGL(k_scaling_sums, dim3((int)b), dim3(kBlock), 0, st, x, y, d, dim_thick, out);
 }
 
+// y[v] = 0 where M v falls outside [0, dim_x) on any axis  (fit()'s clean_fov, run.py:150-164:
+// grid = M (i,j,k), keep = 0 <= g_d < dim_x_d)
+__global__ void __launch_bounds__(kBlock)
+    k_clean_fov(float *__restrict__ y, Dim3i d, Affine M, float nx, float ny, float nz) {
+  const int k = blockIdx.x * kWave + threadIdx.x, j = blockIdx.y * (kBlock / kWave) + threadIdx.y,
+            i = blockIdx.z;
+  if (k >= d.z || j >= d.y) return;
+  float gx, gy, gz;
+  affine_point(M, (float)i, (float)j, (float)k, gx, gy, gz);
+  const bool keep = gx >= 0.f && gx < nx && gy >= 0.f && gy < ny && gz >= 0.f && gz < nz;
+  if (!keep) y[((size_t)i * d.y + j) * d.z + k] = 0.f;
+}
+
 static inline dim3 vblock() { return dim3(kWave, kBlock / kWave, 1); }
+
+void launch_clean_fov(float *y, Dim3i d, const Affine &M, Dim3i dx, hipStream_t st) {
+  const dim3 grid((d.z + kWave - 1) / kWave, (d.y + 3) / 4, d.x);
+  hipLaunchKernelGGL(k_clean_fov, grid, vblock(), 0, st, y, d, M, (float)dx.x, (float)dx.y,
+                     (float)dx.z);
+}
 static inline int tile_blocks(Dim3i d) {
   // <= 1024 workgroups: each ends with ONE float64 atomic on a single accumulator
   const long long nt = (long long)((d.z + kWave - 1) / kWave) * ((d.y + 3) / 4) * d.x;

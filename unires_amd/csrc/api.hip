@@ -806,6 +806,17 @@ extern "C" int unires_scaling_sums(const float *x, const float *ay, const int32_
   return UNIRES_OK;
 }
 
+extern "C" int unires_clean_fov(float *y, const int32_t dim_y[3], const float M[12],
+                                const int32_t dim_x[3], void *stream) {
+  if (!y || !dim_y || !M || !dim_x) return fail(UNIRES_ERR_NULL, "null argument");
+  if (!dims_ok(dim_y) || !dims_ok(dim_x)) return fail(UNIRES_ERR_DIM, "bad dims");
+  Affine A;
+  memcpy(A.m, M, sizeof(A.m));
+  launch_clean_fov(y, mk(dim_y), A, mk(dim_x), (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
 extern "C" int unires_masked_sse(const float *x, const float *ay, int64_t n, double *out_dev,
                                  void *stream) {
   if (!x || !ay || !out_dev) return fail(UNIRES_ERR_NULL, "null argument");

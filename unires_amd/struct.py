@@ -75,6 +75,12 @@ class settings:
         self.rho = None
         self.rho_scl = 1.0
         self.tolerance = 1e-4
+        self.max_iter = 512
+        self.sched_num = 3
+        self.rigid_mod = 1
+        self.scaling = False
+        self.unified_rigid = False
+        self.clean_fov = False
         self.do_print = 0
         # build-side knob: which nitorch-cg objective branch to reproduce
         # ('max_gain' = what the reference passes, unires/_update.py:145)
