@@ -38,6 +38,10 @@ WORKLOADS = {
     'cfg3_256c3_thick6xyz': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(0, 1, 2)),
     'cfg4_384c4_iso2': dict(dim_y=(384, 384, 384), C=4, thick=2, axes=None),
     'small_96c3_thick3': dict(dim_y=(96, 96, 96), C=3, thick=3, axes=(2, 2, 2)),
+    # BASELINE configs[0] / [1] shapes (BrainWeb 1 mm, 181x217x181) on the synthetic phantom:
+    # single-channel denoising with A = I (R0), 3-channel 1 mm recon after coregistration (R1)
+    'cfg1_181c1_denoise': dict(dim_y=(181, 217, 181), C=1, thick=1, axes=(2,), regime='id'),
+    'cfg2_181c3_1mm': dict(dim_y=(181, 217, 181), C=3, thick=1, axes=(2, 2, 2), regime='dn'),
 }
 
 
@@ -93,16 +97,20 @@ def build_subject(wl, device, seed):
         rigid = rigid_matrix((u[:3] * 5.0).tolist(), (u[3:] * 0.1).tolist())
         if wl.get('rigid') == 'identity':  # grid-aligned observations (no motion between scans)
             rigid = torch.eye(4, dtype=torch.float64)
+        regime = wl.get('regime', 'sr')
+        method = 'super-resolution' if regime == 'sr' else 'denoising'
+        if regime == 'id':
+            rigid = torch.eye(4, dtype=torch.float64)
         po = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=0, prof_tp=0,
                           device=device)
-        clean = U._proj_apply('A', truth[None, None], po)[0, 0]
+        clean = truth if regime == 'id' else U._proj_apply('A', truth[None, None], po, method=method)[0, 0]
         noise = torch.randn(clean.shape, generator=gen).to(device) * sd
         x.append([U._input(clean + noise, mat_x, 1.0 / sd ** 2, po)])
         lam = 4.0 * math.sqrt(1.0 / C) / mus[c]
         y.append(U._output(torch.zeros(dim_y, device=device), mat_y, lam))
         del truth
     sett = U.settings()
-    sett.device, sett.method, sett.do_proj = device, 'super-resolution', True
+    sett.device, sett.method, sett.do_proj = device, method, wl.get('regime', 'sr') != 'id'
     sett.cgs_max_iter, sett.cgs_tol = 20, 0.0  # fixed-iteration mode
     sett.cache_atx = False  # every step re-assembles the full RHS (no work skipped in the timed region)
     rho = float(U._step_size(x, y, sett))
@@ -110,8 +118,11 @@ def build_subject(wl, device, seed):
     return x, y, z, w, rho, sett
 
 
-def alg_bytes_matvec(x_c, dim_y):
+def alg_bytes_matvec(x_c, dim_y, do_proj=True):
+    """B_mv of SURVEY 8(d): 4 (2 N_y + 2 sum N_x) for R1/R2, 4 * 2 N_y for R0 (A = I)."""
     n_y = dim_y[0] * dim_y[1] * dim_y[2]
+    if not do_proj:
+        return 4 * 2 * n_y
     n_x = sum(xn.po.dim_x[0] * xn.po.dim_x[1] * xn.po.dim_x[2] for xn in x_c)
     return 4 * (2 * n_y + 2 * n_x)
 
@@ -179,7 +190,9 @@ def cpu_baseline(wl, seconds_budget=25.0):
     yc = O.make_output(torch.zeros(dim_y), mat_y, torch.tensor(4.0 * math.sqrt(1 / 3.0) / 400.0))
     vx = N.voxel_size(mat_y).float()
     rho = torch.tensor(0.9)
-    lhs = lambda d: O.proj('AtA', d, xc, yc, method='super-resolution', rho=rho, vx_y=vx)
+    regime = wl.get('regime', 'sr')
+    method = 'super-resolution' if regime == 'sr' else 'denoising'
+    lhs = lambda d: O.proj('AtA', d, xc, yc, method=method, do=regime != 'id', rho=rho, vx_y=vx)
     b = torch.rand(dim_y, generator=gen)
     t0 = time.perf_counter()
     lhs(b)  # one matvec to size the sample
@@ -323,7 +336,7 @@ def main():
             U._update_admm(x, y, z, w, rho, tmp, obj, it, sett)
         torch.cuda.synchronize()
         t_admm = (time.perf_counter() - ta) / 3
-        b_mv = alg_bytes_matvec(x[0], wl['dim_y'])
+        b_mv = alg_bytes_matvec(x[0], wl['dim_y'], sett.do_proj)
         achieved = b_mv / t_mv / 1e9
         out = {
             'metric': 'cg_iters_per_sec', 'value': total_iters / elapsed, 'unit': 'cg_iters/s',

@@ -5,6 +5,8 @@
 //   AXIS = -1    : grid-space source (denoising regime, op-level push)
 //   AXIS = 0,1,2 : thick slices along that axis: conv_up along ONE axis, fan-in <= 2
 //                  (every rect profile), regenerated on the fly from x-space
+//   AXIS = 3     : conv_up along all three axes (isotropic down-sampling, BASELINE config 4),
+//                  fan-in <= 2 per axis: 8 x-space values per grid voxel, four 8-byte loads
 //
 // Differences that matter for instruction count (this kernel is issue-bound, not
 // HBM-bound - DESIGN.md 4): one z table instead of three, the two x-space values of a
@@ -28,6 +30,9 @@ struct SplatArgs {
   int nkz, sz;        // taps / stride along the thick axis
   float kz[UNIRES_MAX_TAPS];
   float se, so;       // even/odd slice scaling along the thick axis (1,1 = none)
+  // AXIS == 3 (conv_up along all three axes, e.g. isotropic down-sampling, BASELINE config 4):
+  // per-axis taps live in kz[10 a .. 10 a + 9]
+  int nk3[3], s3[3], xd3[3], sdim;
   Affine A, Ainv;
   float alpha, tol;
   const float *p;
@@ -106,6 +111,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
   __shared__ __align__(16) float acc[N];
   __shared__ __align__(8) Seg rows[kSegs];
   __shared__ __align__(16) float4 ztab[64];  // {bits(k offset), w0, w1, -}
+  __shared__ __align__(16) float4 xytab[AXIS == 3 ? 64 : 1];  // AXIS 3: x table, then y table
   const int lane = threadIdx.x, grp = lane / L, gl = lane & (L - 1);
   const Dim3i dd = P.dd;
   const float *__restrict__ src = P.src;
@@ -151,7 +157,35 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
     const int bz0 = max(0, (int)floorf(lo2 - 0.01f)), bz1 = min(P.gz - 1, (int)ceilf(hi2 + 0.01f));
     const int nby = by1 - by0 + 1;
     const int nrow_cand = max(bx1 - bx0 + 1, 0) * max(nby, 0);
-    if (CONV) {
+    if (AXIS == 3) {
+      // one table per axis: {first x-space slice, weight of it, weight of the next one}
+      auto entry = [&](int u, int nk, int sz, int xdn, int tbase, bool scaled) {
+        const float inv = 1.f / (float)sz;
+        int khi = (int)(((float)u + 0.5f) * inv);
+        if (khi * sz > u) --khi;
+        if ((khi + 1) * sz <= u) ++khi;  // khi = u / sz exactly
+        khi = min(khi, xdn - 1);
+        const int tt = u - nk + 1;
+        int klo = 0;
+        if (tt > 0) {
+          klo = (int)(((float)(tt + sz - 1) + 0.5f) * inv);
+          if (klo * sz > tt + sz - 1) --klo;
+          if ((klo + 1) * sz <= tt + sz - 1) ++klo;  // ceil(tt / sz)
+        }
+        const int n = khi - klo + 1;
+        const float fe = scaled ? P.se : 1.f, fo = scaled ? P.so : 1.f;
+        float w0 = 0.f, w1 = 0.f;
+        if (n >= 1) w0 = P.kz[tbase + u - sz * klo] * ((klo & 1) ? fo : fe);
+        if (n >= 2) w1 = P.kz[tbase + u - sz * (klo + 1)] * (((klo + 1) & 1) ? fo : fe);
+        int koff = n < 1 ? 0 : klo;
+        if (koff > xdn - 2) koff = xdn - 2, w1 = w0, w0 = 0.f;  // last slice: pair (xdn-2, xdn-1)
+        return make_float4(__int_as_float(koff), w0, w1, 0.f);
+      };
+      const int a = lane >> 5, l5 = lane & 31;  // lanes 0..31: x table, 32..63: y table
+      xytab[lane] = entry(min((a ? by0 : bx0) + l5, (a ? P.gy : P.gx) - 1), P.nk3[a], P.s3[a],
+                          P.xd3[a], 10 * a, P.sdim == a);
+      ztab[lane] = entry(min(bz0 + lane, P.gz - 1), P.nk3[2], P.s3[2], P.xd3[2], 20, P.sdim == 2);
+    } else if (CONV) {
       // which x-space slices feed grid slice u = (box start along AXIS) + lane; for AXIS 2 the
       // pair is packed for ONE 8-byte load, else the second slice is one x/y stride away
       const int b0 = AXIS == 0 ? bx0 : (AXIS == 1 ? by0 : bz0);
@@ -259,7 +293,21 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
           act[u] = p < npair && idx < nr && gl < R.len;
           solo[u] = R.solo && grp > 0;
           ui[u] = R.ui, uj[u] = R.uj, uk[u] = min(R.k0 + gl, P.gz - 1);
-          if (AXIS == 2) {
+          if (AXIS == 3) {
+            const float4 tx = xytab[min(max(ui[u] - bx0, 0), 31)];
+            const float4 ty = xytab[32 + min(max(uj[u] - by0, 0), 31)];
+            const float4 tz = ztab[min(uk[u] - bz0, 63)];
+            const unsigned sy = (unsigned)P.xdz, sx = (unsigned)P.xdy * (unsigned)P.xdz;
+            const unsigned base =
+                __umul24(__umul24((unsigned)__float_as_int(tx.x), (unsigned)P.xdy) +
+                             (unsigned)__float_as_int(ty.x), (unsigned)P.xdz) +
+                (unsigned)__float_as_int(tz.x);
+            const float2 p00 = ld2_u(src + base), p01 = ld2_u(src + base + sy),
+                         p10 = ld2_u(src + base + sx), p11 = ld2_u(src + base + sx + sy);
+            const float z00 = tz.y * p00.x + tz.z * p00.y, z01 = tz.y * p01.x + tz.z * p01.y;
+            const float z10 = tz.y * p10.x + tz.z * p10.y, z11 = tz.y * p11.x + tz.z * p11.y;
+            val[u] = tx.y * (ty.y * z00 + ty.z * z01) + tx.z * (ty.y * z10 + ty.z * z11);
+          } else if (AXIS == 2) {
             const float4 tb = ztab[min(uk[u] - bz0, 63)];
             const unsigned base =
                 __umul24(__umul24((unsigned)ui[u], (unsigned)P.xdy) + (unsigned)uj[u],
@@ -498,15 +546,42 @@ int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const 
   if (P.gx > 32000 || P.gy > 32000 || P.gz > 32000) return 1;
   P.xdy = src.xd.y, P.xdz = src.xd.z;
   P.nkz = 1, P.sz = 1, P.se = 1.f, P.so = 1.f;
+  for (int d = 0; d < 3; ++d) P.nk3[d] = 1, P.s3[d] = 1, P.xd3[d] = 2;
+  P.sdim = -1;
   int axis = -1;
   if (src.convup) {
-    // conv_up must act along ONE axis, with at most two x-space slices per grid slice
+    // conv_up along ONE axis (AXIS 0..2) or along several (AXIS 3), with at most two x-space
+    // slices per grid slice and axis
+    int nconv = 0;
     for (int d = 0; d < 3; ++d) {
       const bool dirac = src.T.n[d] == 1 && src.T.s[d] == 1 && src.T.t[d][0] == 1.f;
       if (dirac) continue;
-      if (axis >= 0) return 1;
+      ++nconv;
       axis = d;
     }
+    if (nconv > 1) {
+      const int xdv[3] = {src.xd.x, src.xd.y, src.xd.z};
+      for (int d = 0; d < 3; ++d) {
+        if ((src.T.n[d] + src.T.s[d] - 1) / src.T.s[d] > 2 || xdv[d] < 2 || src.T.n[d] > 10) return 1;
+        P.nk3[d] = src.T.n[d], P.s3[d] = src.T.s[d], P.xd3[d] = xdv[d];
+      }
+      // the x / y tables hold 32 grid slices: the grid-space box of an aproned tile must fit
+      const float ext[3] = {(float)SplatLong::TX + 1.f, (float)SplatLong::TY + 1.f, (float)SplatLong::TZ + 1.f};
+      for (int r = 0; r < 2; ++r) {
+        float e = 3.f;
+        for (int c = 0; c < 3; ++c) e += fabsf(Ainv.m[4 * r + c]) * ext[c];
+        if (e > 30.f) return 1;
+      }
+      for (int i = 0; i < UNIRES_MAX_TAPS; ++i) P.kz[i] = 0.f;
+      for (int d = 0; d < 3; ++d)
+        for (int i = 0; i < src.T.n[d]; ++i) P.kz[10 * d + i] = src.T.t[d][i];
+      P.sdim = src.S.dim;
+      if (src.S.dim >= 0) P.se = src.S.e, P.so = src.S.o;
+      P.xdn = 1;
+      axis = 3;
+    }
+  }
+  if (src.convup && axis != 3) {
     if (axis < 0) axis = 2;  // all dirac: conv_up is the identity, any axis works
     const int xdv[3] = {src.xd.x, src.xd.y, src.xd.z};
     if ((src.T.n[axis] + src.T.s[axis] - 1) / src.T.s[axis] > 2 || xdv[axis] < 2) return 1;
@@ -515,7 +590,7 @@ int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const 
     P.xdn = xdv[axis];
     for (int i = 0; i < UNIRES_MAX_TAPS; ++i) P.kz[i] = src.T.t[axis][i];
     if (src.S.dim == axis) P.se = src.S.e, P.so = src.S.o;
-  } else {
+  } else if (!src.convup) {
     P.xdn = 1;
     for (int i = 0; i < UNIRES_MAX_TAPS; ++i) P.kz[i] = 0.f;
   }
@@ -545,6 +620,8 @@ int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const 
       hipLaunchKernelGGL((k_splat<1, CFG>), grid, dim3(kWave), 0, st, P, done);        \
     else if (axis == 2)                                                                \
       hipLaunchKernelGGL((k_splat<2, CFG>), grid, dim3(kWave), 0, st, P, done);        \
+    else if (axis == 3)                                                                \
+      hipLaunchKernelGGL((k_splat<3, CFG>), grid, dim3(kWave), 0, st, P, done);        \
     else                                                                               \
       hipLaunchKernelGGL((k_splat<-1, CFG>), grid, dim3(kWave), 0, st, P, done);       \
   } while (0)
