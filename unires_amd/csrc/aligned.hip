@@ -241,6 +241,56 @@ bool affine_is_integer_shift(const Affine &A, int off[3]) {
   return true;
 }
 
+// Launches the line kernel for filled-in arguments (npt = 2, 4, 6 or 8 z-passes per line).
+static void launch_lines(AlignedArgs &G, int npt, size_t lds, const int *done, hipStream_t st) {
+  const Dim3i dd = G.dd;
+  const double *partials = G.partials;
+  const float *objb = G.objb;
+  const dim3 grid(aligned_blocks(dd)), block(kWave, kLinesPerBlock);
+#define LAUNCH_ALIGNED(NPV)                                                                  \
+  do {                                                                                       \
+    if (objb)                                                                                \
+      hipLaunchKernelGGL((k_ata_aligned<NPV, true, true>), grid, block, lds, st, G, done);   \
+    else if (partials)                                                                       \
+      hipLaunchKernelGGL((k_ata_aligned<NPV, true, false>), grid, block, lds, st, G, done);  \
+    else                                                                                     \
+      hipLaunchKernelGGL((k_ata_aligned<NPV, false, false>), grid, block, lds, st, G, done); \
+  } while (0)
+  if (npt == 2)
+    LAUNCH_ALIGNED(2);
+  else if (npt == 4)
+    LAUNCH_ALIGNED(4);
+  else if (npt == 6)
+    LAUNCH_ALIGNED(6);
+  else
+    LAUNCH_ALIGNED(8);
+#undef LAUNCH_ALIGNED
+}
+
+// Regime A = I: q = a0 p + c DtD p (+ dot / objective) with the same line kernel (no AtA term).
+// Non-zero return: lines too long for the kernel's LDS budget, nothing launched.
+int launch_dtd_lines(const float *p, float *q, Dim3i dd, float a0, float cx, float cy, float cz,
+                     double *partials, const float *objb, const int *done, hipStream_t st) {
+  if (dd.z > 8 * kWave || (objb && !partials)) return 1;
+  const int np = (dd.z + kWave - 1) / kWave;
+  const int npt = np <= 2 ? 2 : (np <= 4 ? 4 : (np <= 6 ? 6 : 8));
+  AlignedArgs G;
+  G.p = p, G.q = q, G.dd = dd;
+  G.gx = G.gy = G.gz = 0;  // no voxel belongs to a grid: the AtA branch is never taken
+  G.xdz = 1, G.ox = G.oy = G.oz = 0, G.nk = 1, G.s = 1;
+  for (int i = 0; i < kAlignedMaxTaps; ++i) G.kz[i] = 0.f;
+  G.se2 = G.so2 = 1.f;
+  G.tau = 0.f, G.a0 = a0, G.cx = cx, G.cy = cy, G.cz = cz;
+  G.partials = partials, G.objb = objb;
+  G.padl = G.padr = 1;
+  G.wave_floats = 1 + dd.z + 1 + 2;
+  G.prof = nullptr;
+  const size_t lds =
+      ((size_t)4 * npt * kWave + kAlignedMaxTaps + (size_t)kLinesPerBlock * G.wave_floats) * sizeof(float);
+  launch_lines(G, npt, lds, done, st);
+  return 0;
+}
+
 // Non-zero return (nothing launched): outside this kernel's domain.
 int launch_ata_aligned(const float *p, float *q, Dim3i dd, Dim3i gd, Dim3i xd, const Taps &T,
                        const Scaling &S2, const Affine &A, float tau, float a0, float cx,
@@ -284,25 +334,7 @@ int launch_ata_aligned(const float *p, float *q, Dim3i dd, Dim3i gd, Dim3i xd, c
   (void)hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), st);
   G.prof = prof;
 #endif
-  const dim3 grid(aligned_blocks(dd)), block(kWave, kLinesPerBlock);
-#define LAUNCH_ALIGNED(NPV)                                                                  \
-  do {                                                                                       \
-    if (objb)                                                                                \
-      hipLaunchKernelGGL((k_ata_aligned<NPV, true, true>), grid, block, lds, st, G, done);   \
-    else if (partials)                                                                       \
-      hipLaunchKernelGGL((k_ata_aligned<NPV, true, false>), grid, block, lds, st, G, done);  \
-    else                                                                                     \
-      hipLaunchKernelGGL((k_ata_aligned<NPV, false, false>), grid, block, lds, st, G, done); \
-  } while (0)
-  if (npt == 2)
-    LAUNCH_ALIGNED(2);
-  else if (npt == 4)
-    LAUNCH_ALIGNED(4);
-  else if (npt == 6)
-    LAUNCH_ALIGNED(6);
-  else
-    LAUNCH_ALIGNED(8);
-#undef LAUNCH_ALIGNED
+  launch_lines(G, npt, lds, done, st);
 #ifdef UNIRES_ALIGNED_PROF
   {
     unsigned long long h[8];

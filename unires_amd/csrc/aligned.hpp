@@ -14,4 +14,8 @@ int launch_ata_aligned(const float *p, float *q, Dim3i dd, Dim3i gd, Dim3i xd, c
                        float cy, float cz, double *partials, const float *objb, const int *done,
                        hipStream_t st);
 
+// Regime A = I through the same line kernel: q = a0 p + c DtD p (+ partials).
+int launch_dtd_lines(const float *p, float *q, Dim3i dd, float a0, float cx, float cy, float cz,
+                     double *partials, const float *objb, const int *done, hipStream_t st);
+
 }  // namespace unires

@@ -564,6 +564,11 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
   if (pl->regime == UNIRES_REGIME_IDENTITY) {
     float a0 = 0.f;
     for (const Repeat &R : pl->reps) a0 += R.tau;
+    static const bool no_lines = getenv("UNIRES_NO_ALIGNED") != nullptr;
+    if (!no_lines &&
+        !launch_dtd_lines(p, q, pl->dy, a0, c / (pl->vx[0] * pl->vx[0]), c / (pl->vx[1] * pl->vx[1]),
+                          c / (pl->vx[2] * pl->vx[2]), part, objb, done, st))
+      return part ? aligned_blocks(pl->dy) : 0;
     launch_dtd(p, pl->dy, pl->vx, a0, c, q, part, objb, done, st);
     return part ? dtd_num_blocks(pl->dy) : 0;
   }
