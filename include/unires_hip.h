@@ -77,6 +77,12 @@ int unires_abi_version(void);
 int unires_pull3d_affine(const float *src, const int32_t sdim[3], const float M[12], float *dst,
                          const int32_t gdim[3], float fov_tol, void *stream);
 
+/* nitorch grid_grad(src, affine_grid(M, gdim), 'linear', bound='zero', extrapolate=False)
+ * (_update.py:508, the rigid Gauss-Newton's spatial derivatives): gradient of the trilinear
+ * sample w.r.t. the voxel coordinate; dst3 is (gdim, 3), component fastest. */
+int unires_pull_grad3d_affine(const float *src, const int32_t sdim[3], const float M[12],
+                              float *dst3, const int32_t gdim[3], float fov_tol, void *stream);
+
 /* nitorch grid_push(src, affine_grid(M, gdim), shape=ddim, ...)
  * (_project.py:172,179,185,188): dst (+)= alpha * push(src).
  * accumulate == 0 overwrites dst. */

@@ -106,6 +106,41 @@ def grid_pull(inp, grid, interpolation='linear', bound='zero', extrapolate=False
     return torch.stack(out)
 
 
+def grid_grad(inp, grid, interpolation='linear', bound='zero', extrapolate=False,
+              fov_tol=FOV_TOL):
+    """Spatial gradient of the trilinear sample w.r.t. the voxel coordinate  [recalled]:
+    (B, C, X', Y', Z', 3).  Out-of-volume corners count as zeros; with extrapolate=False the
+    in-FOV mask multiplies the result (call site unires/_update.py:508)."""
+    if interpolation not in ('linear', 1) or bound != 'zero':
+        raise NotImplementedError('oracle restates linear/zero only')
+    B, C = inp.shape[:2]
+    shape = inp.shape[2:]
+    nx, ny, nz = shape
+    out = []
+    for b in range(B):
+        g = grid[b if grid.shape[0] > 1 else 0]
+        gx, gy, gz = g.unbind(-1)
+        x0, x1, wx, okx0, okx1 = _corners(gx, nx)
+        y0, y1, wy, oky0, oky1 = _corners(gy, ny)
+        z0, z1, wz, okz0, okz1 = _corners(gz, nz)
+        src = inp[b].reshape(C, -1)
+        acc = torch.zeros((C,) + gx.shape + (3,), dtype=inp.dtype)
+        one = torch.ones_like(wx)
+        for (ix, wxx, dxx, okx) in ((x0, 1 - wx, -one, okx0), (x1, wx, one, okx1)):
+            for (iy, wyy, dyy, oky) in ((y0, 1 - wy, -one, oky0), (y1, wy, one, oky1)):
+                for (iz, wzz, dzz, okz) in ((z0, 1 - wz, -one, okz0), (z1, wz, one, okz1)):
+                    idx = (ix * ny + iy) * nz + iz
+                    ok = (okx & oky & okz).to(inp.dtype)
+                    v = src[:, idx.reshape(-1)].reshape((C,) + gx.shape) * ok
+                    acc[..., 0] += v * (dxx * wyy * wzz)
+                    acc[..., 1] += v * (wxx * dyy * wzz)
+                    acc[..., 2] += v * (wxx * wyy * dzz)
+        if not extrapolate:
+            acc = acc * _fov_mask(g, shape, fov_tol).to(inp.dtype)[..., None]
+        out.append(acc)
+    return torch.stack(out)
+
+
 def grid_push(inp, grid, shape, interpolation='linear', bound='zero', extrapolate=False,
               fov_tol=FOV_TOL):
     """Exact adjoint of grid_pull w.r.t. its input (scatter-add of 8 corners).

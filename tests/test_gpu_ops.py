@@ -45,6 +45,32 @@ def test_pull_and_push(dev, name, sdim, gdim):
     assert (outp - refp).abs().max() <= 2e-5 * max(1.0, refp.abs().max().item())
 
 
+@pytest.mark.parametrize('name', list(_affines()))
+@pytest.mark.parametrize('sdim,gdim', [((12, 10, 9), (11, 12, 10)), ((5, 70, 131), (6, 66, 140))])
+def test_grid_grad(dev, name, sdim, gdim):
+    """nitorch grid_grad (spatial derivatives of the trilinear pull; unires/_update.py:508):
+    HIP vs the oracle, and the oracle vs a central finite difference of grid_pull."""
+    from unires_amd import spatial
+    torch.manual_seed(1)
+    M = _affines()[name]
+    src = torch.rand((1, 1) + sdim)
+    g = N.affine_grid(M.float(), gdim)[None]
+    ref = N.grid_grad(src, g)
+    out = spatial.grid_grad(src.to(dev), M, gdim).cpu()
+    assert out.shape == ref.shape == (1, 1) + gdim + (3,)
+    assert (out - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
+    if name == 'small_rigid':  # oracle pin: derivative of its own grid_pull away from cell borders
+        h = 1e-2
+        frac = g - g.floor()
+        inner = ((frac > 0.05) & (frac < 0.95)).all(-1) & (N.grid_pull(torch.ones_like(src), g)[0, 0] > 0.999)
+        for d in range(3):
+            e = torch.zeros(3)
+            e[d] = h
+            gd_, ed_ = g.double(), e.double()
+            fd = (N.grid_pull(src.double(), gd_ + ed_) - N.grid_pull(src.double(), gd_ - ed_)) / (2 * h)
+            assert (fd[0, 0][inner[0]] - ref[0, 0, ..., d][inner[0]]).abs().max() < 2e-5
+
+
 @pytest.mark.parametrize('rot', [(0, 0, 0), (0.02, -0.01, 0.03), (0.1, 0.1, -0.1), (0.0, 0.25, 0.0),
                                  (0.3, 0.0, 0.0), (-0.2, 0.15, 0.5), (0.9, 0.0, 0.0)])
 @pytest.mark.parametrize('scale', [1.0, 0.93, 1.21])

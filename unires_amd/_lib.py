@@ -34,6 +34,8 @@ SIGNATURES = {
     'unires_abi_version': (C.c_int, []),
     'unires_pull3d_affine': (C.c_int, [C.c_void_p, c_i32x3, c_f32x12, C.c_void_p, c_i32x3,
                                        C.c_float, C.c_void_p]),
+    'unires_pull_grad3d_affine': (C.c_int, [C.c_void_p, c_i32x3, c_f32x12, C.c_void_p, c_i32x3,
+                                            C.c_float, C.c_void_p]),
     'unires_push3d_affine': (C.c_int, [C.c_void_p, c_i32x3, c_f32x12, C.c_void_p, c_i32x3,
                                        C.c_float, C.c_float, C.c_int, C.c_void_p]),
     'unires_conv_down3d': (C.c_int, [C.c_void_p, c_i32x3, c_fptrx3, c_i32x3, c_i32x3, C.c_void_p,

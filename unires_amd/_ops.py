@@ -47,6 +47,15 @@ def pull_affine(src, M, gdim, fov_tol=FOV_TOL):
     return out.reshape(lead + tuple(gdim))
 
 
+def pull_grad_affine(src, M, gdim, fov_tol=FOV_TOL):
+    """grid_grad(src, affine_grid(M, gdim)) -> (gdim, 3): spatial gradient of the trilinear sample."""
+    s, lead = _vol(src, 'src')
+    out = torch.empty(tuple(gdim) + (3,), dtype=torch.float32, device=s.device)
+    check(_lib.load().unires_pull_grad3d_affine(_ptr(s), i3(s.shape), f12(M), _ptr(out), i3(gdim),
+                                                fov_tol, _stream()))
+    return out.reshape(lead + tuple(gdim) + (3,))
+
+
 def push_affine(src, M, ddim, alpha=1.0, out=None, fov_tol=FOV_TOL):
     """grid_push(src, affine_grid(M, src.shape), shape=ddim); out += if given."""
     s, lead = _vol(src, 'src')

@@ -138,6 +138,18 @@ extern "C" int unires_pull3d_affine(const float *src, const int32_t sdim[3], con
   return UNIRES_OK;
 }
 
+extern "C" int unires_pull_grad3d_affine(const float *src, const int32_t sdim[3], const float M[12],
+                                         float *dst3, const int32_t gdim[3], float fov_tol,
+                                         void *stream) {
+  if (!src || !dst3 || !sdim || !gdim || !M) return fail(UNIRES_ERR_NULL, "null argument");
+  if (!dims_ok(sdim) || !dims_ok(gdim)) return fail(UNIRES_ERR_DIM, "bad dimensions");
+  Affine A;
+  memcpy(A.m, M, sizeof(A.m));
+  launch_pull_grad(src, mk(sdim), A, dst3, mk(gdim), fov_tol, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
 extern "C" int unires_push3d_affine(const float *src, const int32_t gdim[3], const float M[12],
                                     float *dst, const int32_t ddim[3], float alpha, float fov_tol,
                                     int accumulate, void *stream) {

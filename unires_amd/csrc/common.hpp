@@ -135,6 +135,33 @@ __device__ __forceinline__ float pull_finish(const PullLoads &L) {
   return acc;
 }
 
+// Spatial gradient of the trilinear sample w.r.t. the voxel coordinate (nitorch grid_grad,
+// linear / zero bound / extrapolate=False: out-of-volume corners count as zeros, the in-FOV
+// mask multiplies the result; call site unires/_update.py:508).  d/dx of sum v wx wy wz is
+// sum v (+-1) wy wz with the same validity rules as the weights.
+__device__ __forceinline__ void pull_grad_sample(const float *__restrict__ src, const Dim3i &sd,
+                                                 float gx, float gy, float gz, float tol,
+                                                 float &dx, float &dy, float &dz) {
+  PullLoads L;
+  pull_issue(src, sd, gx, gy, gz, tol, L);  // L.wx* carry the FOV mask
+  const int ix = (int)floorf(gx), iy = (int)floorf(gy), iz = (int)floorf(gz);
+  const float m = in_fov(gx, gy, gz, sd, tol) ? 1.f : 0.f;
+  const float ax0 = (ix >= 0 && ix < sd.x) ? -m : 0.f, ax1 = (ix + 1 >= 0 && ix + 1 < sd.x) ? m : 0.f;
+  const float ay0 = (iy >= 0 && iy < sd.y) ? -1.f : 0.f, ay1 = (iy + 1 >= 0 && iy + 1 < sd.y) ? 1.f : 0.f;
+  const float bz0 = (iz >= 0 && iz < sd.z) ? -1.f : 0.f, bz1 = (iz + 1 >= 0 && iz + 1 < sd.z) ? 1.f : 0.f;
+  const int b = min(max(iz, 0), max(sd.z - 2, 0));  // same pair remap as pull_issue
+  const float az0 = iz == b ? bz0 : (iz == b - 1 ? bz1 : 0.f);
+  const float az1 = iz == b ? bz1 : (iz == b + 1 ? bz0 : 0.f);
+  // z-interpolated / z-differentiated values of the four (x,y) rows
+  const float s00 = L.v00.x * L.wz0 + L.v00.y * L.wz1, s01 = L.v01.x * L.wz0 + L.v01.y * L.wz1;
+  const float s10 = L.v10.x * L.wz0 + L.v10.y * L.wz1, s11 = L.v11.x * L.wz0 + L.v11.y * L.wz1;
+  const float d00 = L.v00.x * az0 + L.v00.y * az1, d01 = L.v01.x * az0 + L.v01.y * az1;
+  const float d10 = L.v10.x * az0 + L.v10.y * az1, d11 = L.v11.x * az0 + L.v11.y * az1;
+  dx = ax0 * (s00 * L.wy0 + s01 * L.wy1) + ax1 * (s10 * L.wy0 + s11 * L.wy1);
+  dy = L.wx0 * (s00 * ay0 + s01 * ay1) + L.wx1 * (s10 * ay0 + s11 * ay1);
+  dz = L.wx0 * (d00 * L.wy0 + d01 * L.wy1) + L.wx1 * (d10 * L.wy0 + d11 * L.wy1);
+}
+
 // Interior fast path: all 8 corners inside the volume (so also inside the FOV): no
 // clamps, no masks, 32-bit offsets, lerp form (~46 VALU per sample vs ~140).
 __device__ __forceinline__ float2 ld2_u(const float *p) {

@@ -240,6 +240,24 @@ void launch_pull(const float *src, Dim3i sd, const Affine &A, float *dst, Dim3i 
   hipLaunchKernelGGL(k_pull, grid, vol_block(), 0, st, src, sd, A, dst, gd, tol, done);
 }
 
+// dst[(i,j,k), 0..2] = gradient of the trilinear sample at A (i,j,k)  (nitorch grid_grad layout)
+__global__ void __launch_bounds__(kBlock) k_pull_grad(const float *__restrict__ src, Dim3i sd,
+                                                      Affine A, float *__restrict__ dst, Dim3i gd,
+                                                      float tol) {
+  const int k = blockIdx.x * kWave + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
+  if (k >= gd.z || j >= gd.y) return;
+  float gx, gy, gz, dx, dy, dz;
+  affine_point(A, (float)i, (float)j, (float)k, gx, gy, gz);
+  pull_grad_sample(src, sd, gx, gy, gz, tol, dx, dy, dz);
+  float *o = dst + (((size_t)i * gd.y + j) * gd.z + k) * 3;
+  o[0] = dx, o[1] = dy, o[2] = dz;
+}
+
+void launch_pull_grad(const float *src, Dim3i sd, const Affine &A, float *dst, Dim3i gd, float tol,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(k_pull_grad, vol_grid(gd), vol_block(), 0, st, src, sd, A, dst, gd, tol);
+}
+
 void launch_push(const float *src, Dim3i gd, const Affine &A, float *dst, Dim3i dd, float alpha,
                  float tol, const int *done, hipStream_t st) {
   Taps T{};

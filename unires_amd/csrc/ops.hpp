@@ -19,6 +19,8 @@ void launch_grad(const float *src, Dim3i d, const float vx[3], float *dst3, hipS
 // dst = [add +] scale * Dt(ca*ua + cb*ub)   (ub, add may be NULL)
 void launch_div(const float *ua, const float *ub, float ca, float cb, Dim3i d, const float vx[3],
                 float scale, const float *add, float *dst, hipStream_t st);
+void launch_pull_grad(const float *src, Dim3i sd, const Affine &A, float *dst, Dim3i gd, float tol,
+                      hipStream_t st);
 int dtd_num_blocks(Dim3i d);
 // dst = a*src + c*DtD(src); partials (nullable, dtd_num_blocks doubles) gets sum(src*dst) pieces;
 // with objb (needs partials): partials = sum (dst - 2 objb) * src and dst is not stored.

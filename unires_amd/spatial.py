@@ -30,6 +30,12 @@ def grid_pull(input, mat, shape, interpolation='linear', bound='zero', extrapola
     return _ops.pull_affine(input, _m12(mat), shape)
 
 
+def grid_grad(input, mat, shape, interpolation='linear', bound='zero', extrapolate=False):
+    """nitorch grid_grad(input, affine_grid(mat, shape), ...) -> (..., *shape, 3)."""
+    _only_linear_zero(interpolation, bound, extrapolate)
+    return _ops.pull_grad_affine(input, _m12(mat), shape)
+
+
 def grid_push(input, mat, shape, interpolation='linear', bound='zero', extrapolate=False):
     """nitorch grid_push(input, affine_grid(mat, input.shape[-3:]), shape=shape, ...)."""
     _only_linear_zero(interpolation, bound, extrapolate)
