@@ -219,6 +219,15 @@ int unires_nll_prior(const float *const *y_ptrs, const float *lam, int32_t n_cha
 /* sum_{x != 0} (x - ay)^2 in float64  (_update.py:414-417; the caller multiplies by tau/2). */
 int unires_masked_sse(const float *x, const float *ay, int64_t n, double *out_dev, void *stream);
 
+/* Gradient and Hessian sums of one rigid Gauss-Newton step (_update_rigid_channel,
+ * _update.py:622-650) in one pass over the grid: gr3 (dim,3) = grid_grad of the pulled image,
+ * diff (dim) = residual (conv_transposed, _update.py:524), ctc (dim) = conv_transpose(conv(1))
+ * or NULL, d_rigid = the six 3x4 matrices mat_y^-1 dR/dq_i mat (row-major, float32).
+ * out_dev (27 float64, device): [0..5] gradient, [6..26] upper triangle of the 6x6 Hessian,
+ * row by row. */
+int unires_rigid_sums(const float *gr3, const float *diff, const float *ctc, const int32_t dim[3],
+                      const float d_rigid[72], double *out_dev, void *stream);
+
 /* fit()'s clean_fov post-processing (run.py:150-164): y[v] = 0 where the voxel M v of the
  * low-resolution image lies outside [0, dim_x) on any axis; M (12 floats, row-major 3x4) =
  * float32 of inv(mat_y^-1 rigid mat_x).  Call once per observation. */

@@ -402,7 +402,8 @@ def get_sched(N, reg_scl=4.0, sched_num=3):
 
 
 def fit(x, y, method, do_proj, max_iter=512, tolerance=1e-4, reg_scl=4.0, sched_num=3,
-        scaling=False, cgs_max_iter=20, cgs_tol=1e-3, alpha=1.0):
+        scaling=False, cgs_max_iter=20, cgs_tol=1e-3, alpha=1.0, unified_rigid=False,
+        rigid_mod=1, rigid_basis=None):
     """The iteration loop of fit() (run.py:56-143) on in-memory structs: lambda scaling,
     rho, ADMM iterations, convergence countdowns, optional scaling update, coarse-to-fine
     switch.  y[c].lam0 must hold the unscaled regularisation.  Returns (y, obj, n_iter, sched)."""
@@ -435,6 +436,9 @@ def fit(x, y, method, do_proj, max_iter=512, tolerance=1e-4, reg_scl=4.0, sched_
             countdown0 = 6
         if scaling:
             x, _ = update_scaling(x, y, method=method, max_niter_gn=1, num_linesearch=6)  # :119
+        if unified_rigid and n_iter > 0 and (n_iter % rigid_mod) == 0:              # :127-132
+            x, _ = update_rigid(x, y, method, rigid_basis, mean_correct=False, max_niter_gn=1,
+                                num_linesearch=6)
         if cnt_scl + 1 < len(sched) and cnt_scl_iter > 16 and gain.abs() < 1e-3:   # :139
             countdown1 -= 1
             if countdown1 == 0:
@@ -447,3 +451,161 @@ def fit(x, y, method, do_proj, max_iter=512, tolerance=1e-4, reg_scl=4.0, sched_
             countdown1 = 6
         cnt_scl_iter += 1
     return y, obj[:n_done], n_done, sched
+
+
+# --------------------------------------------------------------------------
+# unires/_update.py:198-266, 448-538, 541-710  (unified rigid registration)
+# --------------------------------------------------------------------------
+def affine_basis_se3():
+    """A basis of se(3), (6,4,4) float64  [nitorch affine_basis('SE') recalled: translations,
+    then rotations].  Deliberately NOT the product's ordering / signs: rigid matrices and
+    log-likelihoods of a Gauss-Newton step do not depend on the basis (only q does), and the
+    parity tests check exactly that."""
+    B = torch.zeros(6, 4, 4, dtype=torch.float64)
+    for d in range(3):
+        B[d, d, 3] = 1.0
+    B[3, 0, 1], B[3, 1, 0] = 1.0, -1.0
+    B[4, 0, 2], B[4, 2, 0] = 1.0, -1.0
+    B[5, 1, 2], B[5, 2, 1] = 1.0, -1.0
+    return B
+
+
+def expm(q, basis, grad_X=False):
+    """expm(sum q_i B_i) and, optionally, its derivative w.r.t. every q_i: (num_q, 4, 4)."""
+    f = lambda v: torch.linalg.matrix_exp(torch.einsum('i,ijk->jk', v, basis))
+    R = f(q)
+    if not grad_X:
+        return R
+    with torch.enable_grad():
+        J = torch.autograd.functional.jacobian(f, q)
+    return R, J.permute(2, 0, 1)
+
+
+def rigid_match(dat_x, dat_y, po, tau, rigid, method, CtC=None, diff=False):
+    """_rigid_match (:448-538): ll, gr (dim,3), Hes (dim,6)."""
+    import torch.nn.functional as F
+    from .nitorch_restated import affine_grid, grid_grad, grid_pull
+    if method == 'super-resolution':
+        dim, mat = tuple(po.dim_yx), po.mat_yx
+    else:
+        dim, mat = tuple(po.dim_x), po.mat_x
+    mat = torch.linalg.solve(po.mat_y, rigid.mm(mat))                              # :498
+    grid = affine_grid(mat.type(torch.float32), dim)
+    dat_yx = grid_pull(dat_y, grid[None], bound='zero', extrapolate=False)[0, 0]   # :502
+    if method == 'super-resolution':
+        dat_yx = F.conv3d(dat_yx[None, None], po.smo_ker, stride=po.ratio)[0, 0]
+        if po.scl != 0:
+            dat_yx = apply_scaling(dat_yx[None, None], po.scl, po.dim_thick)[0, 0]
+    gr = Hes = None
+    if diff:
+        gr = grid_grad(dat_y, grid[None], bound='zero', extrapolate=False)[0, 0]   # :508
+    msk = dat_x != 0
+    ll = 0.5 * tau * torch.sum((dat_x[msk] - dat_yx[msk]) ** 2, dtype=torch.float64)
+    if diff:
+        d = dat_yx - dat_x
+        msk = msk & (dat_yx != 0)
+        d[~msk] = 0
+        Hes = torch.zeros(dim + (6,), dtype=torch.float32)
+        Hes[..., 0] = gr[..., 0] * gr[..., 0]
+        Hes[..., 1] = gr[..., 1] * gr[..., 1]
+        Hes[..., 2] = gr[..., 2] * gr[..., 2]
+        Hes[..., 3] = gr[..., 0] * gr[..., 1]
+        Hes[..., 4] = gr[..., 0] * gr[..., 2]
+        Hes[..., 5] = gr[..., 1] * gr[..., 2]
+        if method == 'super-resolution':
+            Hes = Hes * CtC[..., None]
+            d = F.conv_transpose3d(d[None, None], po.smo_ker, stride=po.ratio)[0, 0]   # :524
+        gr = gr * d[..., None]
+    return ll, gr, Hes
+
+
+def update_rigid_channel(xc, yc, method, basis, max_niter_gn=1, num_linesearch=4):
+    """_update_rigid_channel (:541-710) for D_x = I (samp / voxel size < 1.5: the
+    nearest-neighbour resample of the data is a copy, :589-601); xc[n].po is used where the
+    reference rebuilds an identical one (:575-578)."""
+    import torch.nn.functional as F
+    from .nitorch_restated import affine_grid
+    num_q = basis.shape[0]
+    lkp = [[0, 3, 4], [3, 1, 5], [4, 5, 2]]
+    one = torch.tensor(1.0, dtype=torch.float64)
+    sll = torch.tensor(0, dtype=torch.float64)
+    for n_x in range(len(xc)):
+        dat_x = xc[n_x].dat
+        q = xc[n_x].rigid_q.clone()
+        tau = xc[n_x].tau
+        armijo = torch.tensor(1, dtype=q.dtype)
+        po = xc[n_x].po
+        if method == 'super-resolution':
+            dim, mat = tuple(po.dim_yx), po.mat_yx
+        else:
+            dim, mat = tuple(po.dim_x), po.mat_x
+        dat_y = yc.dat[None, None]
+        CtC = None
+        if method == 'super-resolution':
+            CtC = F.conv3d(torch.ones((1, 1) + dim), po.smo_ker, stride=po.ratio)
+            CtC = F.conv_transpose3d(CtC, po.smo_ker, stride=po.ratio)[0, 0]         # :603-607
+        id_x = affine_grid(torch.eye(4), dim)                                       # :610
+        ll = torch.tensor(0, dtype=torch.float64)
+        rigid = expm(q, basis)
+        for _gn in range(max_niter_gn):
+            rigid, d_rigid = expm(q, basis, grad_X=True)
+            d_rigid_q = torch.zeros(4, 4, num_q, dtype=torch.float64)
+            for i in range(num_q):
+                d_rigid_q[:, :, i] = torch.linalg.solve(po.mat_y, d_rigid[i].mm(mat))   # :622
+            gr = torch.zeros(num_q, 1, dtype=torch.float64)
+            Hes = torch.zeros(num_q, num_q, dtype=torch.float64)
+            ll, gr_m, Hes_m = rigid_match(dat_x, dat_y, po, tau, rigid, method, CtC=CtC, diff=True)
+            dAff = []
+            for i in range(num_q):
+                dAff.append([])
+                for d in range(3):
+                    dAff[i].append(d_rigid_q[d, 0, i] * id_x[..., 0] + d_rigid_q[d, 1, i] * id_x[..., 1]
+                                   + d_rigid_q[d, 2, i] * id_x[..., 2] + d_rigid_q[d, 3, i])
+            for d in range(3):
+                for i in range(num_q):
+                    gr[i] += torch.sum(gr_m[..., d] * dAff[i][d], dtype=torch.float64)
+            for d1 in range(3):
+                for d2 in range(3):
+                    for i1 in range(num_q):
+                        tmp1 = Hes_m[..., lkp[d1][d2]] * dAff[i1][d1]
+                        for i2 in range(i1, num_q):
+                            Hes[i1, i2] += torch.sum(tmp1 * dAff[i2][d2], dtype=torch.float64)
+            for i1 in range(num_q):
+                for i2 in range(i1 + 1, num_q):
+                    Hes[i2, i1] = Hes[i1, i2]
+            Update = torch.linalg.solve(Hes, gr)[:, 0]                               # :660
+            old_ll, old_q, old_rigid = ll.clone(), q.clone(), rigid.clone()
+            if num_linesearch == 0:
+                q = old_q - armijo * Update
+                rigid = expm(q, basis)
+            else:
+                for _ls in range(num_linesearch):
+                    q = old_q - armijo * Update
+                    rigid = expm(q, basis)
+                    ll = rigid_match(dat_x, dat_y, po, tau, rigid, method)[0]
+                    if ll < old_ll:
+                        armijo = torch.min(1.25 * armijo, one)
+                        break
+                    ll, q, rigid = old_ll, old_q, old_rigid
+                    armijo = armijo * 0.5
+        xc[n_x].rigid_q = q
+        xc[n_x].po.rigid = rigid
+        sll = sll + ll
+    return xc, sll
+
+
+def update_rigid(x, y, method, basis, mean_correct=True, max_niter_gn=1, num_linesearch=4):
+    """_update_rigid (:198-266)."""
+    sll = torch.tensor(0, dtype=torch.float64)
+    for c in range(len(x)):
+        x[c], sllc = update_rigid_channel(x[c], y[c], method, basis, max_niter_gn=max_niter_gn,
+                                          num_linesearch=num_linesearch)
+        sll = sll + sllc
+    if mean_correct:
+        qs = [xn.rigid_q for xc in x for xn in xc]
+        mean_q = torch.stack(qs).sum(0) / float(len(qs))
+        for xc in x:
+            for xn in xc:
+                xn.rigid_q = xn.rigid_q - mean_q
+                xn.po.rigid = expm(xn.rigid_q, basis)
+    return x, sll

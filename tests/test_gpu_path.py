@@ -445,3 +445,103 @@ def test_fit_loop_matches_oracle(dev):
         ref[~keep] = 0
         assert (~keep).any()
         assert rel_err(dat[..., c].cpu(), ref) < 2e-3
+
+
+def _rigid_setup(prob, dev, perturb=0.02):
+    """Observations consistent with po.rigid; the registration then starts from a slightly
+    wrong rigid (both sides express the same start matrix in their own se(3) basis)."""
+    import unires_amd as U
+    from unires_amd._rigid import _logq
+    xo, yo = oracle_structs(prob)
+    xg, yg, sett = gpu_structs(prob, dev)
+    Bo, Bg = O.affine_basis_se3(), U.affine_basis('SE')
+    sett.rigid_basis = Bg
+    g = torch.Generator().manual_seed(9)
+    for c in range(len(xo)):
+        yo[c].dat = prob['truth'][c].clone().float()
+        yg[c].dat = yo[c].dat.clone().to(dev)
+        for n in range(len(xo[c])):
+            dq = (torch.rand(6, generator=g, dtype=torch.float64) * 2 - 1) * perturb
+            dq[:3] *= 20  # translations in mm
+            start = xo[c][n].po.rigid.mm(O.expm(dq, Bo))
+            for xs, B in ((xo, Bo), (xg, Bg)):
+                xs[c][n].rigid_q = _logq(start, B)
+                xs[c][n].po.rigid = start.clone()
+    return xo, yo, xg, yg, sett, Bo
+
+
+@pytest.mark.parametrize('case', ['sr_3ch_axes', 'dn_2ch'])
+def test_rigid_match_terms(dev, case):
+    """_rigid_match (unires/_update.py:448-538): ll, gradient and Hessian volumes."""
+    import unires_amd as U
+    prob = make_problem(seed=51, **CASES[case])
+    xo, yo, xg, yg, sett, Bo = _rigid_setup(prob, dev)
+    method = prob['method']
+    for c in range(len(xo)):
+        po_o, po_g = xo[c][0].po, xg[c][0].po
+        rigid = po_o.rigid
+        CtC_o = CtC_g = None
+        if method == 'super-resolution':
+            import torch.nn.functional as F
+            dim = tuple(po_o.dim_yx)
+            CtC_o = F.conv_transpose3d(F.conv3d(torch.ones((1, 1) + dim), po_o.smo_ker, stride=po_o.ratio),
+                                       po_o.smo_ker, stride=po_o.ratio)[0, 0]
+            from unires_amd._rigid import _ctc
+            CtC_g = _ctc(po_g, dim, dev)
+            assert rel_err(CtC_g.cpu(), CtC_o) < 1e-5
+        ll_o, gr_o, H_o = O.rigid_match(xo[c][0].dat, yo[c].dat[None, None], po_o, xo[c][0].tau, rigid,
+                                        method, CtC=CtC_o, diff=True)
+        ll_g, gr_g, H_g = U._rigid_match(xg[c][0].dat, yg[c].dat, po_g, xg[c][0].tau, rigid, sett,
+                                         CtC=CtC_g, diff=True)
+        assert abs(ll_g.item() - ll_o.item()) < 2e-5 * abs(ll_o.item())
+        assert rel_err(gr_g.cpu(), gr_o) < 5e-5 and rel_err(H_g.cpu(), H_o) < 5e-5
+
+
+@pytest.mark.parametrize('case', ['sr_3ch_axes', 'dn_2ch', 'sr_2rep'])
+def test_update_rigid_matches_oracle(dev, case):
+    """Unified rigid Gauss-Newton (unires/_update.py:198-266, 541-710): the oracle works in a
+    different se(3) basis than the product - the rigid matrices and log-likelihoods agree."""
+    import unires_amd as U
+    prob = make_problem(seed=52, **CASES[case])
+    xo, yo, xg, yg, sett, Bo = _rigid_setup(prob, dev)
+    start = [[xn.po.rigid.clone() for xn in xc] for xc in xo]
+    xo, sll_o = O.update_rigid(xo, yo, prob['method'], Bo, mean_correct=True, max_niter_gn=2,
+                               num_linesearch=4)
+    xg, sll_g = U._update_rigid(xg, yg, sett, mean_correct=True, max_niter_gn=2, num_linesearch=4,
+                                samp=1)
+    assert abs(sll_g.item() - sll_o.item()) < 1e-3 * abs(sll_o.item())
+    moved = 0.0
+    for c in range(len(xo)):
+        for n in range(len(xo[c])):
+            Ro, Rg = xo[c][n].po.rigid, xg[c][n].po.rigid
+            assert (Rg - Ro).abs().max() < 2e-3 * max(1.0, Ro[:3, 3].abs().max().item()), (c, n)
+            assert torch.allclose(U._expm(xg[c][n].rigid_q, sett.rigid_basis), Rg)
+            moved = max(moved, (Ro - start[c][n]).abs().max().item())
+    assert moved > 1e-3
+
+
+def test_fit_with_rigid_and_scaling_updates(dev):
+    """fit() with unified_rigid and scaling switched on (run.py:115-132): five iterations of
+    ADMM + slice-scaling GN + rigid GN, GPU driver vs oracle."""
+    import unires_amd as U
+    prob = make_problem(seed=53, **CASES['sr_2rep'])
+    xo, yo, xg, yg, sett, Bo = _rigid_setup(prob, dev, perturb=0.01)
+    for c in range(len(yo)):
+        yo[c].dat = prob['y0'][c].clone()
+        yg[c].dat = prob['y0'][c].clone().to(dev)
+        yo[c].lam0 = yo[c].lam / 4.0
+        yg[c].lam0 = float(yg[c].lam) / 4.0
+    sett.max_iter, sett.tolerance, sett.reg_scl, sett.sched_num = 5, 1e-4, 4.0, 3
+    sett.unified_rigid, sett.scaling, sett.rigid_samp = True, True, 1
+    y_ref, obj_ref, n_ref, sched = O.fit(xo, yo, prob['method'], prob['do_proj'], max_iter=5,
+                                         scaling=True, unified_rigid=True, rigid_basis=Bo)
+    dat, mat, R, info = U.fit(xg, yg, sett)
+    assert info['n_iter'] == n_ref == 5
+    assert torch.allclose(info['obj'], obj_ref, rtol=2e-3)
+    k = 0
+    for c in range(len(xo)):
+        for n in range(len(xo[c])):
+            assert (R[k] - xo[c][n].po.rigid).abs().max() < 5e-3
+            assert abs(float(xg[c][n].po.scl) - float(xo[c][n].po.scl)) < 1e-4
+            k += 1
+        assert rel_err(dat[..., c].cpu(), y_ref[c].dat) < 5e-3

@@ -14,6 +14,9 @@ from ._update import (_admm_aux, _compute_nll, _precond, _step_size, _update_adm
 
 from .run import fit, _get_sched  # noqa: F401,E402
 from ._util import _read_image, _write_image  # noqa: F401,E402
+from ._rigid import (_expm, _rigid_match, _update_rigid, _update_rigid_channel,  # noqa: F401,E402
+                     affine_basis)
 
-__all__ = ['fit', '_get_sched', '_read_image', '_write_image', '_input', '_output', '_proj_op', 'settings', '_proj_info', '_proj_apply', '_proj',
+__all__ = ['fit', '_get_sched', '_update_rigid', '_update_rigid_channel', '_rigid_match', '_expm',
+           'affine_basis', '_read_image', '_write_image', '_input', '_output', '_proj_op', 'settings', '_proj_info', '_proj_apply', '_proj',
            '_DtD', '_apply_scaling', '_check_adjoint', '_update_admm', '_update_y', '_update_zw', '_compute_nll', '_step_size', '_admm_aux', '_init_y_dat', '_precond', '_update_scaling']

@@ -72,6 +72,8 @@ SIGNATURES = {
                                    c_f32x3, C.c_void_p, C.c_void_p]),
     'unires_scaling_sums': (C.c_int, [C.c_void_p, C.c_void_p, c_i32x3, C.c_int32, C.c_void_p,
                                       C.c_void_p]),
+    'unires_rigid_sums': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i32x3, C.c_float * 72,
+                                    C.c_void_p, C.c_void_p]),
     'unires_clean_fov': (C.c_int, [C.c_void_p, c_i32x3, c_f32x12, c_i32x3, C.c_void_p]),
     'unires_masked_sse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }

@@ -32,9 +32,6 @@ def _proj_info(dim_y, mat_y, dim_x, mat_x, rigid=None, prof_ip=0, prof_tp=0, gap
                device='cuda', scl=0.0, samp=0, gauss_lim=None):
     """Define a projection operator object for _proj_apply.  All 4x4 arithmetic is
     float64 on the host (it is set-up work: once per input, again per rigid update)."""
-    if samp:
-        raise NotImplementedError('samp > 0 is only used by the rigid Gauss-Newton '
-                                  '(unires/_project.py:245-264), outside the y-update path')
     po = _proj_op()
     mat_y = torch.as_tensor(mat_y).detach().to('cpu', _F64)
     mat_x = torch.as_tensor(mat_x).detach().to('cpu', _F64)
@@ -46,6 +43,17 @@ def _proj_info(dim_y, mat_y, dim_x, mat_x, rigid=None, prof_ip=0, prof_tp=0, gap
     po.dim_x, po.mat_x, po.vx_x = dim_x, mat_x, voxel_size(mat_x)
     po.rigid = torch.eye(4, dtype=_F64) if rigid is None \
         else torch.as_tensor(rigid).detach().to('cpu', _F64)
+    po.D_x = po.D_y = None
+    if samp > 0:
+        # sub-sampling for the rigid Gauss-Newton (unires/_project.py:245-264): the low-res
+        # image is decimated by sk = max(1, floor(samp / vx_x + 0.5)); the high-res branch is
+        # dead code in the reference (:255 compares vx_x with itself).  Built: sk = 1 (any
+        # voxel size >= 2/3 samp), where the decimation is the identity.
+        sk = torch.clamp(torch.floor(float(samp) / po.vx_x + 0.5), min=1.0)
+        if bool((sk != 1).any()):
+            raise NotImplementedError('rigid Gauss-Newton on decimated data (samp / voxel size '
+                                      '>= 1.5) is not built')
+        po.D_x = torch.eye(4, dtype=_F64)
     # thick-slice axis and per-axis profile / gap
     po.dim_thick = int(torch.max(po.vx_x, dim=0)[1])
     profile = [int(prof_ip)] * 3

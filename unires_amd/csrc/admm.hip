@@ -7,6 +7,8 @@
 //   k_jtv_scale : s(v) = max(n - 1/rho, 0) / (n + 1e-7),  n = sqrt(sum_c |w_c/rho + lam_c D y_c|^2)
 //   k_zw_update : z_c = s * (w_c/rho + lam_c D y_c);  w_c += rho * (lam_c D y_c - z_c)
 // (alpha == 1 path; over-relaxation is a per-voxel blend with z_old and is built too).
+#include <string.h>
+
 #include "admm.hpp"
 
 namespace unires {
@@ -153,6 +155,60 @@ void launch_scaling_sums(const float *x, const float *y, Dim3i d, int dim_thick,
   size_t b = (d.numel() + kBlock - 1) / kBlock;
   if (b > 256) b = 256;
   hipLaunchKernelGGL(k_scaling_sums, dim3((int)b), dim3(kBlock), 0, st, x, y, d, dim_thick, out);
+}
+
+// Gauss-Newton sums of the rigid update (unires/_update.py:622-650).  With s_i(v) =
+// sum_d gr_d(v) * dAff_i,d(v)  and  dAff_i,d(v) = D_i[d,0] i + D_i[d,1] j + D_i[d,2] k + D_i[d,3]:
+//   out[i]            = sum_v diff(v) s_i(v)                       (gradient, i < 6)
+//   out[6 + tri(i,j)] = sum_v ctc(v) s_i(v) s_j(v),  i <= j         (Hessian: Hes_m is the
+//                       rank-1 outer product gr gr^T times CtC, so the reference's 9 x 21
+//                       triple loop collapses to 21 products per voxel)
+// gr3: (dim,3) spatial gradients of the pulled image; diff: (dim) residual (conv_transposed in
+// the super-resolution case); ctc: (dim) or nullptr (= 1).  float64 accumulation.
+struct RigidD {
+  float d[6][12];
+};
+__global__ void __launch_bounds__(kBlock)
+    k_rigid_sums(const float *__restrict__ gr3, const float *__restrict__ diff,
+                 const float *__restrict__ ctc, Dim3i dm, RigidD D, double *__restrict__ out) {
+  const size_t n = dm.numel(), stride = (size_t)gridDim.x * blockDim.x;
+  double acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = 0.0;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += stride) {
+    const int k = (int)(v % dm.z), j = (int)((v / dm.z) % dm.y), i = (int)(v / ((size_t)dm.z * dm.y));
+    const float g0 = gr3[3 * v], g1 = gr3[3 * v + 1], g2 = gr3[3 * v + 2];
+    const double df = diff[v], c = ctc ? (double)ctc[v] : 1.0;
+    double s[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const float *m = D.d[q];
+      const double a0 = (double)m[0] * i + (double)m[1] * j + (double)m[2] * k + (double)m[3];
+      const double a1 = (double)m[4] * i + (double)m[5] * j + (double)m[6] * k + (double)m[7];
+      const double a2 = (double)m[8] * i + (double)m[9] * j + (double)m[10] * k + (double)m[11];
+      s[q] = g0 * a0 + g1 * a1 + g2 * a2;
+      acc[q] += df * s[q];
+    }
+    int t = 6;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = a; b < 6; ++b) acc[t++] += c * s[a] * s[b];
+  }
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+    const double tot = block_sum(acc[t]);
+    if (threadIdx.x == 0) atomicAdd(out + t, tot);
+  }
+}
+
+void launch_rigid_sums(const float *gr3, const float *diff, const float *ctc, Dim3i dm,
+                       const float D[6][12], double *out, hipStream_t st) {
+  RigidD R;
+  memcpy(R.d, D, sizeof(R.d));
+  size_t b = (dm.numel() + kBlock - 1) / kBlock;
+  if (b > 512) b = 512;
+  hipLaunchKernelGGL(k_rigid_sums, dim3((int)b), dim3(kBlock), 0, st, gr3, diff, ctc, dm, R, out);
 }
 
 // y[v] = 0 where M v falls outside [0, dim_x) on any axis  (fit()'s clean_fov, run.py:150-164:

@@ -13,6 +13,8 @@ void launch_zw_update(const float *y, float lam, const float *scale, float *z, f
                       const float vx[3], float rho, float alpha, hipStream_t st);
 void launch_scaling_sums(const float *x, const float *y, Dim3i d, int dim_thick, double *out,
                          hipStream_t st);
+void launch_rigid_sums(const float *gr3, const float *diff, const float *ctc, Dim3i dm,
+                       const float D[6][12], double *out, hipStream_t st);
 void launch_clean_fov(float *y, Dim3i d, const Affine &M, Dim3i dx, hipStream_t st);
 int launch_masked_sse(const float *x, const float *ay, size_t n, double *partials, hipStream_t st);
 

@@ -823,6 +823,20 @@ extern "C" int unires_scaling_sums(const float *x, const float *ay, const int32_
   return UNIRES_OK;
 }
 
+extern "C" int unires_rigid_sums(const float *gr3, const float *diff, const float *ctc,
+                                 const int32_t dim[3], const float d_rigid[72], double *out_dev,
+                                 void *stream) {
+  if (!gr3 || !diff || !dim || !d_rigid || !out_dev) return fail(UNIRES_ERR_NULL, "null argument");
+  if (!dims_ok(dim)) return fail(UNIRES_ERR_DIM, "bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(out_dev, 0, 27 * sizeof(double), st));
+  float D[6][12];
+  memcpy(D, d_rigid, sizeof(D));
+  launch_rigid_sums(gr3, diff, ctc, mk(dim), D, out_dev, st);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
 extern "C" int unires_clean_fov(float *y, const int32_t dim_y[3], const float M[12],
                                 const int32_t dim_x[3], void *stream) {
   if (!y || !dim_y || !M || !dim_x) return fail(UNIRES_ERR_NULL, "null argument");

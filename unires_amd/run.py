@@ -7,6 +7,7 @@ import torch
 from . import _lib
 from ._lib import check, i3
 from ._ops import _ptr, _stream
+from ._rigid import _update_rigid
 from ._update import _admm_aux, _step_size, _update_admm, _update_scaling
 from .optim import get_gain
 from .spatial import _m12
@@ -47,9 +48,6 @@ def fit(x, y, sett):
     Returns (dat_y, mat_y, R, info): reconstructions stacked to (dim_y, C) float32, the
     output affine, the rigid matrices (N, 4, 4) and a dict with the objective trace
     ``obj`` (n_iter, 3), the iteration count and the regularisation schedule."""
-    if getattr(sett, 'unified_rigid', False):
-        raise NotImplementedError('unified rigid registration (unires/_update.py:448-710) is not '
-                                  'built: rigid matrices stay as given in po.rigid')
     with torch.no_grad():
         dev = y[0].dat.device
         N = sum(len(xc) for xc in x)
@@ -83,6 +81,9 @@ def fit(x, y, sett):
                 countdown0 = 6
             if sett.scaling:
                 x, _ = _update_scaling(x, y, sett, max_niter_gn=1, num_linesearch=6, verbose=0)
+            if sett.unified_rigid and n_iter > 0 and (n_iter % sett.rigid_mod) == 0:
+                x, _ = _update_rigid(x, y, sett, mean_correct=False, max_niter_gn=1,
+                                     num_linesearch=6, verbose=0, samp=sett.rigid_samp)
             if cnt_scl + 1 < len(sett.reg_scl) and cnt_scl_iter > 16 and abs(gain) < 1e-3:
                 countdown1 -= 1
                 if countdown1 == 0:

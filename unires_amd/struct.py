@@ -80,6 +80,8 @@ class settings:
         self.rigid_mod = 1
         self.scaling = False
         self.unified_rigid = False
+        self.rigid_samp = 1
+        self.rigid_basis = None  # set by _update_rigid / fit: affine_basis('SE')
         self.clean_fov = False
         self.do_print = 0
         # build-side knob: which nitorch-cg objective branch to reproduce
