@@ -59,8 +59,12 @@ enum unires_cg_stop {
 
 enum unires_precond {
   UNIRES_PRECOND_IDENTITY = 0, /* the reference's only live mode (_update.py:136-137) */
-  UNIRES_PRECOND_JACOBI = 1    /* _precond (_update.py:80-102), commented out at :136:
+  UNIRES_PRECOND_JACOBI = 1,   /* _precond (_update.py:80-102), commented out at :136:
                                   z = r / (tau AtA(1) + 2 rho lam^2 sum_d 1/vx_d^2)         */
+  UNIRES_PRECOND_FFT = 2       /* build-side extension (not in the reference): exact inverse of
+                                  the circulant operator a I + rho lam^2 sum_d L_d / vx_d^2 with
+                                  periodic second differences L_d, a = mean diagonal of
+                                  sum_n tau_n AtA_n; two rocFFT real 3-D transforms per call  */
 };
 
 const char *unires_last_error(void);
@@ -185,6 +189,9 @@ int unires_rhs_from_atx(unires_plan_t *plan, const float *atx, const float *w_c,
  * with the same rho and lam. */
 int unires_precond_build(unires_plan_t *plan, int32_t precond_mode, float rho, float lam,
                          float *m_out, void *stream);
+
+/* out = precond(in) for the preconditioner last built on this plan (identity: copy). */
+int unires_precond_apply(unires_plan_t *plan, const float *in, float *out, void *stream);
 
 /* nitorch cg(A=lhs, b, x, precond, max_iter, tolerance, stop,
  * inplace=True, sum_dtype=float64)  (_update.py:142-148): x is updated in place.

@@ -227,8 +227,29 @@ def precond(xc, yc, rho, method):
     return lambda v: v / M                                                              # :100
 
 
+def fft_precond(xc, yc, rho, method, do_proj=True):
+    """Build-side extension (NOT in the reference): x -> IFFT(FFT(x) / (a + sum_d c_d lam_d)),
+    the exact inverse of the circulant operator a I + rho lam^2 sum_d L_d / vx_d^2 with periodic
+    second differences; a = mean diagonal of sum_n tau_n AtA_n (tau for A = I)."""
+    import math
+    dim = tuple(yc.dim)
+    vx = voxel_size(yc.mat).float()
+    if do_proj:
+        acc = torch.zeros(dim)
+        for xn in xc:
+            acc += xn.tau * proj_apply('AtA', torch.ones(dim)[None, None], xn.po, method=method)[0, 0]
+        a = float(acc.double().mean())
+    else:
+        a = float(sum(float(xn.tau) for xn in xc))
+    c = [float(rho) * float(yc.lam) ** 2 / float(vx[d]) ** 2 for d in range(3)]
+    lam = [2.0 - 2.0 * torch.cos(2.0 * math.pi * torch.arange(n, dtype=torch.float64) / n) for n in dim]
+    den = a + c[0] * lam[0][:, None, None] + c[1] * lam[1][None, :, None] \
+        + c[2] * lam[2][None, None, :dim[2] // 2 + 1]
+    return lambda v: torch.fft.irfftn(torch.fft.rfftn(v.double()) / den, s=dim).float()
+
+
 def update_y(x, y, z, w, rho, method, do_proj, cgs_max_iter=20, cgs_tol=1e-3,
-             return_info=False, jacobi=False):
+             return_info=False, jacobi=False, fft=False):
     """In-place CG update of every y[c].dat; identity preconditioner (:136-137),
     stop='max_gain' (:145).  ``jacobi`` enables the line the reference keeps commented
     out (:136)."""
@@ -239,6 +260,8 @@ def update_y(x, y, z, w, rho, method, do_proj, cgs_max_iter=20, cgs_tol=1e-3,
         lhs = lambda dat, c=c: proj('AtA', dat, x[c], y[c], method=method, do=do_proj,
                                     rho=rho, vx_y=vx_y)                   # :140-141
         pre = precond(x[c], y[c], rho, method) if jacobi else (lambda r: r)   # :136-137
+        if fft:
+            pre = fft_precond(x[c], y[c], rho, method, do_proj)
         _, n_it, obj = cg(A=lhs, b=tmp, x=y[c].dat, max_iter=cgs_max_iter, stop='max_gain',
                           inplace=True, precond=pre, tolerance=cgs_tol,
                           return_info=True)                               # :142-148

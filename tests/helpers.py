@@ -145,12 +145,12 @@ def oracle_structs(prob):
     return x, y
 
 
-def run_oracle_update_y(prob, max_iter=20, tol=1e-3, jacobi=False):
+def run_oracle_update_y(prob, max_iter=20, tol=1e-3, jacobi=False, fft=False):
     x, y = oracle_structs(prob)
     rho = torch.tensor(prob['rho'])
     y, info = O.update_y(x, y, prob['z'].clone(), prob['w'].clone(), rho, prob['method'],
                          prob['do_proj'], cgs_max_iter=max_iter, cgs_tol=tol, return_info=True,
-                         jacobi=jacobi)
+                         jacobi=jacobi, fft=fft)
     return [yc.dat for yc in y], info
 
 

@@ -13,7 +13,7 @@ UNIRES_MAX_TAPS = 32
 OP = {'A': 0, 'At': 1, 'AtA': 2}
 REGIME_IDENTITY, REGIME_DENOISE, REGIME_SUPERRES = 0, 1, 2
 STOP = {'e': 0, 'max_gain': 1, 'max_gain_recurred': 2}
-PRECOND = {'none': 0, 'identity': 0, 'jacobi': 1}
+PRECOND = {'none': 0, 'identity': 0, 'jacobi': 1, 'fft': 2}
 
 c_i32x3 = C.c_int32 * 3
 c_f32x3 = C.c_float * 3
@@ -62,6 +62,7 @@ SIGNATURES = {
                                       C.c_float, C.c_void_p, C.c_void_p]),
     'unires_precond_build': (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p,
                                        C.c_void_p]),
+    'unires_precond_apply': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'unires_cg_solve': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.c_double, C.c_int32, C.c_int32,
                                   C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p]),

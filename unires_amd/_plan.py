@@ -174,11 +174,19 @@ class ChannelPlan:
                                             _ptr(out) if out is not None else None, _stream()))
         return out
 
+    def precond_apply(self, v, out=None):
+        """out = precond(v) for the preconditioner last built on this plan (identity: copy)."""
+        v = self._y(v, 'v')
+        if out is None:
+            out = torch.empty_like(v)
+        check(self.lib.unires_precond_apply(self._h, _ptr(v), _ptr(out), _stream()))
+        return out
+
     def cg(self, b, x, rho, lam, max_iter=20, tolerance=1e-3, stop='max_gain', sync=True,
            precond='none'):
         """In-place CG on x (must be contiguous (X,Y,Z)).  Returns (iters, obj) when
         ``sync`` (one stream sync), else None with everything left enqueued.
-        ``precond='jacobi'`` needs :meth:`precond_build` with the same rho, lam first."""
+        ``precond='jacobi' | 'fft'`` needs :meth:`precond_build` with the same mode, rho, lam first."""
         if precond not in _lib.PRECOND:
             raise ValueError('Undefined preconditioner')
         pm = _lib.PRECOND[precond]

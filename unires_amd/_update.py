@@ -76,8 +76,8 @@ def _update_y(x, y, z, w, rho, tmp, sett, info=None):
             plan = _channel_plan(x[c], y[c], sett.method, sett.do_proj, vx_y)
             lam = float(y[c].lam)
             plan.rhs([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=tmp)
-            if pre == 'jacobi':
-                plan.precond_build(rho, lam, mode='jacobi')
+            if pre in ('jacobi', 'fft'):
+                plan.precond_build(rho, lam, mode=pre)
             res = plan.cg(tmp, y[c].dat, rho, lam, max_iter=sett.cgs_max_iter,
                           tolerance=sett.cgs_tol, stop=sett.cgs_stop, sync=sync, precond=pre)
             if sync:
@@ -97,8 +97,8 @@ def _update_y(x, y, z, w, rho, tmp, sett, info=None):
                 plan.rhs_cached([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=b)
             else:
                 plan.rhs([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=b)
-            if pre == 'jacobi':
-                plan.precond_build(rho, lam, mode='jacobi')
+            if pre in ('jacobi', 'fft'):
+                plan.precond_build(rho, lam, mode=pre)
             plan.cg(b, y[c].dat, rho, lam, max_iter=sett.cgs_max_iter, tolerance=sett.cgs_tol,
                     stop=sett.cgs_stop, sync=False, precond=pre)
     for c in range(C):

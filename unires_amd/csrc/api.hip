@@ -15,6 +15,7 @@
 #include "admm.hpp"
 #include "aligned.hpp"
 #include "cg.hpp"
+#include "fftpre.hpp"
 #include "fused.hpp"
 #include "ops.hpp"
 
@@ -280,7 +281,9 @@ struct unires_plan {
   CgState *state = nullptr;
   size_t cap_g = 0, cap_x = 0;
   float *precM = nullptr;  // Jacobi diagonal (own allocation, made by unires_precond_build)
+  FftPre fft;              // FFT-diagonal preconditioner (plans + buffers, made on demand)
   float prec_rho = 0.f, prec_lam = 0.f;
+  int prec_mode = UNIRES_PRECOND_IDENTITY;
   bool prec_ready = false;
 };
 
@@ -423,6 +426,7 @@ extern "C" int unires_plan_destroy(unires_plan_t *plan) {
   if (!plan) return UNIRES_OK;
   if (plan->ws) (void)hipFree(plan->ws);
   if (plan->precM) (void)hipFree(plan->precM);
+  fftpre_destroy(plan->fft);
   for (Repeat &R : plan->reps) free_ztabs(R);
   delete plan;
   return UNIRES_OK;
@@ -633,12 +637,43 @@ extern "C" int unires_precond_build(unires_plan_t *plan, int32_t precond_mode, f
     plan->prec_ready = false;
     return UNIRES_OK;
   }
-  if (precond_mode != UNIRES_PRECOND_JACOBI)
-    return fail(UNIRES_ERR_UNSUPPORTED, "preconditioner modes: identity (0), Jacobi (1)");
-  if (plan->reps.size() != 1)  // the reference raises ValueError here (_update.py:84-85)
-    return fail(UNIRES_ERR_ARG, "CG pre-conditioning only supports one repeat per contrast.");
+  if (precond_mode != UNIRES_PRECOND_JACOBI && precond_mode != UNIRES_PRECOND_FFT)
+    return fail(UNIRES_ERR_UNSUPPORTED, "preconditioner modes: identity (0), Jacobi (1), FFT (2)");
   hipStream_t st = (hipStream_t)stream;
   const size_t ny = plan->dy.numel();
+  if (precond_mode == UNIRES_PRECOND_FFT) {
+    if (int rc = fftpre_setup(plan->fft, plan->dy))
+      return fail(rc == 2 ? UNIRES_ERR_ALLOC : UNIRES_ERR_HIP, "hipFFT plan / buffer creation failed");
+    FftPre &F = plan->fft;
+    // a = mean diagonal of the data term: mean_v sum_n tau_n (AtA_n 1)(v)
+    double a = 0.0;
+    if (plan->regime == UNIRES_REGIME_IDENTITY) {
+      for (const Repeat &R : plan->reps) a += R.tau;
+    } else {
+      launch_fill(1.f, plan->ax, ny, st);
+      for (size_t n = 0; n < plan->reps.size(); ++n) {
+        const Repeat &R = plan->reps[n];
+        const PushSrc src = ata_forward(plan, R, plan->ax, nullptr, st);
+        PushEpilogue ep;
+        ep.accumulate = n > 0;
+        push_any(plan, src, R, R.tau, ep, F.z, nullptr, st);
+      }
+      launch_dot(F.z, plan->ax, ny, plan->part0, nullptr, st);
+      launch_sum_to(plan->part0, vec_num_blocks(ny), &plan->state->rz, st);
+      HIP_TRY(hipMemcpyAsync(&a, &plan->state->rz, sizeof(double), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      a /= (double)ny;
+    }
+    if (!(a > 0.0)) return fail(UNIRES_ERR_ARG, "data term has an empty diagonal");
+    F.a = (float)a;
+    for (int d = 0; d < 3; ++d) F.c[d] = rho * (lam * lam) / (plan->vx[d] * plan->vx[d]);
+    if (m_out) return fail(UNIRES_ERR_ARG, "m_out is only defined for the Jacobi diagonal");
+    CHECK_LAUNCH();
+    plan->prec_rho = rho, plan->prec_lam = lam, plan->prec_mode = precond_mode, plan->prec_ready = true;
+    return UNIRES_OK;
+  }
+  if (plan->reps.size() != 1)  // the reference raises ValueError here (_update.py:84-85)
+    return fail(UNIRES_ERR_ARG, "CG pre-conditioning only supports one repeat per contrast.");
   if (!plan->precM) HIP_TRY(hipMalloc((void **)&plan->precM, ny * sizeof(float)));
   const Repeat &R = plan->reps[0];
   float c = 0.f;  // 2 rho lam^2 sum_d 1/vx_d^2, float32 like the reference's 0-d tensors
@@ -655,7 +690,23 @@ extern "C" int unires_precond_build(unires_plan_t *plan, int32_t precond_mode, f
   if (m_out)
     HIP_TRY(hipMemcpyAsync(m_out, plan->precM, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
   CHECK_LAUNCH();
-  plan->prec_rho = rho, plan->prec_lam = lam, plan->prec_ready = true;
+  plan->prec_rho = rho, plan->prec_lam = lam, plan->prec_mode = precond_mode, plan->prec_ready = true;
+  return UNIRES_OK;
+}
+
+extern "C" int unires_precond_apply(unires_plan_t *plan, const float *in, float *out, void *stream) {
+  if (!plan || !in || !out) return fail(UNIRES_ERR_NULL, "null argument");
+  if (in == out) return fail(UNIRES_ERR_ARG, "precond_apply cannot run in place");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t ny = plan->dy.numel();
+  if (!plan->prec_ready || plan->prec_mode == UNIRES_PRECOND_IDENTITY) {
+    HIP_TRY(hipMemcpyAsync(out, in, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else if (plan->prec_mode == UNIRES_PRECOND_FFT) {
+    if (fftpre_apply(plan->fft, in, out, st)) return fail(UNIRES_ERR_HIP, "hipFFT execution failed");
+  } else {
+    launch_div(in, plan->precM, out, ny, st);
+  }
+  CHECK_LAUNCH();
   return UNIRES_OK;
 }
 
@@ -710,12 +761,14 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
   if (b == x) return fail(UNIRES_ERR_ARG, "b and x must not alias");
   if (max_iter < 0 || max_iter > kMaxCgIter) return fail(UNIRES_ERR_ARG, "max_iter out of range");
   if (stop_mode < 0 || stop_mode > 2) return fail(UNIRES_ERR_ARG, "bad stop mode");
-  if (precond_mode != UNIRES_PRECOND_IDENTITY && precond_mode != UNIRES_PRECOND_JACOBI)
-    return fail(UNIRES_ERR_UNSUPPORTED, "preconditioner modes: identity (0), Jacobi (1)");
-  if (precond_mode == UNIRES_PRECOND_JACOBI &&
-      (!plan->prec_ready || plan->prec_rho != rho || plan->prec_lam != lam))
-    return fail(UNIRES_ERR_ARG, "call unires_precond_build with this rho and lam first");
+  if (precond_mode < UNIRES_PRECOND_IDENTITY || precond_mode > UNIRES_PRECOND_FFT)
+    return fail(UNIRES_ERR_UNSUPPORTED, "preconditioner modes: identity (0), Jacobi (1), FFT (2)");
+  if (precond_mode != UNIRES_PRECOND_IDENTITY &&
+      (!plan->prec_ready || plan->prec_mode != precond_mode || plan->prec_rho != rho ||
+       plan->prec_lam != lam))
+    return fail(UNIRES_ERR_ARG, "call unires_precond_build with this mode, rho and lam first");
   const float *M = precond_mode == UNIRES_PRECOND_JACOBI ? plan->precM : nullptr;
+  const bool fft = precond_mode == UNIRES_PRECOND_FFT;
   if (!(tol >= 0.0)) return fail(UNIRES_ERR_ARG, "tolerance must be >= 0");
   hipStream_t st = (hipStream_t)stream;
   unires_plan *pl = plan;
@@ -731,6 +784,11 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
   const bool want_obj0 = check && stop_mode != UNIRES_STOP_RESIDUAL;
   launch_residual_init(b, pl->ap, x, pl->r, pl->p, ny, pl->part0, want_obj0 ? pl->part1 : nullptr,
                        M, st);
+  if (fft) {  // z = M^-1 r ; p = z ; rz = r.z
+    if (fftpre_apply(pl->fft, pl->r, pl->fft.z, st)) return fail(UNIRES_ERR_HIP, "hipFFT execution failed");
+    HIP_TRY(hipMemcpyAsync(pl->p, pl->fft.z, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
+    launch_dot(pl->r, pl->fft.z, ny, pl->part0, nullptr, st);
+  }
   launch_sc_init(S, pl->part0, pl->part1, gv, stop_mode, check ? 1 : 0, st);
 
   for (int k = 1; k <= max_iter; ++k) {
@@ -742,8 +800,12 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
     int obj_kind = 0;
     if (check && stop_mode == UNIRES_STOP_RESIDUAL) obj_kind = 1;
     if (recur) obj_kind = 2;
+    if (fft) {  // (the transforms also run after convergence: hipFFT has no device-side skip)
+      if (fftpre_apply(pl->fft, pl->r, pl->fft.z, st)) return fail(UNIRES_ERR_HIP, "hipFFT execution failed");
+      launch_dot(pl->r, pl->fft.z, ny, pl->part0, done, st);
+    }
     launch_sc_beta(S, pl->part0, pl->part1, gv, k, obj_kind, tol, st);
-    launch_update_p(S, pl->r, pl->p, ny, M, st);
+    launch_update_p(S, fft ? pl->fft.z : pl->r, pl->p, ny, M, st);
     if (check && stop_mode == UNIRES_STOP_MAXGAIN) {
       // objective sum x (Ax - 2b) folded into the matvec epilogue: A(x) is never stored
       const int go = matvec(pl, rho, lam, x, pl->ax, pl->part1, done, st, b);

@@ -298,6 +298,16 @@ void launch_fill(float v, float *y, size_t n, hipStream_t st) {
   hipLaunchKernelGGL(k_fill, dim3(vec_blocks(n) * 4 > 4096 ? 4096 : vec_blocks(n) * 4), dim3(kBlock), 0,
                      st, v, y, n);
 }
+__global__ void __launch_bounds__(kBlock)
+    k_divide(const float *__restrict__ a, const float *__restrict__ m, float *__restrict__ y, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = __fdiv_rn(a[i], m[i]);
+}
+void launch_div(const float *a, const float *m, float *y, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_divide, dim3(vec_blocks(n) * 4 > 4096 ? 4096 : vec_blocks(n) * 4), dim3(kBlock), 0,
+                     st, a, m, y, n);
+}
 void launch_axpy(float a, const float *x, float *y, size_t n, hipStream_t st) {
   hipLaunchKernelGGL(k_axpy, dim3(vec_blocks(n) * 4 > 4096 ? 4096 : vec_blocks(n) * 4),
                      dim3(kBlock), 0, st, a, x, y, n);

@@ -26,6 +26,7 @@ void launch_update_p(const CgState *s, const float *r, float *p, size_t n, const
 // M = nullptr: identity preconditioner; else z = r / M (Jacobi)
 void launch_scale_shift(float a, float c, float *y, size_t n, hipStream_t st);
 void launch_fill(float v, float *y, size_t n, hipStream_t st);
+void launch_div(const float *a, const float *m, float *y, size_t n, hipStream_t st);  // y = a / m
 void launch_axpy(float a, const float *x, float *y, size_t n, hipStream_t st);
 void launch_sc_init(CgState *s, const double *part_rr, const double *part_obj, int g, int mode,
                     int check, hipStream_t st);

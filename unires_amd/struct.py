@@ -87,7 +87,9 @@ class settings:
         # build-side knob: which nitorch-cg objective branch to reproduce
         # ('max_gain' = what the reference passes, unires/_update.py:145)
         self.cgs_stop = 'max_gain'
-        self.cgs_precond = 'none'  # 'jacobi': _precond (reference has it commented out, _update.py:136)
+        # 'jacobi': _precond (the reference has it commented out, _update.py:136);
+        # 'fft': build-side FFT-diagonal preconditioner (circulant a I + rho lam^2 DtD)
+        self.cgs_precond = 'none'
         # build-side knob: enqueue the (independent) channels of the y-update on separate HIP streams
         self.channel_streams = True
         # build-side knob: keep sum_n tau_n At x_n across ADMM iterations (recomputed on change)
