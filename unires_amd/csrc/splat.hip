@@ -344,6 +344,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
           if (edge) ok = ok && in_fov(gx, gy, gz, dd, P.tol);
           const float v = P.alpha * val[u];
           ok = ok && v != 0.f;
+          if (!__any(ok)) continue;  // nothing of this instruction lands in the tile
           const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
           const int lx = (int)fx - (x0 - 1), ly = (int)fy - (y0 - 1), lz = (int)fz - (z0 - 1);
           const float wx1 = gx - fx, wy1 = gy - fy, wz1 = gz - fz;
