@@ -2,7 +2,7 @@
 # dynamic VALU / time share of k_splat phases via the UNIRES_DBG ablation bits
 cd /tmp && export TMPDIR=/tmp
 for d in ${DBGS:-0 2 4 6 8 10 18}; do
-  rm -rf /tmp/pm && UNIRES_DBG=$d WL=cfg3_256c3_thick6z CH=${CH:-0} rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d /tmp/pm -o p -- python $GRAFT_REPO_ROOT/scratch/pmc5.py > /tmp/pm.log 2>&1
+  rm -rf /tmp/pm && UNIRES_DBG=$d WL=cfg3_256c3_thick6z CH=${CH:-0} rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d /tmp/pm -o p -- python $GRAFT_REPO_ROOT/tools/pmc5.py > /tmp/pm.log 2>&1
   python - <<PY
 import csv, collections
 rows=list(csv.DictReader(open('/tmp/pm/p_counter_collection.csv')))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/pmc.sh <script.py> -> per-kernel PMC averages
+# usage: tools/pmc.sh <script.py> -> per-kernel PMC averages
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pm && rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pm -o p -- python $GRAFT_REPO_ROOT/$1 > /tmp/pm.log 2>&1
 python - <<'PY'

@@ -14,8 +14,8 @@ rm -rf /tmp/kt3 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/
 cp /tmp/kt3/k_kernel_stats.csv $OUT/r01_bench_aligned_serial_kernel_stats.csv
 grep '^{"metric"' $OUT/bench_prof_aligned.log | tail -1 > $OUT/r01_bench_aligned_serial.json
 cd $GRAFT_REPO_ROOT
-for c in 0 1 2; do echo channel $c; CH=$c WL=cfg3_256c3_thick6z bash scratch/traffic.sh scratch/pmc5.py; done > $OUT/r01_traffic_pmc.txt 2>&1
-WL=cfg3_256c3_thick6z_aligned bash scratch/traffic.sh scratch/pmc5.py > $OUT/r01_traffic_aligned_pmc.txt 2>&1
-WL=cfg3_256c3_thick6z bash scratch/pmc.sh scratch/pmc5.py > $OUT/r01_sq_counters.txt 2>&1
-WL=cfg3_256c3_thick6z_aligned bash scratch/pmc.sh scratch/pmc5.py >> $OUT/r01_sq_counters.txt 2>&1
+for c in 0 1 2; do echo channel $c; CH=$c WL=cfg3_256c3_thick6z bash tools/traffic.sh tools/pmc5.py; done > $OUT/r01_traffic_pmc.txt 2>&1
+WL=cfg3_256c3_thick6z_aligned bash tools/traffic.sh tools/pmc5.py > $OUT/r01_traffic_aligned_pmc.txt 2>&1
+WL=cfg3_256c3_thick6z bash tools/pmc.sh tools/pmc5.py > $OUT/r01_sq_counters.txt 2>&1
+WL=cfg3_256c3_thick6z_aligned bash tools/pmc.sh tools/pmc5.py >> $OUT/r01_sq_counters.txt 2>&1
 ls -la $OUT
