@@ -54,6 +54,7 @@ struct SplatArgs {
 //   Long  8 x 4 x 30, L = 32 : 169 / 236 / 208 us   <- used
 //   Short 8 x 8 x 14, L = 16 : 219 / 239 / 234 us   (less apron, but per-tile set-up doubles)
 //         8 x 8 x 30, L = 32 : 219 / 281 / 267 us   (fewer segments, but 12 instead of 16 waves/CU)
+//         6 x 4 x 30, L = 32 : 204 / 287 / 274 us   (20 instead of 16 waves/CU, but 34 % more tiles)
 //   earlier sweeps of the long form: 6x6 230, 4x8 249, 4x4 329 (vs 8x4 218)
 // UNIRES_SPLAT_CFG=short selects the short tile (kept as a tested variant).
 struct SplatLong {
