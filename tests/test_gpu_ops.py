@@ -71,6 +71,22 @@ def test_grid_grad(dev, name, sdim, gdim):
             assert (fd[0, 0][inner[0]] - ref[0, 0, ..., d][inner[0]]).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize('zscale', [0.9, 0.45, 0.12])
+def test_push_with_a_grid_much_finer_than_the_output(dev, zscale):
+    """Long grid rows per output tile (5+ segments per row): the segment list of the tile
+    kernels is filled in several passes - nothing may be dropped."""
+    from unires_amd import spatial
+    torch.manual_seed(11)
+    sdim, gdim = (20, 12, 40), (22, 14, int(40 / zscale) + 3)
+    M = rigid_matrix([0.3, -0.2, 0.4], [0.02, -0.03, 0.01])
+    M[:3, 2] *= zscale
+    val = torch.rand((1, 1) + gdim)
+    g = N.affine_grid(M.float(), gdim)[None]
+    ref = N.grid_push(val, g, sdim)
+    out = spatial.grid_push(val.to(dev), M, sdim).cpu()
+    assert (out - ref).abs().max() <= 5e-5 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize('rot', [(0, 0, 0), (0.02, -0.01, 0.03), (0.1, 0.1, -0.1), (0.0, 0.25, 0.0),
                                  (0.3, 0.0, 0.0), (-0.2, 0.15, 0.5), (0.9, 0.0, 0.0)])
 @pytest.mark.parametrize('scale', [1.0, 0.93, 1.21])

@@ -281,13 +281,16 @@ __global__ void __launch_bounds__(kPushThreads)
     const int nrow_cand = (P.dbg & 8) ? 0 : max(nbx, 0) * max(nby, 0);
     const int segs_per_row = (max(bz1 - bz0 + 1, 1) + 31) / 32;
     int nseg = 0;
+    // candidate rows per pass: never more segments than the row list holds (long rows when the
+    // grid is much finer than the output along z)
+    const int chunk = max(1, min(kPushThreads, Tile::kSegs / segs_per_row));
     for (int rc0 = 0;;) {
-      // ---- phase A: 64 candidate rows (ui,uj) per pass -> exact grid-z intervals ----
+      // ---- phase A: up to 64 candidate rows (ui,uj) per pass -> exact grid-z intervals ----
       PROF_T(t_a0);
       if (rc0 < nrow_cand) {
         const int rc = rc0 + lane;
         int ui = 0, uj = 0, k0 = 0, k1 = -1;
-        if (rc < nrow_cand) {
+        if (rc < nrow_cand && lane < chunk) {
           const int a = rc / nby, b = rc - a * nby;
           ui = bx0 + a, uj = by0 + b;
           float r0, r1, r2;
@@ -325,12 +328,12 @@ __global__ void __launch_bounds__(kPushThreads)
           k0 += 32;
           has = has && k1 >= k0;
         }
-        rc0 += kPushThreads;
+        rc0 += chunk;
       }
       PROF_T(t_a1);
       PROF_ADD(1, t_a0, t_a1);
       const bool last = rc0 >= nrow_cand;
-      if (!last && nseg + kPushThreads * segs_per_row <= Tile::kSegs) continue;
+      if (!last && nseg + chunk * segs_per_row <= Tile::kSegs) continue;
       WAVE_FENCE();  // segment list / tables / zeroed acc written before being read
       // ---- phase B: the two half-waves take segments p and p + npair, lanes along grid z.
       // Batches of kU segment pairs, software-pipelined: the global loads of batch b+1 are

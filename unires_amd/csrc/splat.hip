@@ -219,6 +219,9 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
     SP_ADD(0, t_start, t_setup);
     // ---- phase A: rows (ui,uj) -> exact grid-z intervals -> <=32-long segments ----
     const int segs_per_row = (max(bz1 - bz0 + 1, 1) + L - 1) / L;
+    // candidate rows per pass: never more segments than the LDS row list holds (a grid much
+    // finer than the output in z yields long rows; the usual case is 2 segments per row)
+    const int chunk = max(1, min(kWave, kSegs / segs_per_row));
     int nseg = 0;
     for (int rc0 = 0;;) {
       if (P.dbg & 16) break;
@@ -226,7 +229,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
       if (rc0 < nrow_cand) {
         const int rc = rc0 + lane;
         int ui = 0, uj = 0, k0 = 0, k1 = -1;
-        if (rc < nrow_cand) {
+        if (rc < nrow_cand && lane < chunk) {
           const int a = rc / nby, b = rc - a * nby;
           ui = bx0 + a, uj = by0 + b;
           float r0, r1, r2;
@@ -257,10 +260,10 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
           k0 += L;
           has = has && k1 >= k0;
         }
-        rc0 += kWave;
+        rc0 += chunk;
       }
       const bool last = rc0 >= nrow_cand;
-      if (!last && nseg + kWave * segs_per_row <= kSegs) continue;
+      if (!last && nseg + chunk * segs_per_row <= kSegs) continue;
       SPLAT_FENCE();
       const int nr = min(nseg, kSegs);
       const int npair = (nr + G - 1) / G;  // instruction p carries rows p, p + npair, ... (G of them)
