@@ -586,6 +586,16 @@ int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const 
       axis = 3;
     }
   }
+  if (src.convup) {
+    // the conv tables hold 64 grid slices along z (32 along x / y for AXIS 3): the grid-space
+    // box of an aproned tile must fit, else the general kernel (which checks per tile) runs
+    const float ext[3] = {(float)SplatLong::TX + 1.f, (float)SplatLong::TY + 1.f, (float)SplatLong::TZ + 1.f};
+    for (int r = 0; r < 3; ++r) {
+      float e = 3.f;
+      for (int c = 0; c < 3; ++c) e += fabsf(Ainv.m[4 * r + c]) * ext[c];
+      if (e > 62.f) return 1;
+    }
+  }
   if (src.convup && axis != 3) {
     if (axis < 0) axis = 2;  // all dirac: conv_up is the identity, any axis works
     const int xdv[3] = {src.xd.x, src.xd.y, src.xd.z};
