@@ -162,6 +162,12 @@ __device__ __forceinline__ void pull_grad_sample(const float *__restrict__ src, 
   dz = L.wx0 * (d00 * L.wy0 + d01 * L.wy1) + L.wx1 * (d10 * L.wy0 + d11 * L.wy1);
 }
 
+// 32-bit / 24-bit index arithmetic of the fast paths (pull_interior, the splat's x-space
+// gathers) is exact for volumes below these sizes; larger ones take the size_t paths.
+__host__ __device__ __forceinline__ bool fits_fast_index(const Dim3i &d) {
+  return (long long)d.x * d.y < (1ll << 24) && d.z < (1 << 24) && d.numel() < (1ull << 31);
+}
+
 // Interior fast path: all 8 corners inside the volume (so also inside the FOV): no
 // clamps, no masks, 32-bit offsets, lerp form (~46 VALU per sample vs ~140).
 __device__ __forceinline__ float2 ld2_u(const float *p) {

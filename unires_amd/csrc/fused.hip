@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(kBlock)
       const bool outside = gx <= -tol || gx >= bx + tol || gy <= -tol || gy >= by + tol ||
                            gz <= -tol || gz >= bz + tol;
       float v;
-      if (__all(inside) && sd.z >= 2)
+      if (__all(inside) && sd.z >= 2 && fits_fast_index(sd))
         v = pull_interior(src, ny, nz, nynz, gx, gy, gz);
       else if (__all(outside))
         v = 0.f;

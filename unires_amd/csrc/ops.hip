@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(kBlock) k_pull(const float *__restrict__ src, 
   const unsigned ny = sd.y, nz = sd.z, nynz = ny * nz;
   const float bx = (float)(sd.x - 1), by = (float)(sd.y - 1), bz = (float)(sd.z - 1);
   float g[kPullChunks][3];
-  bool inside = sd.z >= 2;
+  bool inside = sd.z >= 2 && fits_fast_index(sd);
 #pragma unroll
   for (int u = 0; u < kPullChunks; ++u) {
     const int k = min(kbase + u * kWave + lane, gd.z - 1);

@@ -549,6 +549,7 @@ int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const 
   P.src = src.data;
   P.gx = src.gd.x, P.gy = src.gd.y, P.gz = src.gd.z;
   if (P.gx > 32000 || P.gy > 32000 || P.gz > 32000) return 1;
+  if (!fits_fast_index(src.gd) || (src.convup && !fits_fast_index(src.xd))) return 1;
   P.xdy = src.xd.y, P.xdz = src.xd.z;
   P.nkz = 1, P.sz = 1, P.se = 1.f, P.so = 1.f;
   for (int d = 0; d < 3; ++d) P.nk3[d] = 1, P.s3[d] = 1, P.xd3[d] = 2;
