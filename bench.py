@@ -291,7 +291,9 @@ def main():
     import unires_amd as U
 
     wl = WORKLOADS[args.workload]
-    x, y, z, w, rho, sett = build_subject(wl, device, seed=1234 + rank)
+    # every rank reconstructs a subject of identical cost (same geometry draw): the kernels'
+    # run time depends on the rigid transforms, and weak scaling should not measure that spread
+    x, y, z, w, rho, sett = build_subject(wl, device, seed=1234)
     if args.serial_channels:
         sett.channel_streams = False
     tmp = torch.zeros_like(y[0].dat)
