@@ -795,17 +795,19 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
     const int g = matvec(pl, rho, lam, pl->p, pl->ap, pl->part0, done, st);
     launch_sc_alpha(S, pl->part0, g, st);
     const bool recur = check && stop_mode == UNIRES_STOP_MAXGAIN_RECURRED;
-    launch_update_xr(S, pl->p, pl->ap, x, pl->r, b, ny, pl->part0, recur ? pl->part1 : nullptr, M,
-                     st);
     int obj_kind = 0;
     if (check && stop_mode == UNIRES_STOP_RESIDUAL) obj_kind = 1;
     if (recur) obj_kind = 2;
+    // "x += alpha p" rides with the p update unless sc_beta can stop the solve in between
+    const bool lazy_x = obj_kind == 0;
+    launch_update_xr(S, pl->p, pl->ap, lazy_x ? nullptr : x, pl->r, b, ny, pl->part0,
+                     recur ? pl->part1 : nullptr, M, st);
     if (fft) {  // (the transforms also run after convergence: hipFFT has no device-side skip)
       if (fftpre_apply(pl->fft, pl->r, pl->fft.z, st)) return fail(UNIRES_ERR_HIP, "hipFFT execution failed");
       launch_dot(pl->r, pl->fft.z, ny, pl->part0, done, st);
     }
     launch_sc_beta(S, pl->part0, pl->part1, gv, k, obj_kind, tol, st);
-    launch_update_p(S, fft ? pl->fft.z : pl->r, pl->p, ny, M, st);
+    launch_update_p(S, fft ? pl->fft.z : pl->r, pl->p, ny, M, lazy_x ? x : nullptr, st);
     if (check && stop_mode == UNIRES_STOP_MAXGAIN) {
       // objective sum x (Ax - 2b) folded into the matvec epilogue: A(x) is never stored
       const int go = matvec(pl, rho, lam, x, pl->ax, pl->part1, done, st, b);

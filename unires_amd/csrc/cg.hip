@@ -104,6 +104,10 @@ __global__ void __launch_bounds__(kBlock)
 
 // x += alpha p ; r -= alpha Ap ; part_rr = sum r*r ;
 // part_obj (optional) = sum x*(b+r)  (recurred objective -0.5*sum x (b+r))
+// XUPD = false: only r is updated here and "x += alpha p" rides along with the p update
+// (k_update_p<true>), which reads the OLD p anyway: 3 + 5 instead of 6 + 3 volume passes per
+// iteration, same operations and roundings.
+template <bool XUPD>
 __global__ void __launch_bounds__(kBlock)
     k_update_xr(const CgState *__restrict__ st, const float *__restrict__ p,
                 const float *__restrict__ ap, float *__restrict__ x, float *__restrict__ r,
@@ -114,22 +118,26 @@ __global__ void __launch_bounds__(kBlock)
   GRID_STRIDE_VEC4(n);
   double rr = 0.0, ob = 0.0;
   for (size_t i = tid0; i < n4; i += stride) {
-    const float4 vp = ld4(p, i), va = ld4(ap, i);
-    float4 vx = ld4(x, i), vr = ld4(r, i);
-    vx.x = __fadd_rn(vx.x, __fmul_rn(alpha, vp.x));
-    vx.y = __fadd_rn(vx.y, __fmul_rn(alpha, vp.y));
-    vx.z = __fadd_rn(vx.z, __fmul_rn(alpha, vp.z));
-    vx.w = __fadd_rn(vx.w, __fmul_rn(alpha, vp.w));
+    const float4 va = ld4(ap, i);
+    float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vr = ld4(r, i);
+    if (XUPD) {
+      const float4 vp = ld4(p, i);
+      vx = ld4(x, i);
+      vx.x = __fadd_rn(vx.x, __fmul_rn(alpha, vp.x));
+      vx.y = __fadd_rn(vx.y, __fmul_rn(alpha, vp.y));
+      vx.z = __fadd_rn(vx.z, __fmul_rn(alpha, vp.z));
+      vx.w = __fadd_rn(vx.w, __fmul_rn(alpha, vp.w));
+      st4(x, i, vx);
+    }
     vr.x = __fsub_rn(vr.x, __fmul_rn(alpha, va.x));
     vr.y = __fsub_rn(vr.y, __fmul_rn(alpha, va.y));
     vr.z = __fsub_rn(vr.z, __fmul_rn(alpha, va.z));
     vr.w = __fsub_rn(vr.w, __fmul_rn(alpha, va.w));
-    st4(x, i, vx);
     st4(r, i, vr);
     const float4 vz = zval4(vr, M, i);
     rr += (double)__fmul_rn(vr.x, vz.x) + (double)__fmul_rn(vr.y, vz.y) +
           (double)__fmul_rn(vr.z, vz.z) + (double)__fmul_rn(vr.w, vz.w);
-    if (part_obj) {
+    if (XUPD && part_obj) {
       const float4 vb = ld4(b, i);
       ob += (double)__fmul_rn(vx.x, __fadd_rn(vb.x, vr.x)) +
             (double)__fmul_rn(vx.y, __fadd_rn(vb.y, vr.y)) +
@@ -138,39 +146,54 @@ __global__ void __launch_bounds__(kBlock)
     }
   }
   for (size_t i = n4 * 4 + tid0; i < n; i += stride) {
-    const float vx = __fadd_rn(x[i], __fmul_rn(alpha, p[i]));
+    float vx = 0.f;
+    if (XUPD) {
+      vx = __fadd_rn(x[i], __fmul_rn(alpha, p[i]));
+      x[i] = vx;
+    }
     const float vr = __fsub_rn(r[i], __fmul_rn(alpha, ap[i]));
-    x[i] = vx;
     r[i] = vr;
     rr += (double)__fmul_rn(vr, zval1(vr, M, i));
-    if (part_obj) ob += (double)__fmul_rn(vx, __fadd_rn(b[i], vr));
+    if (XUPD && part_obj) ob += (double)__fmul_rn(vx, __fadd_rn(b[i], vr));
   }
   const double t = block_sum(rr);
   if (threadIdx.x == 0) part_rr[blockIdx.x] = t;
-  if (part_obj) {
+  if (XUPD && part_obj) {
     const double t2 = block_sum(ob);
     if (threadIdx.x == 0) part_obj[blockIdx.x] = t2;
   }
 }
 
-// p = beta*p + r   (p *= beta; p += z with z = r)
+// p = beta*p + z   (p *= beta; p += z);  XUPD: first x += alpha * p with the old p
+template <bool XUPD>
 __global__ void __launch_bounds__(kBlock)
     k_update_p(const CgState *__restrict__ st, const float *__restrict__ r, float *__restrict__ p,
-               size_t n, const float *__restrict__ M) {
+               size_t n, const float *__restrict__ M, float *__restrict__ x) {
   if (st->done) return;
-  const float beta = (float)st->beta;
+  const float beta = (float)st->beta, alpha = (float)st->alpha;
   GRID_STRIDE_VEC4(n);
   for (size_t i = tid0; i < n4; i += stride) {
     const float4 vr = zval4(ld4(r, i), M, i);
     float4 vp = ld4(p, i);
+    if (XUPD) {
+      float4 vx = ld4(x, i);
+      vx.x = __fadd_rn(vx.x, __fmul_rn(alpha, vp.x));
+      vx.y = __fadd_rn(vx.y, __fmul_rn(alpha, vp.y));
+      vx.z = __fadd_rn(vx.z, __fmul_rn(alpha, vp.z));
+      vx.w = __fadd_rn(vx.w, __fmul_rn(alpha, vp.w));
+      st4(x, i, vx);
+    }
     vp.x = __fadd_rn(__fmul_rn(beta, vp.x), vr.x);
     vp.y = __fadd_rn(__fmul_rn(beta, vp.y), vr.y);
     vp.z = __fadd_rn(__fmul_rn(beta, vp.z), vr.z);
     vp.w = __fadd_rn(__fmul_rn(beta, vp.w), vr.w);
     st4(p, i, vp);
   }
-  for (size_t i = n4 * 4 + tid0; i < n; i += stride)
-    p[i] = __fadd_rn(__fmul_rn(beta, p[i]), zval1(r[i], M, i));
+  for (size_t i = n4 * 4 + tid0; i < n; i += stride) {
+    const float vp = p[i];
+    if (XUPD) x[i] = __fadd_rn(x[i], __fmul_rn(alpha, vp));
+    p[i] = __fadd_rn(__fmul_rn(beta, vp), zval1(r[i], M, i));
+  }
 }
 
 // y = a*x + y (generic axpy; used by the identity regime's RHS)
@@ -273,12 +296,19 @@ void launch_dot(const float *a, const float *b, size_t n, double *part, const in
 void launch_update_xr(const CgState *s, const float *p, const float *ap, float *x, float *r,
                       const float *b, size_t n, double *part_rr, double *part_obj,
                       const float *M, hipStream_t st) {
-  hipLaunchKernelGGL(k_update_xr, dim3(vec_blocks(n)), dim3(kBlock), 0, st, s, p, ap, x, r, b, n,
-                     part_rr, part_obj, M);
+  if (x)
+    hipLaunchKernelGGL(k_update_xr<true>, dim3(vec_blocks(n)), dim3(kBlock), 0, st, s, p, ap, x, r, b,
+                       n, part_rr, part_obj, M);
+  else
+    hipLaunchKernelGGL(k_update_xr<false>, dim3(vec_blocks(n)), dim3(kBlock), 0, st, s, p, ap, x, r,
+                       b, n, part_rr, part_obj, M);
 }
-void launch_update_p(const CgState *s, const float *r, float *p, size_t n, const float *M,
+void launch_update_p(const CgState *s, const float *r, float *p, size_t n, const float *M, float *x,
                      hipStream_t st) {
-  hipLaunchKernelGGL(k_update_p, dim3(vec_blocks(n)), dim3(kBlock), 0, st, s, r, p, n, M);
+  if (x)
+    hipLaunchKernelGGL(k_update_p<true>, dim3(vec_blocks(n)), dim3(kBlock), 0, st, s, r, p, n, M, x);
+  else
+    hipLaunchKernelGGL(k_update_p<false>, dim3(vec_blocks(n)), dim3(kBlock), 0, st, s, r, p, n, M, x);
 }
 // y = a*y + c  (preconditioner diagonal: tau * AtA(1) + const)
 __global__ void __launch_bounds__(kBlock) k_scale_shift(float a, float c, float *__restrict__ y, size_t n) {

@@ -21,7 +21,9 @@ void launch_dot(const float *a, const float *b, size_t n, double *part, const in
 void launch_update_xr(const CgState *s, const float *p, const float *ap, float *x, float *r,
                       const float *b, size_t n, double *part_rr, double *part_obj, const float *M,
                       hipStream_t st);
-void launch_update_p(const CgState *s, const float *r, float *p, size_t n, const float *M,
+// x == nullptr in launch_update_xr defers "x += alpha p" to launch_update_p(..., x): one volume
+// pass less per iteration (only valid when nothing stops the solve between the two launches)
+void launch_update_p(const CgState *s, const float *r, float *p, size_t n, const float *M, float *x,
                      hipStream_t st);
 // M = nullptr: identity preconditioner; else z = r / M (Jacobi)
 void launch_scale_shift(float a, float c, float *y, size_t n, hipStream_t st);
