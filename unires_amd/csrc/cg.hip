@@ -206,8 +206,18 @@ __global__ void __launch_bounds__(kBlock)
 
 // ---- scalar kernels: <<<1, kBlock>>> -------------------------------------
 __device__ __forceinline__ double sum_partials(const double *part, int g) {
+  // loads batched eight deep (the additions keep their order): this one-block kernel is pure
+  // latency, and sixteen dependent load->add steps per thread were most of its 6 us
   double v = 0.0;
-  for (int i = threadIdx.x; i < g; i += kBlock) v += part[i];
+  int i = threadIdx.x;
+  for (; i + 7 * kBlock < g; i += 8 * kBlock) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = part[i + u * kBlock];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; i < g; i += kBlock) v += part[i];
   return block_sum(v);
 }
 
