@@ -56,6 +56,10 @@ struct SplatArgs {
 //         8 x 8 x 30, L = 32 : 219 / 281 / 267 us   (fewer segments, but 12 instead of 16 waves/CU)
 //         6 x 4 x 30, L = 32 : 204 / 287 / 274 us   (20 instead of 16 waves/CU, but 34 % more tiles)
 //   earlier sweeps of the long form: 6x6 230, 4x8 249, 4x4 329 (vs 8x4 218)
+// Also tried and dropped: packing the short segments of a tilted grid (half of them are <= 16
+// lanes) four to an instruction - 183 / 235 / 221 us with a second code instantiation, 187 / 254 /
+// 235 us with a run-time group width: short segments come from rows next to the same tile face,
+// so the packed rows conflict and fall into the serialised turn schedule.
 // UNIRES_SPLAT_CFG=short selects the short tile (kept as a tested variant).
 struct SplatLong {
   static constexpr int TX = 8, TY = 4, TZ = 30, L = 32;
