@@ -201,7 +201,7 @@ def _update_scaling(x, y, sett, max_niter_gn=1, num_linesearch=4, verbose=0):
                 ll = 0.5 * tau * s[0]
                 gr = tau * (s[1] - s[2])
                 hes = tau * (s[3] + s[4])
-                update = gr / hes
+                update = float(torch.tensor(gr, dtype=torch.float64) / torch.tensor(hes, dtype=torch.float64))  # IEEE: 0/0 -> nan, like the reference's tensors
                 old_scl, old_ll, armijo = scl, ll, 1.0
                 if num_linesearch == 0:
                     scl = old_scl - armijo * update
