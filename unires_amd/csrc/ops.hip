@@ -75,52 +75,6 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // --------------------------------------------------------------------------
-// push: dst[corner_c(M g)] += alpha * w_c * mask(g) * val(g)   (scatter, f32 atomics)
-// val(g) = src[g]                       (CONVUP = false; regime 1)
-//        = conv_up(S xs)[g]             (CONVUP = true;  regime 2, fuses the
-//                                        transposed conv so the grid-space
-//                                        intermediate never exists in HBM)
-// --------------------------------------------------------------------------
-template <bool CONVUP>
-__global__ void __launch_bounds__(kBlock)
-    k_push(const float *__restrict__ src, Dim3i xd, Taps T, Scaling S, Dim3i gd, Affine A,
-           float *__restrict__ dst, Dim3i dd, float alpha, float tol,
-           const int *__restrict__ done) {
-  if (done && *done) return;
-  const int k = blockIdx.x * kWave + threadIdx.x;
-  const int j = blockIdx.y * 4 + threadIdx.y;
-  const int i = blockIdx.z;
-  if (k >= gd.z || j >= gd.y) return;
-  float gx, gy, gz;
-  affine_point(A, (float)i, (float)j, (float)k, gx, gy, gz);
-  if (!in_fov(gx, gy, gz, dd, tol)) return;
-  float v;
-  if (CONVUP)
-    v = conv_up_sample(src, xd, T, S, i, j, k);
-  else
-    v = src[((size_t)i * gd.y + j) * gd.z + k];
-  v *= alpha;
-  if (v == 0.f) return;
-  const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
-  const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-  const float wx1 = gx - fx, wy1 = gy - fy, wz1 = gz - fz;
-  const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
-  const bool x0 = ix >= 0 && ix < dd.x, x1 = ix + 1 >= 0 && ix + 1 < dd.x;
-  const bool y0 = iy >= 0 && iy < dd.y, y1 = iy + 1 >= 0 && iy + 1 < dd.y;
-  const bool z0 = iz >= 0 && iz < dd.z, z1 = iz + 1 >= 0 && iz + 1 < dd.z;
-  const long long sx = (long long)dd.y * dd.z, sy = dd.z;
-  float *p = dst + ((long long)ix * sx + (long long)iy * sy + iz);
-  if (x0 && y0 && z0) atomicAdd(p, v * (wx0 * wy0 * wz0));
-  if (x0 && y0 && z1) atomicAdd(p + 1, v * (wx0 * wy0 * wz1));
-  if (x0 && y1 && z0) atomicAdd(p + sy, v * (wx0 * wy1 * wz0));
-  if (x0 && y1 && z1) atomicAdd(p + sy + 1, v * (wx0 * wy1 * wz1));
-  if (x1 && y0 && z0) atomicAdd(p + sx, v * (wx1 * wy0 * wz0));
-  if (x1 && y0 && z1) atomicAdd(p + sx + 1, v * (wx1 * wy0 * wz1));
-  if (x1 && y1 && z0) atomicAdd(p + sx + sy, v * (wx1 * wy1 * wz0));
-  if (x1 && y1 && z1) atomicAdd(p + sx + sy + 1, v * (wx1 * wy1 * wz1));
-}
-
-// --------------------------------------------------------------------------
 // conv_down: dst[i,j,k] = S(i,j,k) * sum_abc kx[a]ky[b]kz[c] src[rx i+a, ry j+b, rz k+c]
 // (F.conv3d, cross-correlation, no padding) + _apply_scaling epilogue
 // --------------------------------------------------------------------------
@@ -256,21 +210,6 @@ __global__ void __launch_bounds__(kBlock) k_pull_grad(const float *__restrict__ 
 void launch_pull_grad(const float *src, Dim3i sd, const Affine &A, float *dst, Dim3i gd, float tol,
                       hipStream_t st) {
   hipLaunchKernelGGL(k_pull_grad, vol_grid(gd), vol_block(), 0, st, src, sd, A, dst, gd, tol);
-}
-
-void launch_push(const float *src, Dim3i gd, const Affine &A, float *dst, Dim3i dd, float alpha,
-                 float tol, const int *done, hipStream_t st) {
-  Taps T{};
-  Scaling S{1.f, 1.f, -1};
-  hipLaunchKernelGGL(k_push<false>, vol_grid(gd), vol_block(), 0, st, src, gd, T, S, gd, A, dst,
-                     dd, alpha, tol, done);
-}
-
-void launch_push_convup(const float *xs, Dim3i xd, const Taps &T, const Scaling &S, Dim3i gd,
-                        const Affine &A, float *dst, Dim3i dd, float alpha, float tol,
-                        const int *done, hipStream_t st) {
-  hipLaunchKernelGGL(k_push<true>, vol_grid(gd), vol_block(), 0, st, xs, xd, T, S, gd, A, dst, dd,
-                     alpha, tol, done);
 }
 
 void launch_conv_down(const float *src, Dim3i gd, const Taps &T, const Scaling &S, float *dst,

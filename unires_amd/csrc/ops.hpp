@@ -6,11 +6,6 @@ namespace unires {
 
 void launch_pull(const float *src, Dim3i sd, const Affine &A, float *dst, Dim3i gd, float tol,
                  const int *done, hipStream_t st);
-void launch_push(const float *src, Dim3i gd, const Affine &A, float *dst, Dim3i dd, float alpha,
-                 float tol, const int *done, hipStream_t st);
-void launch_push_convup(const float *xs, Dim3i xd, const Taps &T, const Scaling &S, Dim3i gd,
-                        const Affine &A, float *dst, Dim3i dd, float alpha, float tol,
-                        const int *done, hipStream_t st);
 void launch_conv_down(const float *src, Dim3i gd, const Taps &T, const Scaling &S, float *dst,
                       Dim3i xd, const int *done, hipStream_t st);
 void launch_conv_up(const float *xs, Dim3i xd, const Taps &T, const Scaling &S, float *dst,
