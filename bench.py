@@ -37,6 +37,8 @@ WORKLOADS = {
     'cfg3_256c3_thick6z_aligned': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 2, 2), rigid='identity'),
     'cfg3_256c3_thick6xyz': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(0, 1, 2)),
     'cfg4_384c4_iso2': dict(dim_y=(384, 384, 384), C=4, thick=2, axes=None),
+    # the same with the reference's default in-plane profile (Gaussian, struct.py:95; fan-in > 2)
+    'cfg4_384c4_iso2_gauss': dict(dim_y=(384, 384, 384), C=4, thick=2, axes=None, prof_ip=2),
     'small_96c3_thick3': dict(dim_y=(96, 96, 96), C=3, thick=3, axes=(2, 2, 2)),
     # BASELINE configs[0] / [1] shapes (BrainWeb 1 mm, 181x217x181) on the synthetic phantom:
     # single-channel denoising with A = I (R0), 3-channel 1 mm recon after coregistration (R1)
@@ -101,8 +103,8 @@ def build_subject(wl, device, seed):
         method = 'super-resolution' if regime == 'sr' else 'denoising'
         if regime == 'id':
             rigid = torch.eye(4, dtype=torch.float64)
-        po = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=0, prof_tp=0,
-                          device=device)
+        po = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=wl.get('prof_ip', 0),
+                          prof_tp=0, device=device)
         clean = truth if regime == 'id' else U._proj_apply('A', truth[None, None], po, method=method)[0, 0]
         noise = torch.randn(clean.shape, generator=gen).to(device) * sd
         x.append([U._input(clean + noise, mat_x, 1.0 / sd ** 2, po)])

@@ -261,6 +261,7 @@ struct Repeat {
   Affine Af, Afinv;
   Taps Tf;
   SplatSafety safe;  // of Af (the linear part is the same for A)
+  bool sep = false;  // many-tap profile: convolutions run as separable 1-D passes
   // device tables for the on-the-fly conv_up of k_gather2: [0] no scaling (AtA), [1] S(scl) (At)
   float *ztab_dev[2] = {nullptr, nullptr};
 };
@@ -276,6 +277,7 @@ struct unires_plan {
   size_t ws_bytes = 0;
   float *r = nullptr, *p = nullptr, *ap = nullptr, *ax = nullptr;  // N_y each
   float *gbuf = nullptr;                                           // max N_g
+  float *gbuf2 = nullptr;  // second grid-space scratch, only for many-tap profiles (separable passes)
   float *xbuf = nullptr;                                           // max N_x
   double *part0 = nullptr, *part1 = nullptr;                       // kMaxPartials each
   CgState *state = nullptr;
@@ -317,6 +319,12 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
     for (int d = 0; d < 3; ++d) out.T.n[d] = out.T.s[d] = 1, out.T.t[d][0] = 1.f;
   }
   trim_taps(out.T, out.A, out.dim_g, out.Tf, out.Af, out.dim_gf);
+  // many taps (e.g. a Gaussian in-plane profile on top of the slice profile): the fused kernels'
+  // direct 3-D sum (prod n_d taps per output, fan-in^3 gathers per grid voxel) loses to one
+  // 1-D pass per axis through grid-space scratch
+  out.sep = (long long)out.Tf.n[0] * out.Tf.n[1] * out.Tf.n[2] > 64;
+  for (int d = 0; d < 3; ++d)
+    if ((out.Tf.n[d] + out.Tf.s[d] - 1) / out.Tf.s[d] > 2) out.sep = true;
   if (!invert_affine(out.Af, out.Afinv)) return fail(UNIRES_ERR_ARG, "singular affine");
   splat_safety(out.Af, out.safe.row_sep, out.safe.use_atomics);
   return UNIRES_OK;
@@ -364,6 +372,7 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
   pl->regime = regime;
   pl->fov_tol = fov_tol;
   pl->reps.resize(n_repeats);
+  bool need_sep = false;
   for (int n = 0; n < n_repeats; ++n) {
     int rc = fill_repeat(pl, &repeats[n], pl->reps[n]);
     if (rc) {
@@ -374,6 +383,7 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
       pl->cap_g = std::max(pl->cap_g, pl->reps[n].dim_g.numel());
       pl->cap_x = std::max(pl->cap_x, pl->reps[n].dim_x.numel());
     }
+    need_sep = need_sep || (regime == UNIRES_REGIME_SUPERRES && pl->reps[n].sep);
   }
   const size_t ny = pl->dy.numel();
   size_t off = 0;
@@ -384,6 +394,7 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
   };
   const size_t o_r = carve(ny * 4), o_p = carve(ny * 4), o_ap = carve(ny * 4), o_ax = carve(ny * 4);
   const size_t o_g = carve(pl->cap_g * 4), o_x = carve(pl->cap_x * 4);
+  const size_t o_g2 = carve(need_sep ? pl->cap_g * 4 : 0);
   const size_t o_p0 = carve(kMaxPartials * 8), o_p1 = carve(kMaxPartials * 8);
   const size_t o_st = carve(sizeof(CgState));
   pl->ws_bytes = off;
@@ -399,6 +410,7 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
   pl->ax = (float *)(pl->ws + o_ax);
   pl->gbuf = (float *)(pl->ws + o_g);
   pl->xbuf = (float *)(pl->ws + o_x);
+  pl->gbuf2 = need_sep ? (float *)(pl->ws + o_g2) : nullptr;
   pl->part0 = (double *)(pl->ws + o_p0);
   pl->part1 = (double *)(pl->ws + o_p1);
   pl->state = (CgState *)(pl->ws + o_st);
@@ -442,6 +454,8 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   if (plan->regime != UNIRES_REGIME_IDENTITY &&
       (tmp.dim_g.numel() > plan->cap_g || tmp.dim_x.numel() > plan->cap_x))
     return fail(UNIRES_ERR_DIM, "new repeat exceeds the plan's workspace");
+  if (plan->regime == UNIRES_REGIME_SUPERRES && tmp.sep && !plan->gbuf2)
+    return fail(UNIRES_ERR_DIM, "new repeat needs the separable-conv scratch the plan was built without");
   if (tmp.dim_gf.z != plan->reps[n].dim_gf.z) free_ztabs(plan->reps[n]);
   tmp.ztab_dev[0] = plan->reps[n].ztab_dev[0];
   tmp.ztab_dev[1] = plan->reps[n].ztab_dev[1];
@@ -477,6 +491,11 @@ static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, co
   }
   // S(2 scl) once between conv and conv^T  (unires/_project.py:175-177)
   const Scaling S2 = make_scaling(2.f * R.scl, R.dim_thick);
+  if (R.sep && pl->gbuf2) {
+    launch_pull(in, pl->dy, R.Af, pl->gbuf, R.dim_gf, pl->fov_tol, done, st);
+    launch_conv_down_sep(pl->gbuf, R.dim_gf, R.Tf, S2, pl->xbuf, R.dim_x, pl->gbuf, pl->gbuf2, done, st);
+    return push_src(R, pl->xbuf, true, 0.f);
+  }
   if (launch_pull_conv(in, pl->dy, R.Af, R.Tf, S2, pl->xbuf, R.dim_x, R.dim_gf, pl->fov_tol, done,
                        st)) {
     launch_pull(in, pl->dy, R.A, pl->gbuf, R.dim_g, pl->fov_tol, done, st);
@@ -515,6 +534,16 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
   if (!use_tile &&
       !launch_splat(src, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
     return ep.partials ? splat_blocks(pl->dy, A) : 0;
+  if (!use_tile && src.convup && R.sep && pl->gbuf2) {
+    // many-tap profile: conv_up as 1-D passes into grid space, then the grid-source splat
+    PushSrc d = src;
+    d.data = launch_conv_up_sep(src.data, src.xd, src.T, src.S, src.gd, pl->gbuf, pl->gbuf2, st);
+    d.convup = 0;
+    if (!launch_splat(d, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
+      return ep.partials ? splat_blocks(pl->dy, A) : 0;
+    (void)launch_push_tile(d, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st);
+    return ep.partials ? push_tile_blocks(pl->dy) : 0;
+  }
   if (launch_push_tile(src, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st)) {
     launch_conv_up(src.data, src.xd, src.T, src.S, pl->gbuf, src.gd, st);
     PushSrc d = src;
@@ -556,9 +585,15 @@ extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, con
     if (plan->regime == UNIRES_REGIME_DENOISE) {
       launch_pull(in, plan->dy, R.A, out, R.dim_g, plan->fov_tol, nullptr, st);
     } else {
-      launch_pull(in, plan->dy, R.A, plan->gbuf, R.dim_g, plan->fov_tol, nullptr, st);
-      launch_conv_down(plan->gbuf, R.dim_g, R.T, make_scaling(R.scl, R.dim_thick), out, R.dim_x,
-                       nullptr, st);
+      if (R.sep && plan->gbuf2) {
+        launch_pull(in, plan->dy, R.Af, plan->gbuf, R.dim_gf, plan->fov_tol, nullptr, st);
+        launch_conv_down_sep(plan->gbuf, R.dim_gf, R.Tf, make_scaling(R.scl, R.dim_thick), out,
+                             R.dim_x, plan->gbuf, plan->gbuf2, nullptr, st);
+      } else {
+        launch_pull(in, plan->dy, R.A, plan->gbuf, R.dim_g, plan->fov_tol, nullptr, st);
+        launch_conv_down(plan->gbuf, R.dim_g, R.T, make_scaling(R.scl, R.dim_thick), out, R.dim_x,
+                         nullptr, st);
+      }
     }
   } else if (op == UNIRES_OP_AT) {
     at_accumulate(plan, R, in, out, 1.f, false, st);

@@ -194,6 +194,112 @@ void launch_pull(const float *src, Dim3i sd, const Affine &A, float *dst, Dim3i 
   hipLaunchKernelGGL(k_pull, grid, vol_block(), 0, st, src, sd, A, dst, gd, tol, done);
 }
 
+// --------------------------------------------------------------------------
+// Separable form of the slice-profile convolutions: one 1-D pass per non-dirac axis.
+// The fused kernels apply the 3-D kernel directly (fine for a thick-slice profile: 7 x 1 x 1
+// taps); a Gaussian in-plane profile on top (reference default, struct.py:95: 5 x 11 x 11 taps
+// for ratio 2) costs 605 taps per output directly and 27 as three passes.
+// --------------------------------------------------------------------------
+struct Taps1 {
+  float t[UNIRES_MAX_TAPS];
+};
+// dst[.., o, ..] = S(o) sum_t ker[t] src[.., s o + t, ..]   along `axis`
+__global__ void __launch_bounds__(kBlock)
+    k_conv1d_down(const float *__restrict__ src, Dim3i sd, int axis, Taps1 K, int n, int s,
+                  float se, float so, float *__restrict__ dst, Dim3i dd, const int *__restrict__ done) {
+  if (done && *done) return;
+  const int k = blockIdx.x * kWave + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
+  if (k >= dd.z || j >= dd.y) return;
+  const size_t sstr = axis == 0 ? (size_t)sd.y * sd.z : (axis == 1 ? (size_t)sd.z : 1);
+  const int o = axis == 0 ? i : (axis == 1 ? j : k);
+  const size_t base = ((size_t)(axis == 0 ? s * i : i) * sd.y + (axis == 1 ? s * j : j)) * sd.z +
+                      (axis == 2 ? s * k : k);
+  float acc = 0.f;
+  for (int t = 0; t < n; ++t) acc = fmaf(K.t[t], src[base + (size_t)t * sstr], acc);
+  dst[((size_t)i * dd.y + j) * dd.z + k] = acc * ((o & 1) ? so : se);
+}
+// dst[.., u, ..] = sum_k ker[u - s k] S(k) src[.., k, ..]   along `axis` (transposed conv)
+__global__ void __launch_bounds__(kBlock)
+    k_conv1d_up(const float *__restrict__ src, Dim3i sd, int axis, Taps1 K, int n, int s, float se,
+                float so, float *__restrict__ dst, Dim3i dd) {
+  __shared__ float taps[UNIRES_MAX_TAPS];
+  const int tid = threadIdx.y * kWave + threadIdx.x;
+  if (tid < UNIRES_MAX_TAPS) taps[tid] = K.t[tid];
+  __syncthreads();
+  const int k = blockIdx.x * kWave + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
+  if (k >= dd.z || j >= dd.y) return;
+  const size_t sstr = axis == 0 ? (size_t)sd.y * sd.z : (axis == 1 ? (size_t)sd.z : 1);
+  const int u = axis == 0 ? i : (axis == 1 ? j : k);
+  const int nsrc = axis == 0 ? sd.x : (axis == 1 ? sd.y : sd.z);
+  int lo, hi;
+  up_range(u, n, s, nsrc, lo, hi);
+  const size_t base = ((size_t)(axis == 0 ? 0 : i) * sd.y + (axis == 1 ? 0 : j)) * sd.z + (axis == 2 ? 0 : k);
+  float acc = 0.f;
+  for (int c = lo; c <= hi; ++c)
+    acc = fmaf(taps[u - s * c] * ((c & 1) ? so : se), src[base + (size_t)c * sstr], acc);
+  dst[((size_t)i * dd.y + j) * dd.z + k] = acc;
+}
+
+static inline Dim3i with_axis(Dim3i d, int axis, int v) {
+  if (axis == 0) d.x = v;
+  if (axis == 1) d.y = v;
+  if (axis == 2) d.z = v;
+  return d;
+}
+static inline int axis_len(const Dim3i &d, int axis) { return axis == 0 ? d.x : (axis == 1 ? d.y : d.z); }
+static inline bool axis_is_dirac(const Taps &T, int a) {
+  return T.n[a] == 1 && T.s[a] == 1 && T.t[a][0] == 1.f;
+}
+
+// xs = S conv_down(g): passes z, y, x through two scratch volumes (a and b, each >= numel(gd));
+// the last pass writes dst.  `g` may be `a`.
+void launch_conv_down_sep(const float *g, Dim3i gd, const Taps &T, const Scaling &S, float *dst,
+                          Dim3i xd, float *a, float *b, const int *done, hipStream_t st) {
+  const float *cur = g;
+  Dim3i cd = gd;
+  int todo = 0;
+  for (int ax = 0; ax < 3; ++ax) todo += !axis_is_dirac(T, ax) || S.dim == ax;
+  if (todo == 0) {  // identity: plain copy
+    (void)hipMemcpyAsync(dst, g, gd.numel() * sizeof(float), hipMemcpyDeviceToDevice, st);
+    return;
+  }
+  for (int ax = 2; ax >= 0; --ax) {
+    if (axis_is_dirac(T, ax) && S.dim != ax) continue;
+    const Dim3i od = with_axis(cd, ax, axis_len(xd, ax));
+    float *out = --todo == 0 ? dst : (cur == a ? b : a);
+    Taps1 K;
+    for (int t = 0; t < UNIRES_MAX_TAPS; ++t) K.t[t] = T.t[ax][t];
+    const bool sc = S.dim == ax;
+    hipLaunchKernelGGL(k_conv1d_down, vol_grid(od), vol_block(), 0, st, cur, cd, ax, K, T.n[ax], T.s[ax],
+                       sc ? S.e : 1.f, sc ? S.o : 1.f, out, od, done);
+    cur = out, cd = od;
+  }
+}
+
+// g = conv_up(S xs): passes x, y, z; returns the buffer (a or b) that holds the grid volume.
+float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scaling &S, Dim3i gd,
+                          float *a, float *b, hipStream_t st) {
+  const float *cur = xs;
+  Dim3i cd = xd;
+  float *out = nullptr;
+  for (int ax = 0; ax < 3; ++ax) {
+    if (axis_is_dirac(T, ax) && S.dim != ax) continue;
+    const Dim3i od = with_axis(cd, ax, axis_len(gd, ax));
+    out = cur == a ? b : a;
+    Taps1 K;
+    for (int t = 0; t < UNIRES_MAX_TAPS; ++t) K.t[t] = T.t[ax][t];
+    const bool sc = S.dim == ax;
+    hipLaunchKernelGGL(k_conv1d_up, vol_grid(od), vol_block(), 0, st, cur, cd, ax, K, T.n[ax], T.s[ax],
+                       sc ? S.e : 1.f, sc ? S.o : 1.f, out, od);
+    cur = out, cd = od;
+  }
+  if (!out) {  // identity
+    (void)hipMemcpyAsync(a, xs, xd.numel() * sizeof(float), hipMemcpyDeviceToDevice, st);
+    out = a;
+  }
+  return out;
+}
+
 // dst[(i,j,k), 0..2] = gradient of the trilinear sample at A (i,j,k)  (nitorch grid_grad layout)
 __global__ void __launch_bounds__(kBlock) k_pull_grad(const float *__restrict__ src, Dim3i sd,
                                                       Affine A, float *__restrict__ dst, Dim3i gd,

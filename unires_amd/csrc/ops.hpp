@@ -16,6 +16,12 @@ void launch_div(const float *ua, const float *ub, float ca, float cb, Dim3i d, c
                 float scale, const float *add, float *dst, hipStream_t st);
 void launch_pull_grad(const float *src, Dim3i sd, const Affine &A, float *dst, Dim3i gd, float tol,
                       hipStream_t st);
+// separable (one 1-D pass per axis) forms of conv_down / conv_up for profiles with many taps;
+// a, b: scratch volumes of at least numel(gd) floats each
+void launch_conv_down_sep(const float *g, Dim3i gd, const Taps &T, const Scaling &S, float *dst,
+                          Dim3i xd, float *a, float *b, const int *done, hipStream_t st);
+float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scaling &S, Dim3i gd,
+                          float *a, float *b, hipStream_t st);
 int dtd_num_blocks(Dim3i d);
 // dst = a*src + c*DtD(src); partials (nullable, dtd_num_blocks doubles) gets sum(src*dst) pieces;
 // with objb (needs partials): partials = sum (dst - 2 objb) * src and dst is not stored.
