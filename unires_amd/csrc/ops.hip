@@ -240,6 +240,53 @@ __global__ void __launch_bounds__(kBlock)
   dst[((size_t)i * dd.y + j) * dd.z + k] = acc;
 }
 
+// z-axis forms: a wave stages the contiguous piece of the input row it needs in LDS with
+// coalesced loads (the generic kernels above issue one strided global load per tap and lane).
+constexpr int kConvZStage = 64 * 8 + UNIRES_MAX_TAPS;  // stride <= 8
+__global__ void __launch_bounds__(kBlock)
+    k_conv1d_down_z(const float *__restrict__ src, Dim3i sd, Taps1 K, int n, int s, float se, float so,
+                    float *__restrict__ dst, Dim3i dd, const int *__restrict__ done) {
+  if (done && *done) return;
+  __shared__ float stage[kBlock / kWave][kConvZStage];
+  const int lane = threadIdx.x, w = threadIdx.y;
+  const int k0 = blockIdx.x * kWave, j = blockIdx.y * 4 + w, i = blockIdx.z;
+  if (j >= dd.y) return;
+  const float *row = src + ((size_t)i * sd.y + j) * sd.z;
+  const int z0 = s * k0, need = min(s * kWave + n - s, sd.z - z0);
+  for (int t = lane; t < need; t += kWave) stage[w][t] = row[z0 + t];
+  asm volatile("" ::: "memory");  // one wave, LDS ops in order
+  const int k = k0 + lane;
+  if (k >= dd.z) return;
+  float acc = 0.f;
+  for (int t = 0; t < n; ++t) acc = fmaf(K.t[t], stage[w][s * lane + t], acc);
+  dst[((size_t)i * dd.y + j) * dd.z + k] = acc * ((k & 1) ? so : se);
+}
+__global__ void __launch_bounds__(kBlock)
+    k_conv1d_up_z(const float *__restrict__ src, Dim3i sd, Taps1 K, int n, int s, float se, float so,
+                  float *__restrict__ dst, Dim3i dd) {
+  __shared__ float taps[UNIRES_MAX_TAPS];
+  __shared__ float stage[kBlock / kWave][kWave + UNIRES_MAX_TAPS + 2];
+  const int lane = threadIdx.x, w = threadIdx.y;
+  const int tid = w * kWave + lane;
+  if (tid < UNIRES_MAX_TAPS) taps[tid] = K.t[tid];
+  __syncthreads();
+  const int u0 = blockIdx.x * kWave, j = blockIdx.y * 4 + w, i = blockIdx.z;
+  if (j >= dd.y) return;
+  const float *row = src + ((size_t)i * sd.y + j) * sd.z;
+  int c0, c1, dummy;
+  up_range(u0, n, s, sd.z, c0, dummy);                           // first slice feeding this piece
+  up_range(min(u0 + kWave - 1, dd.z - 1), n, s, sd.z, dummy, c1);  // last one
+  for (int t = lane; t <= c1 - c0; t += kWave) stage[w][t] = row[c0 + t];
+  asm volatile("" ::: "memory");
+  const int u = u0 + lane;
+  if (u >= dd.z) return;
+  int lo, hi;
+  up_range(u, n, s, sd.z, lo, hi);
+  float acc = 0.f;
+  for (int c = lo; c <= hi; ++c) acc = fmaf(taps[u - s * c] * ((c & 1) ? so : se), stage[w][c - c0], acc);
+  dst[((size_t)i * dd.y + j) * dd.z + u] = acc;
+}
+
 static inline Dim3i with_axis(Dim3i d, int axis, int v) {
   if (axis == 0) d.x = v;
   if (axis == 1) d.y = v;
@@ -270,8 +317,12 @@ void launch_conv_down_sep(const float *g, Dim3i gd, const Taps &T, const Scaling
     Taps1 K;
     for (int t = 0; t < UNIRES_MAX_TAPS; ++t) K.t[t] = T.t[ax][t];
     const bool sc = S.dim == ax;
-    hipLaunchKernelGGL(k_conv1d_down, vol_grid(od), vol_block(), 0, st, cur, cd, ax, K, T.n[ax], T.s[ax],
-                       sc ? S.e : 1.f, sc ? S.o : 1.f, out, od, done);
+    if (ax == 2 && T.s[2] <= 8)
+      hipLaunchKernelGGL(k_conv1d_down_z, vol_grid(od), vol_block(), 0, st, cur, cd, K, T.n[2], T.s[2],
+                         sc ? S.e : 1.f, sc ? S.o : 1.f, out, od, done);
+    else
+      hipLaunchKernelGGL(k_conv1d_down, vol_grid(od), vol_block(), 0, st, cur, cd, ax, K, T.n[ax],
+                         T.s[ax], sc ? S.e : 1.f, sc ? S.o : 1.f, out, od, done);
     cur = out, cd = od;
   }
 }
@@ -289,8 +340,12 @@ float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scalin
     Taps1 K;
     for (int t = 0; t < UNIRES_MAX_TAPS; ++t) K.t[t] = T.t[ax][t];
     const bool sc = S.dim == ax;
-    hipLaunchKernelGGL(k_conv1d_up, vol_grid(od), vol_block(), 0, st, cur, cd, ax, K, T.n[ax], T.s[ax],
-                       sc ? S.e : 1.f, sc ? S.o : 1.f, out, od);
+    if (ax == 2)
+      hipLaunchKernelGGL(k_conv1d_up_z, vol_grid(od), vol_block(), 0, st, cur, cd, K, T.n[2], T.s[2],
+                         sc ? S.e : 1.f, sc ? S.o : 1.f, out, od);
+    else
+      hipLaunchKernelGGL(k_conv1d_up, vol_grid(od), vol_block(), 0, st, cur, cd, ax, K, T.n[ax], T.s[ax],
+                         sc ? S.e : 1.f, sc ? S.o : 1.f, out, od);
     cur = out, cd = od;
   }
   if (!out) {  // identity
