@@ -208,15 +208,26 @@ __global__ void __launch_bounds__(kBlock)
     k_conv1d_down(const float *__restrict__ src, Dim3i sd, int axis, Taps1 K, int n, int s,
                   float se, float so, float *__restrict__ dst, Dim3i dd, const int *__restrict__ done) {
   if (done && *done) return;
-  const int k = blockIdx.x * kWave + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
+  const int k = blockIdx.x * kWave + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
   if (k >= dd.z || j >= dd.y) return;
   const size_t sstr = axis == 0 ? (size_t)sd.y * sd.z : (axis == 1 ? (size_t)sd.z : 1);
-  const int o = axis == 0 ? i : (axis == 1 ? j : k);
-  const size_t base = ((size_t)(axis == 0 ? s * i : i) * sd.y + (axis == 1 ? s * j : j)) * sd.z +
-                      (axis == 2 ? s * k : k);
-  float acc = 0.f;
-  for (int t = 0; t < n; ++t) acc = fmaf(K.t[t], src[base + (size_t)t * sstr], acc);
-  dst[((size_t)i * dd.y + j) * dd.z + k] = acc * ((o & 1) ? so : se);
+  for (int i = blockIdx.z; i < dd.x; i += gridDim.z) {  // several x slabs per workgroup
+    const int o = axis == 0 ? i : (axis == 1 ? j : k);
+    const size_t base = ((size_t)(axis == 0 ? s * i : i) * sd.y + (axis == 1 ? s * j : j)) * sd.z +
+                        (axis == 2 ? s * k : k);
+    // loads batched four deep (the sum keeps its order): a one-load-per-iteration loop is a
+    // chain of full memory round trips
+    float acc = 0.f;
+    int t = 0;
+    for (; t + 4 <= n; t += 4) {
+      const float v0 = src[base + (size_t)t * sstr], v1 = src[base + (size_t)(t + 1) * sstr],
+                  v2 = src[base + (size_t)(t + 2) * sstr], v3 = src[base + (size_t)(t + 3) * sstr];
+      acc = fmaf(K.t[t], v0, acc), acc = fmaf(K.t[t + 1], v1, acc);
+      acc = fmaf(K.t[t + 2], v2, acc), acc = fmaf(K.t[t + 3], v3, acc);
+    }
+    for (; t < n; ++t) acc = fmaf(K.t[t], src[base + (size_t)t * sstr], acc);
+    dst[((size_t)i * dd.y + j) * dd.z + k] = acc * ((o & 1) ? so : se);
+  }
 }
 // dst[.., u, ..] = sum_k ker[u - s k] S(k) src[.., k, ..]   along `axis` (transposed conv)
 __global__ void __launch_bounds__(kBlock)
@@ -226,18 +237,26 @@ __global__ void __launch_bounds__(kBlock)
   const int tid = threadIdx.y * kWave + threadIdx.x;
   if (tid < UNIRES_MAX_TAPS) taps[tid] = K.t[tid];
   __syncthreads();
-  const int k = blockIdx.x * kWave + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
+  const int k = blockIdx.x * kWave + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
   if (k >= dd.z || j >= dd.y) return;
   const size_t sstr = axis == 0 ? (size_t)sd.y * sd.z : (axis == 1 ? (size_t)sd.z : 1);
-  const int u = axis == 0 ? i : (axis == 1 ? j : k);
   const int nsrc = axis == 0 ? sd.x : (axis == 1 ? sd.y : sd.z);
-  int lo, hi;
-  up_range(u, n, s, nsrc, lo, hi);
-  const size_t base = ((size_t)(axis == 0 ? 0 : i) * sd.y + (axis == 1 ? 0 : j)) * sd.z + (axis == 2 ? 0 : k);
-  float acc = 0.f;
-  for (int c = lo; c <= hi; ++c)
-    acc = fmaf(taps[u - s * c] * ((c & 1) ? so : se), src[base + (size_t)c * sstr], acc);
-  dst[((size_t)i * dd.y + j) * dd.z + k] = acc;
+  const float inv_s = 1.f / (float)s;
+  for (int i = blockIdx.z; i < dd.x; i += gridDim.z) {  // several x slabs per workgroup
+    const int u = axis == 0 ? i : (axis == 1 ? j : k);
+    int lo, hi;
+    up_range_f(u, n, s, inv_s, nsrc, lo, hi);
+    const size_t base = ((size_t)(axis == 0 ? 0 : i) * sd.y + (axis == 1 ? 0 : j)) * sd.z + (axis == 2 ? 0 : k);
+    float acc = 0.f;
+    int c = lo;
+    for (; c + 2 <= hi + 1; c += 2) {  // two loads in flight
+      const float v0 = src[base + (size_t)c * sstr], v1 = src[base + (size_t)(c + 1) * sstr];
+      acc = fmaf(taps[u - s * c] * ((c & 1) ? so : se), v0, acc);
+      acc = fmaf(taps[u - s * (c + 1)] * (((c + 1) & 1) ? so : se), v1, acc);
+    }
+    for (; c <= hi; ++c) acc = fmaf(taps[u - s * c] * ((c & 1) ? so : se), src[base + (size_t)c * sstr], acc);
+    dst[((size_t)i * dd.y + j) * dd.z + k] = acc;
+  }
 }
 
 // z-axis forms: a wave stages the contiguous piece of the input row it needs in LDS with
@@ -249,17 +268,21 @@ __global__ void __launch_bounds__(kBlock)
   if (done && *done) return;
   __shared__ float stage[kBlock / kWave][kConvZStage];
   const int lane = threadIdx.x, w = threadIdx.y;
-  const int k0 = blockIdx.x * kWave, j = blockIdx.y * 4 + w, i = blockIdx.z;
+  const int k0 = blockIdx.x * kWave, j = blockIdx.y * 4 + w;
   if (j >= dd.y) return;
-  const float *row = src + ((size_t)i * sd.y + j) * sd.z;
   const int z0 = s * k0, need = min(s * kWave + n - s, sd.z - z0);
-  for (int t = lane; t < need; t += kWave) stage[w][t] = row[z0 + t];
-  asm volatile("" ::: "memory");  // one wave, LDS ops in order
   const int k = k0 + lane;
-  if (k >= dd.z) return;
-  float acc = 0.f;
-  for (int t = 0; t < n; ++t) acc = fmaf(K.t[t], stage[w][s * lane + t], acc);
-  dst[((size_t)i * dd.y + j) * dd.z + k] = acc * ((k & 1) ? so : se);
+  for (int i = blockIdx.z; i < dd.x; i += gridDim.z) {  // several x slabs per workgroup
+    const float *row = src + ((size_t)i * sd.y + j) * sd.z;
+    asm volatile("" ::: "memory");
+    for (int t = lane; t < need; t += kWave) stage[w][t] = row[z0 + t];
+    asm volatile("" ::: "memory");  // one wave, LDS ops in order
+    if (k < dd.z) {
+      float acc = 0.f;
+      for (int t = 0; t < n; ++t) acc = fmaf(K.t[t], stage[w][s * lane + t], acc);
+      dst[((size_t)i * dd.y + j) * dd.z + k] = acc * ((k & 1) ? so : se);
+    }
+  }
 }
 __global__ void __launch_bounds__(kBlock)
     k_conv1d_up_z(const float *__restrict__ src, Dim3i sd, Taps1 K, int n, int s, float se, float so,
@@ -270,23 +293,39 @@ __global__ void __launch_bounds__(kBlock)
   const int tid = w * kWave + lane;
   if (tid < UNIRES_MAX_TAPS) taps[tid] = K.t[tid];
   __syncthreads();
-  const int u0 = blockIdx.x * kWave, j = blockIdx.y * 4 + w, i = blockIdx.z;
+  const int u0 = blockIdx.x * kWave, j = blockIdx.y * 4 + w;
   if (j >= dd.y) return;
-  const float *row = src + ((size_t)i * sd.y + j) * sd.z;
   int c0, c1, dummy;
   up_range(u0, n, s, sd.z, c0, dummy);                           // first slice feeding this piece
   up_range(min(u0 + kWave - 1, dd.z - 1), n, s, sd.z, dummy, c1);  // last one
-  for (int t = lane; t <= c1 - c0; t += kWave) stage[w][t] = row[c0 + t];
-  asm volatile("" ::: "memory");
   const int u = u0 + lane;
-  if (u >= dd.z) return;
-  int lo, hi;
-  up_range(u, n, s, sd.z, lo, hi);
-  float acc = 0.f;
-  for (int c = lo; c <= hi; ++c) acc = fmaf(taps[u - s * c] * ((c & 1) ? so : se), stage[w][c - c0], acc);
-  dst[((size_t)i * dd.y + j) * dd.z + u] = acc;
+  int lo = 0, hi = -1;
+  if (u < dd.z) up_range_f(u, n, s, 1.f / (float)s, sd.z, lo, hi);
+  float wgt[UNIRES_MAX_TAPS / 4];  // this lane's (<= 8) weights are the same for every row
+  const int nw = min(hi - lo + 1, UNIRES_MAX_TAPS / 4);
+  for (int c = 0; c < UNIRES_MAX_TAPS / 4; ++c)
+    wgt[c] = c < nw ? taps[u - s * (lo + c)] * (((lo + c) & 1) ? so : se) : 0.f;
+  for (int i = blockIdx.z; i < dd.x; i += gridDim.z) {  // several x slabs per workgroup
+    const float *row = src + ((size_t)i * sd.y + j) * sd.z;
+    asm volatile("" ::: "memory");
+    for (int t = lane; t <= c1 - c0; t += kWave) stage[w][t] = row[c0 + t];
+    asm volatile("" ::: "memory");
+    if (u < dd.z) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < UNIRES_MAX_TAPS / 4; ++c)
+        if (c < nw) acc = fmaf(wgt[c], stage[w][lo - c0 + c], acc);
+      for (int c = lo + UNIRES_MAX_TAPS / 4; c <= hi; ++c)  // fan-in beyond 8: generic tail
+        acc = fmaf(taps[u - s * c] * ((c & 1) ? so : se), stage[w][c - c0], acc);
+      dst[((size_t)i * dd.y + j) * dd.z + u] = acc;
+    }
+  }
 }
 
+// grid of the 1-D conv passes: x slabs are looped inside the kernel (<= 48 workgroups along x)
+static inline dim3 conv1d_grid(const Dim3i &d) {
+  return dim3((d.z + kWave - 1) / kWave, (d.y + 3) / 4, d.x < 48 ? d.x : 48);
+}
 static inline Dim3i with_axis(Dim3i d, int axis, int v) {
   if (axis == 0) d.x = v;
   if (axis == 1) d.y = v;
@@ -318,10 +357,10 @@ void launch_conv_down_sep(const float *g, Dim3i gd, const Taps &T, const Scaling
     for (int t = 0; t < UNIRES_MAX_TAPS; ++t) K.t[t] = T.t[ax][t];
     const bool sc = S.dim == ax;
     if (ax == 2 && T.s[2] <= 8)
-      hipLaunchKernelGGL(k_conv1d_down_z, vol_grid(od), vol_block(), 0, st, cur, cd, K, T.n[2], T.s[2],
+      hipLaunchKernelGGL(k_conv1d_down_z, conv1d_grid(od), vol_block(), 0, st, cur, cd, K, T.n[2], T.s[2],
                          sc ? S.e : 1.f, sc ? S.o : 1.f, out, od, done);
     else
-      hipLaunchKernelGGL(k_conv1d_down, vol_grid(od), vol_block(), 0, st, cur, cd, ax, K, T.n[ax],
+      hipLaunchKernelGGL(k_conv1d_down, conv1d_grid(od), vol_block(), 0, st, cur, cd, ax, K, T.n[ax],
                          T.s[ax], sc ? S.e : 1.f, sc ? S.o : 1.f, out, od, done);
     cur = out, cd = od;
   }
@@ -341,10 +380,10 @@ float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scalin
     for (int t = 0; t < UNIRES_MAX_TAPS; ++t) K.t[t] = T.t[ax][t];
     const bool sc = S.dim == ax;
     if (ax == 2)
-      hipLaunchKernelGGL(k_conv1d_up_z, vol_grid(od), vol_block(), 0, st, cur, cd, K, T.n[2], T.s[2],
+      hipLaunchKernelGGL(k_conv1d_up_z, conv1d_grid(od), vol_block(), 0, st, cur, cd, K, T.n[2], T.s[2],
                          sc ? S.e : 1.f, sc ? S.o : 1.f, out, od);
     else
-      hipLaunchKernelGGL(k_conv1d_up, vol_grid(od), vol_block(), 0, st, cur, cd, ax, K, T.n[ax], T.s[ax],
+      hipLaunchKernelGGL(k_conv1d_up, conv1d_grid(od), vol_block(), 0, st, cur, cd, ax, K, T.n[ax], T.s[ax],
                          sc ? S.e : 1.f, sc ? S.o : 1.f, out, od);
     cur = out, cd = od;
   }
