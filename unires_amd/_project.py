@@ -131,8 +131,10 @@ def _plan_signature(x, y, method, do):
         po = xn.po
         if do:
             mat, dim_g = proj_matrix(po, method)
+            taps = tuple(tuple(float(v) for v in k) for k in _taps(po)) \
+                if method == 'super-resolution' else ()
             sig.append((tuple(_m12(mat).tolist()), dim_g, tuple(po.dim_x), float(po.scl),
-                        float(xn.tau), tuple(po.ratio)))
+                        float(xn.tau), tuple(po.ratio), taps))
         else:
             sig.append((float(xn.tau),))
     return tuple(sig)
