@@ -282,6 +282,20 @@ struct unires_plan {
   double *part0 = nullptr, *part1 = nullptr;                       // kMaxPartials each
   CgState *state = nullptr;
   size_t cap_g = 0, cap_x = 0;
+  // the whole CG solve as one hipGraph, re-launched while (b, x, rho, lam, options) stay the
+  // same - the ADMM loop calls it with identical arguments until the schedule changes
+  struct CgKey {
+    const float *b = nullptr;
+    float *x = nullptr;
+    float rho = 0.f, lam = 0.f;
+    int max_iter = -1, stop = -1, pre = -1;
+    double tol = -1.0;
+    bool operator==(const CgKey &o) const {
+      return b == o.b && x == o.x && rho == o.rho && lam == o.lam && max_iter == o.max_iter &&
+             stop == o.stop && pre == o.pre && tol == o.tol;
+    }
+  } cg_key;
+  hipGraphExec_t cg_exec = nullptr;
   float *precM = nullptr;  // Jacobi diagonal (own allocation, made by unires_precond_build)
   FftPre fft;              // FFT-diagonal preconditioner (plans + buffers, made on demand)
   float prec_rho = 0.f, prec_lam = 0.f;
@@ -438,6 +452,7 @@ extern "C" int unires_plan_destroy(unires_plan_t *plan) {
   if (!plan) return UNIRES_OK;
   if (plan->ws) (void)hipFree(plan->ws);
   if (plan->precM) (void)hipFree(plan->precM);
+  if (plan->cg_exec) (void)hipGraphExecDestroy(plan->cg_exec);
   fftpre_destroy(plan->fft);
   for (Repeat &R : plan->reps) free_ztabs(R);
   delete plan;
@@ -456,6 +471,10 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
     return fail(UNIRES_ERR_DIM, "new repeat exceeds the plan's workspace");
   if (plan->regime == UNIRES_REGIME_SUPERRES && tmp.sep && !plan->gbuf2)
     return fail(UNIRES_ERR_DIM, "new repeat needs the separable-conv scratch the plan was built without");
+  if (plan->cg_exec) {  // the captured solve has the old operator baked in
+    (void)hipGraphExecDestroy(plan->cg_exec);
+    plan->cg_exec = nullptr;
+  }
   if (tmp.dim_gf.z != plan->reps[n].dim_gf.z) free_ztabs(plan->reps[n]);
   tmp.ztab_dev[0] = plan->reps[n].ztab_dev[0];
   tmp.ztab_dev[1] = plan->reps[n].ztab_dev[1];
@@ -668,6 +687,10 @@ extern "C" int unires_ata_matvec(unires_plan_t *plan, float rho, float lam, cons
 extern "C" int unires_precond_build(unires_plan_t *plan, int32_t precond_mode, float rho,
                                     float lam, float *m_out, void *stream) {
   if (!plan) return fail(UNIRES_ERR_NULL, "null plan");
+  if (plan->cg_exec) {
+    (void)hipGraphExecDestroy(plan->cg_exec);
+    plan->cg_exec = nullptr;
+  }
   if (precond_mode == UNIRES_PRECOND_IDENTITY) {
     plan->prec_ready = false;
     return UNIRES_OK;
@@ -788,25 +811,9 @@ extern "C" int unires_rhs_from_atx(unires_plan_t *plan, const float *atx, const 
 // --------------------------------------------------------------------------
 // CG  (nitorch.core.optim.cg as UniRes calls it)
 // --------------------------------------------------------------------------
-extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const float *b, float *x,
-                               int32_t max_iter, double tol, int32_t stop_mode,
-                               int32_t precond_mode, int32_t *iters_out, double *obj_trace,
-                               void *stream) {
-  if (!plan || !b || !x) return fail(UNIRES_ERR_NULL, "null argument");
-  if (b == x) return fail(UNIRES_ERR_ARG, "b and x must not alias");
-  if (max_iter < 0 || max_iter > kMaxCgIter) return fail(UNIRES_ERR_ARG, "max_iter out of range");
-  if (stop_mode < 0 || stop_mode > 2) return fail(UNIRES_ERR_ARG, "bad stop mode");
-  if (precond_mode < UNIRES_PRECOND_IDENTITY || precond_mode > UNIRES_PRECOND_FFT)
-    return fail(UNIRES_ERR_UNSUPPORTED, "preconditioner modes: identity (0), Jacobi (1), FFT (2)");
-  if (precond_mode != UNIRES_PRECOND_IDENTITY &&
-      (!plan->prec_ready || plan->prec_mode != precond_mode || plan->prec_rho != rho ||
-       plan->prec_lam != lam))
-    return fail(UNIRES_ERR_ARG, "call unires_precond_build with this mode, rho and lam first");
-  const float *M = precond_mode == UNIRES_PRECOND_JACOBI ? plan->precM : nullptr;
-  const bool fft = precond_mode == UNIRES_PRECOND_FFT;
-  if (!(tol >= 0.0)) return fail(UNIRES_ERR_ARG, "tolerance must be >= 0");
-  hipStream_t st = (hipStream_t)stream;
-  unires_plan *pl = plan;
+// Enqueues the whole solve (every kernel of nitorch's cg()) on `st`.
+static int cg_enqueue(unires_plan *pl, float rho, float lam, const float *b, float *x, int max_iter,
+                      double tol, int stop_mode, const float *M, bool fft, hipStream_t st) {
   const size_t ny = pl->dy.numel();
   const bool check = tol != 0.0;
   CgState *S = pl->state;
@@ -849,9 +856,74 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
       launch_sc_obj(S, pl->part1, go, k, tol, st);
     }
   }
+  return UNIRES_OK;
+}
+
+extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const float *b, float *x,
+                               int32_t max_iter, double tol, int32_t stop_mode,
+                               int32_t precond_mode, int32_t *iters_out, double *obj_trace,
+                               void *stream) {
+  if (!plan || !b || !x) return fail(UNIRES_ERR_NULL, "null argument");
+  if (b == x) return fail(UNIRES_ERR_ARG, "b and x must not alias");
+  if (max_iter < 0 || max_iter > kMaxCgIter) return fail(UNIRES_ERR_ARG, "max_iter out of range");
+  if (stop_mode < 0 || stop_mode > 2) return fail(UNIRES_ERR_ARG, "bad stop mode");
+  if (precond_mode < UNIRES_PRECOND_IDENTITY || precond_mode > UNIRES_PRECOND_FFT)
+    return fail(UNIRES_ERR_UNSUPPORTED, "preconditioner modes: identity (0), Jacobi (1), FFT (2)");
+  if (precond_mode != UNIRES_PRECOND_IDENTITY &&
+      (!plan->prec_ready || plan->prec_mode != precond_mode || plan->prec_rho != rho ||
+       plan->prec_lam != lam))
+    return fail(UNIRES_ERR_ARG, "call unires_precond_build with this mode, rho and lam first");
+  const float *M = precond_mode == UNIRES_PRECOND_JACOBI ? plan->precM : nullptr;
+  const bool fft = precond_mode == UNIRES_PRECOND_FFT;
+  if (!(tol >= 0.0)) return fail(UNIRES_ERR_ARG, "tolerance must be >= 0");
+  hipStream_t st = (hipStream_t)stream;
+  unires_plan *pl = plan;
+
+  // hipGraph replay (UNIRES_CG_GRAPH=0 disables): the ~8 launches per iteration of a solve are
+  // captured once and re-launched as one graph while the arguments stay the same
+  static const bool use_graph = !(getenv("UNIRES_CG_GRAPH") && getenv("UNIRES_CG_GRAPH")[0] == '0');
+  unires_plan::CgKey key;
+  key.b = b, key.x = x, key.rho = rho, key.lam = lam, key.max_iter = max_iter, key.stop = stop_mode;
+  key.pre = precond_mode, key.tol = tol;
+  const bool graphable = use_graph && !fft && max_iter > 0;
+  if (graphable && pl->cg_exec && pl->cg_key == key) {
+    HIP_TRY(hipGraphLaunch(pl->cg_exec, st));
+  } else {
+    bool capturing = false;
+    if (graphable) {
+      if (pl->cg_exec) {
+        (void)hipGraphExecDestroy(pl->cg_exec);
+        pl->cg_exec = nullptr;
+      }
+      capturing = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (!capturing) (void)hipGetLastError();
+    }
+    const int rc = cg_enqueue(pl, rho, lam, b, x, max_iter, tol, stop_mode, M, fft, st);
+    if (capturing) {
+      hipGraph_t graph = nullptr;
+      const hipError_t ce = hipStreamEndCapture(st, &graph);
+      if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      if (ce != hipSuccess || !graph) return fail(UNIRES_ERR_HIP, "hipStreamEndCapture failed");
+      const hipError_t ge = hipGraphInstantiate(&pl->cg_exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ge != hipSuccess) {
+        pl->cg_exec = nullptr;
+        return fail(UNIRES_ERR_HIP, "hipGraphInstantiate failed");
+      }
+      pl->cg_key = key;
+      HIP_TRY(hipGraphLaunch(pl->cg_exec, st));
+    } else if (rc) {
+      return rc;
+    }
+  }
   CHECK_LAUNCH();
 
   if (iters_out) {
+    CgState *S = pl->state;
+    const bool check = tol != 0.0;
     int it = 0;
     HIP_TRY(hipMemcpyAsync(&it, &S->iters, sizeof(int), hipMemcpyDeviceToHost, st));
     if (obj_trace && check)
