@@ -1,0 +1,31 @@
+# random problems through the fused path (matvec, RHS, y-update) against the CPU oracle
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import nitorch_restated as N, unires_restated as O
+from tests.helpers import make_problem, oracle_structs, gpu_structs, rel_err, run_oracle_update_y, run_gpu_update_y
+import unires_amd as U
+dev = 'cuda:0'
+g = torch.Generator().manual_seed(int(os.environ.get('SEED', '0')))
+worst = 0.0
+for it in range(int(os.environ.get('N', '12'))):
+    dims = tuple(int(v) for v in torch.randint(10, 40, (3,), generator=g))
+    regime = ['sr', 'sr', 'dn'][int(torch.randint(0, 3, (1,), generator=g))]
+    kw = dict(dim_y=dims, n_channels=int(torch.randint(1, 3, (1,), generator=g)), regime=regime,
+              rot=float(torch.rand(1, generator=g)) * 0.25, trans=float(torch.rand(1, generator=g)) * 4,
+              seed=1000 + it)
+    if regime == 'sr':
+        kw.update(thick=int(torch.randint(2, 6, (1,), generator=g)), scl=float(torch.rand(1, generator=g)) * 0.2,
+                  n_repeats=int(torch.randint(1, 3, (1,), generator=g)))
+    try:
+        prob = make_problem(**kw)
+    except Exception as e:  # degenerate draw (e.g. a thick axis longer than the volume)
+        print('skip', kw, type(e).__name__)
+        continue
+    y_ref, info_ref = run_oracle_update_y(prob, max_iter=10, tol=1e-3)
+    y_gpu, info_gpu = run_gpu_update_y(prob, dev, max_iter=10, tol=1e-3)
+    for c in range(len(y_ref)):
+        e = rel_err(y_gpu[c].cpu(), y_ref[c])
+        worst = max(worst, e)
+        if e > 1e-4 or info_gpu[c][0] != info_ref[c][0]:
+            print('MISMATCH', kw, c, e, info_gpu[c][0], info_ref[c][0])
+print('fuzz done, worst relative error %.2e' % worst)
