@@ -169,6 +169,13 @@ struct UpTab {
 
 constexpr int kPushThreads = kWave;  // ONE wave per tile (see below)
 
+// phase-ablation switches: compiled in only with -DUNIRES_ABLATE (UNIRES_DBG selects the bits)
+#ifdef UNIRES_ABLATE
+#define ABL(bit) ((P.dbg & (bit)) != 0)
+#else
+#define ABL(bit) (false)
+#endif
+
 // compiler-only memory barrier for wave-synchronous LDS code (no instruction emitted)
 #define WAVE_FENCE() asm volatile("" ::: "memory")
 #define PROF_T(var) const unsigned long long var = P.prof ? __builtin_readcyclecounter() : 0ull
@@ -278,7 +285,7 @@ __global__ void __launch_bounds__(kPushThreads)
     PROF_T(t_setup);
     PROF_ADD(0, t_start, t_setup);
     const float c0 = P.A.m[2], c1 = P.A.m[6], c2 = P.A.m[10];  // step of g along grid z
-    const int nrow_cand = (P.dbg & 8) ? 0 : max(nbx, 0) * max(nby, 0);
+    const int nrow_cand = ABL(8) ? 0 : max(nbx, 0) * max(nby, 0);
     const int segs_per_row = (max(bz1 - bz0 + 1, 1) + 31) / 32;
     int nseg = 0;
     // candidate rows per pass: never more segments than the row list holds (long rows when the
@@ -338,7 +345,7 @@ __global__ void __launch_bounds__(kPushThreads)
       // ---- phase B: the two half-waves take segments p and p + npair, lanes along grid z.
       // Batches of kU segment pairs, software-pipelined: the global loads of batch b+1 are
       // issued before the LDS updates of batch b.
-      const int nr = (P.dbg & 1) ? 0 : min(nseg, Tile::kSegs);
+      const int nr = ABL(1) ? 0 : min(nseg, Tile::kSegs);
       const int npair = (nr + 1) / 2;
       constexpr int kU = 4;
       struct Batch {
@@ -400,7 +407,7 @@ __global__ void __launch_bounds__(kPushThreads)
           bool ok = B.act[u] && gx >= flx && gx < fhx && gy >= fly && gy < fhy && gz >= flz && gz < fhz;
           if (edge) ok = ok && in_fov(gx, gy, gz, dd, P.tol);
           const float v = P.alpha * (B.s0[u] * B.w0[u] + B.s1[u] * B.w1[u]);
-          ok = ok && v != 0.f && !(P.dbg & 2);
+          ok = ok && v != 0.f && !ABL(2);
           const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
           const int lx = (int)fx - (x0 - 1), ly = (int)fy - (y0 - 1), lz = (int)fz - (z0 - 1);
           const float wx1 = gx - fx, wy1 = gy - fy, wz1 = gz - fz;
@@ -500,7 +507,7 @@ __global__ void __launch_bounds__(kPushThreads)
       const size_t idx = ((size_t)i * dd.y + j) * dd.z + k;
       float q = acc[((lx + 1) * Tile::SY + ly + 1) * Tile::SZ + lz + 1];
       float pc = 0.f;
-      if (pin && !(P.dbg & 4)) {  // dbg 4: no stencil
+      if (pin && !ABL(4)) {  // dbg 4: no stencil
         const float st = dtd_at(pin, idx, i, j, k, dd, P.cx, P.cy, P.cz, pc);
         q += P.a0 * pc + st;
       }

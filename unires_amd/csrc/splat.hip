@@ -94,6 +94,14 @@ __device__ __forceinline__ float dpp_up1f(float v) {
 #define SPLAT_FENCE() asm volatile("" ::: "memory")
 #endif
 
+// phase-ablation switches (tools/abl.sh): compiled in only with -DUNIRES_ABLATE, then driven by
+// the UNIRES_DBG environment variable; product builds carry none of it
+#ifdef UNIRES_ABLATE
+#define ABL(bit) ((P.dbg & (bit)) != 0)
+#else
+#define ABL(bit) (false)
+#endif
+
 #ifdef UNIRES_SPLAT_PROF  // per-phase timer sums (debug builds only)
 #define SP_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define SP_ADD(slot, t0, t1) \
@@ -233,7 +241,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
     const int chunk = max(1, min(kWave, kSegs / segs_per_row));
     int nseg = 0;
     for (int rc0 = 0;;) {
-      if (P.dbg & 16) break;
+      if (ABL(16)) break;
       SP_T(t_a0);
       if (rc0 < nrow_cand) {
         const int rc = rc0 + lane;
@@ -293,7 +301,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
       SP_ADD(1, t_a0, t_a1);
       // ---- phase B: one lane group per segment, lanes along grid z, kU instructions per batch ----
       constexpr int kU = 4;
-      for (int p0 = 0; p0 < ((P.dbg & 8) ? 0 : npair); p0 += kU) {
+      for (int p0 = 0; p0 < (ABL(8) ? 0 : npair); p0 += kU) {
         SP_T(t_b0);
         float val[kU];
         int ui[kU], uj[kU], uk[kU];
@@ -348,7 +356,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
         }
         SP_T(t_b1);
         SP_ADD(2, t_b0, t_b1);
-        if (P.dbg & 4) continue;
+        if (ABL(4)) continue;
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           float gx, gy, gz;
@@ -372,7 +380,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
           const int prev_lz = dpp_up1(lzk);  // executed by ALL lanes: a DPP read of a lane that
                                              // is masked off returns the reader's own value
           const bool dup = ok && gl > 0 && lzk == prev_lz;
-          const bool slow = __any(dup) || __any(ok && solo[u]) || (P.dbg & 1);
+          const bool slow = __any(dup) || __any(ok && solo[u]) || ABL(1);
           if (!slow) {
             // common case, straight line: z-adjacent lanes hand their shared plane over in
             // registers, then every lane updates ONE z plane (+ the top plane of lanes
@@ -434,7 +442,7 @@ __global__ void __launch_bounds__(kWave) k_splat(SplatArgs P, const int *__restr
     // tile, and every load/store is "scalar base + lane offset" - no per-row index arithmetic.
     // (A wave64 VALU instruction occupies the SIMD for 4 clocks; the generic form below spends
     // ~125 of them per pair of rows, this one ~25.)
-    if (P.dbg & 2) continue;
+    if (ABL(2)) continue;
     constexpr int RPX = TY / G;  // instructions per x slab of the tile
     static_assert((TX * RPX) % 4 == 0, "fast epilogue unrolls four instructions");
     const bool fast_xy = pin != nullptr && !P.accumulate && x0 > 0 && y0 > 0 &&
