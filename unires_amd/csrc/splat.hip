@@ -56,6 +56,12 @@ struct SplatArgs {
 //         8 x 8 x 30, L = 32 : 219 / 281 / 267 us   (fewer segments, but 12 instead of 16 waves/CU)
 //         6 x 4 x 30, L = 32 : 204 / 287 / 274 us   (20 instead of 16 waves/CU, but 34 % more tiles)
 //   earlier sweeps of the long form: 6x6 230, 4x8 249, 4x4 329 (vs 8x4 218)
+// Also tried and dropped: SHEARED tiles (layer z of a tile shifted by round(z c0/c2), round(z c1/c2)
+// voxels so that a tilted z line stays inside one tile column).  It works (all parity and
+// reproducibility tests pass) and does what it should to the splat proper - 30 full segments per
+// tile instead of 41 half-empty ones, splat phase 153 -> 121 us on the 0.1 rad channel - but the
+// stencil epilogue then writes rows that change (x, y) every ~10 z: its time doubles (41 -> 91 us)
+// and the kernel ends up slower (203 / 246 / 251 us vs 162 / 227 / 201 us).
 // Also tried and dropped: packing the short segments of a tilted grid (half of them are <= 16
 // lanes) four to an instruction - 183 / 235 / 221 us with a second code instantiation, 187 / 254 /
 // 235 us with a run-time group width: short segments come from rows next to the same tile face,
