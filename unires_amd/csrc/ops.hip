@@ -18,11 +18,14 @@ static inline dim3 vol_grid(const Dim3i &d) {
 // pull: dst[g] = mask(g) * sum_8 w_c * src[corner_c(M g)]
 // (nitorch grid_pull linear / zero / extrapolate=False)
 // --------------------------------------------------------------------------
-constexpr int kPullChunks = 4;  // z chunks of 64 per thread: 16 eight-byte loads in flight
+constexpr int kPullChunksMax = 4;  // z chunks of 64 per thread: up to 16 eight-byte loads in flight
 
 // block = 4 waves = 4 consecutive grid rows j (same i); each lane takes kPullChunks grid-z
 // positions 64 apart.  Blocks whose whole footprint is inside the volume (all but a thin
 // shell) take the interior path.
+// kPullChunks = chunks per thread, chosen so that the last one is not mostly idle lanes
+// (a 181-long row takes 3 chunks, not 4)
+template <int kPullChunks>
 __global__ void __launch_bounds__(kBlock) k_pull(const float *__restrict__ src, Dim3i sd, Affine A,
                                                  float *__restrict__ dst, Dim3i gd, float tol,
                                                  const int *__restrict__ done) {
@@ -189,9 +192,22 @@ __global__ void __launch_bounds__(kBlock)
 // --------------------------------------------------------------------------
 void launch_pull(const float *src, Dim3i sd, const Affine &A, float *dst, Dim3i gd, float tol,
                  const int *done, hipStream_t st) {
-  const int zspan = kWave * kPullChunks;
+  // fewest idle lanes: chunks per thread = the count (<= 4) that wastes least of the row's tail
+  int best = kPullChunksMax, waste = 1 << 30;
+  for (int c = kPullChunksMax; c >= 1; --c) {
+    const int span = kWave * c, w = (gd.z + span - 1) / span * span - gd.z;
+    if (w < waste) waste = w, best = c;
+  }
+  const int zspan = kWave * best;
   const dim3 grid((gd.z + zspan - 1) / zspan, (gd.y + 3) / 4, gd.x);
-  hipLaunchKernelGGL(k_pull, grid, vol_block(), 0, st, src, sd, A, dst, gd, tol, done);
+  if (best == 4)
+    hipLaunchKernelGGL(k_pull<4>, grid, vol_block(), 0, st, src, sd, A, dst, gd, tol, done);
+  else if (best == 3)
+    hipLaunchKernelGGL(k_pull<3>, grid, vol_block(), 0, st, src, sd, A, dst, gd, tol, done);
+  else if (best == 2)
+    hipLaunchKernelGGL(k_pull<2>, grid, vol_block(), 0, st, src, sd, A, dst, gd, tol, done);
+  else
+    hipLaunchKernelGGL(k_pull<1>, grid, vol_block(), 0, st, src, sd, A, dst, gd, tol, done);
 }
 
 // --------------------------------------------------------------------------
