@@ -5,12 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import unires_amd as U
 dev = torch.device('cuda:0')
-x, y, z, w, rho, sett = bench.build_subject(bench.WORKLOADS['cfg3_256c3_thick6z'], dev, seed=1234)
+x, y, z, w, rho, sett = bench.build_subject(bench.WORKLOADS[os.environ.get('WL', 'cfg3_256c3_thick6z')], dev, seed=1234)
 y = U._init_y_dat(x, y, sett)  # trilinear reslice of the observations, as the reference starts
 for yc in y:
     yc.lam0 = float(yc.lam) / 4.0
 sett.cgs_tol, sett.cache_atx = 1e-3, True
-sett.max_iter, sett.tolerance = 4, 1e-4
+sett.max_iter, sett.tolerance = int(os.environ.get('ITERS', '4')), 1e-4
 sett.scaling, sett.unified_rigid, sett.rigid_samp = True, True, 1
 def timed(f, *a, **k):
     torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(*a, **k); torch.cuda.synchronize()
