@@ -147,6 +147,20 @@ def _channel_plan(x, y, method, do, vx_y=None):
     cached = getattr(y, '_plan', None)
     if cached is not None and cached[0] == sig:
         return cached[1]
+    if cached is not None and len(cached[0]) == len(sig) and cached[0][:3] == sig[:3]:
+        # same volume and method, some repeat's operator changed (rigid / scaling update):
+        # swap the descriptors in place, keeping the plan's device workspace
+        plan = cached[1]
+        try:
+            for n, (old, new) in enumerate(zip(cached[0][3:], sig[3:])):
+                if old != new:
+                    plan.set_repeat(n, x[n].po, x[n].tau)
+            plan.dims_x = [tuple(xn.po.dim_x) for xn in x] if do else plan.dims_x
+            plan._atx = None  # cached sum tau At x belongs to the old operator
+            y._plan = (sig, plan)
+            return plan
+        except ValueError:
+            pass  # the new repeat does not fit the workspace: build a new plan
     if cached is not None:
         cached[1].close()
     if vx_y is None:

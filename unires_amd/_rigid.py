@@ -16,6 +16,7 @@ rotation generators about x, y, z.
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib, _ops
@@ -40,17 +41,43 @@ def affine_basis(group='SE', device='cpu', dtype=_F64):
     return B
 
 
+def _expm_small(M):
+    """Matrix exponential of a small float64 matrix: scaling and squaring with a degree-16 Taylor
+    polynomial (norm scaled below 1/4: truncation error < 1e-20)."""
+    import numpy as np
+    nrm = np.abs(M).sum(1).max()
+    sq = max(0, int(np.ceil(np.log2(max(nrm, 1e-300) * 4.0))))
+    A = M / (2.0 ** sq)
+    E = np.eye(M.shape[0])
+    T = np.eye(M.shape[0])
+    for k in range(1, 17):
+        T = T @ A / k
+        E = E + T
+    for _ in range(sq):
+        E = E @ E
+    return E
+
+
 def _expm(q, basis, grad_X=False):
     """rigid = expm(sum_i q_i basis_i) [, d rigid / d q_i as (num_q, 4, 4)]  (float64, host)."""
-    q = torch.as_tensor(q, dtype=_F64).cpu()
-    basis = basis.to('cpu', _F64)
-    f = lambda v: torch.linalg.matrix_exp(torch.einsum('i,ijk->jk', v, basis))
-    rigid = f(q)
+    import numpy as np
+    expm = _expm_small  # tiny matrices: plain numpy beats torch's threaded CPU ops (and scipy) here
+    qn = np.asarray(torch.as_tensor(q, dtype=_F64).cpu())
+    Bn = np.asarray(basis.to('cpu', _F64))
+    X = np.einsum('i,ijk->jk', qn, Bn)
     if not grad_X:
-        return rigid
-    with torch.enable_grad():
-        J = torch.autograd.functional.jacobian(f, q)  # (4, 4, num_q)
-    return rigid, J.permute(2, 0, 1).contiguous()
+        return torch.from_numpy(expm(X))
+    # Frechet derivative by the block trick: expm([[X, B_i], [0, X]]) = [[e^X, dexp_X(B_i)], [0, e^X]]
+    dR = np.empty((Bn.shape[0], 4, 4))
+    R = None
+    for i in range(Bn.shape[0]):
+        M = np.zeros((8, 8))
+        M[:4, :4] = X
+        M[4:, 4:] = X
+        M[:4, 4:] = Bn[i]
+        E = expm(M)
+        R, dR[i] = E[:4, :4], E[:4, 4:]
+    return torch.from_numpy(R.copy()), torch.from_numpy(dR)
 
 
 def _logq(rigid, basis):
@@ -122,7 +149,7 @@ def _update_rigid_channel(xc, yc, sett, max_niter_gn=1, num_linesearch=4, verbos
     num_q = basis.shape[0]
     sll = torch.zeros((), dtype=_F64, device=dev)
     sums = torch.empty(27, dtype=_F64, device=dev)
-    iu = torch.triu_indices(num_q, num_q)
+    iu = np.triu_indices(num_q)
     for n_x in range(len(xc)):
         xn = xc[n_x]
         if xn.rigid_q is None:
@@ -147,12 +174,11 @@ def _update_rigid_channel(xc, yc, sett, max_niter_gn=1, num_linesearch=4, verbos
             d72 = (C.c_float * 72)(*D[:, :3, :].reshape(-1).float().tolist())
             check(lib.unires_rigid_sums(_ptr(gr3), _ptr(dg), _ptr(CtC) if CtC is not None else None,
                                         i3(dim), d72, _ptr(sums), _stream()))
-            s = sums.cpu()
-            gr = s[:num_q].reshape(num_q, 1)
-            Hes = torch.zeros(num_q, num_q, dtype=_F64)
-            Hes[iu[0], iu[1]] = s[num_q:]
-            Hes = Hes + Hes.triu(1).T
-            Update = torch.linalg.solve(Hes, gr)[:, 0]
+            s = sums.cpu().numpy()  # (6x6 host algebra in numpy: torch's CPU ops cost ~10 ms each here)
+            Hes = np.zeros((num_q, num_q))
+            Hes[iu] = s[num_q:]
+            Hes = Hes + np.triu(Hes, 1).T
+            Update = torch.from_numpy(np.linalg.solve(Hes, s[:num_q]))
             old_ll, old_q, old_rigid = ll.clone(), q.clone(), rigid.clone()
             if num_linesearch == 0:
                 q = old_q - armijo * Update

@@ -475,6 +475,7 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
     (void)hipGraphExecDestroy(plan->cg_exec);
     plan->cg_exec = nullptr;
   }
+  plan->prec_ready = false;  // a preconditioner built for the old operator is stale
   if (tmp.dim_gf.z != plan->reps[n].dim_gf.z) free_ztabs(plan->reps[n]);
   tmp.ztab_dev[0] = plan->reps[n].ztab_dev[0];
   tmp.ztab_dev[1] = plan->reps[n].ztab_dev[1];
