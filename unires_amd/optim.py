@@ -1,15 +1,20 @@
 """nitorch.core.optim-shaped entry points used by UniRes
 (cg: unires/_update.py:9,142-148; get_gain: unires/run.py:7,100)."""
+import math
+
 import torch
 
 
 def get_gain(obj, monotonicity='increasing'):
     """Normalised gain of the last objective value (host-side scalar logic)."""
-    obj = torch.as_tensor(obj, dtype=torch.float64)
-    if len(obj) <= 1:
+    vals = obj.tolist() if isinstance(obj, torch.Tensor) else [float(v) for v in obj]
+    if len(vals) <= 1:
         return torch.tensor(float('inf'), dtype=torch.float64)
-    gain = obj[-1] - obj[-2] if monotonicity == 'increasing' else obj[-2] - obj[-1]
-    return gain / (torch.max(obj) - torch.min(obj))
+    gain = vals[-1] - vals[-2] if monotonicity == 'increasing' else vals[-2] - vals[-1]
+    span = max(vals) - min(vals)
+    # plain float arithmetic (IEEE: x/0 -> inf, 0/0 -> nan, as the tensor version would give)
+    out = gain / span if span != 0.0 else (float('nan') if gain == 0.0 else math.copysign(float('inf'), gain))
+    return torch.tensor(out, dtype=torch.float64)
 
 
 def cg(A, b, x=None, precond=None, max_iter=None, tolerance=1e-5, verbose=False,
