@@ -609,7 +609,8 @@ extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, con
         launch_pull(in, plan->dy, R.Af, plan->gbuf, R.dim_gf, plan->fov_tol, nullptr, st);
         launch_conv_down_sep(plan->gbuf, R.dim_gf, R.Tf, make_scaling(R.scl, R.dim_thick), out,
                              R.dim_x, plan->gbuf, plan->gbuf2, nullptr, st);
-      } else {
+      } else if (launch_pull_conv(in, plan->dy, R.Af, R.Tf, make_scaling(R.scl, R.dim_thick), out,
+                                  R.dim_x, R.dim_gf, plan->fov_tol, nullptr, st)) {
         launch_pull(in, plan->dy, R.A, plan->gbuf, R.dim_g, plan->fov_tol, nullptr, st);
         launch_conv_down(plan->gbuf, R.dim_g, R.T, make_scaling(R.scl, R.dim_thick), out, R.dim_x,
                          nullptr, st);
