@@ -118,3 +118,38 @@ def test_step_size_matches_oracle(lib):
     oy = [O.make_output(torch.zeros(1, 1, 1), None, yc.lam) for yc in y]
     b = O.step_size(ox, oy)
     assert abs(float(a) - float(b)) < 1e-6 * float(b)
+
+
+def test_rigid_host_algebra():
+    """se(3) helpers of the rigid Gauss-Newton (host only): expm against scipy, its derivative
+    against central differences, the logarithm round trip, basis shape."""
+    import numpy as np
+    from scipy.linalg import expm
+    from unires_amd._rigid import _expm, _expm_small, _logq, affine_basis
+    B = affine_basis('SE')
+    assert B.shape == (6, 4, 4) and torch.all(B[:, 3, :] == 0)
+    q = torch.tensor([3.0, -12.0, 0.5, 0.3, -0.25, 0.4], dtype=torch.float64)
+    X = np.einsum('i,ijk->jk', q.numpy(), B.numpy())
+    R, dR = _expm(q, B, grad_X=True)
+    assert np.abs(expm(X) - R.numpy()).max() < 1e-12
+    assert np.abs(_expm_small(np.zeros((4, 4))) - np.eye(4)).max() == 0
+    assert torch.allclose(R[:3, :3] @ R[:3, :3].T, torch.eye(3, dtype=torch.float64), atol=1e-12)
+    h = 1e-6
+    for i in range(6):
+        e = torch.zeros(6, dtype=torch.float64)
+        e[i] = h
+        fd = (_expm(q + e, B) - _expm(q - e, B)) / (2 * h)
+        assert (fd - dR[i]).abs().max() < 1e-6
+    assert torch.allclose(_logq(R, B), q, atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        affine_basis('Aff+')
+
+
+def test_fit_schedule_and_gain():
+    import unires_amd as U
+    s = U.settings()
+    assert U._get_sched(3, s).reg_scl.tolist() == [32.0, 16.0, 8.0, 4.0]
+    assert U._get_sched(1, U.settings()).reg_scl.tolist() == [4.0]
+    from unires_amd.optim import get_gain
+    assert abs(float(get_gain([5.481, 4.983, 4.706], 'decreasing')) - 0.3574) < 1e-3  # demo trace
+    assert float(get_gain([1.0])) == float('inf')
