@@ -18,6 +18,7 @@
 #include "fftpre.hpp"
 #include "fused.hpp"
 #include "ops.hpp"
+#include "splat2.hpp"
 
 using namespace unires;
 
@@ -264,6 +265,13 @@ struct Repeat {
   bool sep = false;  // many-tap profile: convolutions run as separable 1-D passes
   // device tables for the on-the-fly conv_up of k_gather2: [0] no scaling (AtA), [1] S(scl) (At)
   float *ztab_dev[2] = {nullptr, nullptr};
+  // schedule-driven splat (splat2.hip): per-tile segment lists of this operator + conv_up tables
+  // along the schedule's axis ([0] no scaling, [1] S(scl)); ctab_n entries, second x-space value
+  // ctab_step elements after the first
+  SplatSched sched;
+  float *ctab_dev[2] = {nullptr, nullptr};
+  int ctab_n = 0, ctab_cap = 0;
+  unsigned ctab_step = 1;
 };
 
 struct unires_plan {
@@ -307,6 +315,8 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
   if (!in) return fail(UNIRES_ERR_NULL, "null repeat descriptor");
   if (!(in->tau > 0.f)) return fail(UNIRES_ERR_ARG, "tau must be positive");
   memset(&out, 0, sizeof(out));
+  out.sched = SplatSched();
+  out.ctab_step = 1;
   out.tau = in->tau;
   out.scl = in->scl;
   out.dim_thick = in->dim_thick;
@@ -366,6 +376,63 @@ static int upload_ztabs(unires_plan *pl, Repeat &R) {
 static void free_ztabs(Repeat &R) {
   for (int v = 0; v < 2; ++v)
     if (R.ztab_dev[v]) (void)hipFree(R.ztab_dev[v]), R.ztab_dev[v] = nullptr;
+}
+
+// (re)build the splat schedule of a repeat for its current operator; a non-applicable operator
+// simply leaves the schedule invalid (the general push kernels then run)
+static int build_sched(unires_plan *pl, Repeat &R) {
+  R.sched.valid = false;
+  if (pl->regime == UNIRES_REGIME_IDENTITY) return UNIRES_OK;
+  int axis = -1;
+  unsigned sx = (unsigned)R.dim_gf.y * (unsigned)R.dim_gf.z, sy = (unsigned)R.dim_gf.z;
+  const bool direct = pl->regime == UNIRES_REGIME_DENOISE || R.sep;
+  if (!direct) {
+    int nconv = 0;
+    for (int d = 0; d < 3; ++d) {
+      const bool dirac = R.Tf.n[d] == 1 && R.Tf.s[d] == 1 && R.Tf.t[d][0] == 1.f;
+      if (dirac) continue;
+      ++nconv;
+      axis = d;
+    }
+    if (nconv > 1) return UNIRES_OK;  // conv_up along several axes: k_splat<3> / general kernels
+    if (axis < 0) axis = 2;           // all dirac: conv_up is the identity, any axis works
+    const int xdv[3] = {R.dim_x.x, R.dim_x.y, R.dim_x.z}, gdv[3] = {R.dim_gf.x, R.dim_gf.y, R.dim_gf.z};
+    if ((R.Tf.n[axis] + R.Tf.s[axis] - 1) / R.Tf.s[axis] > 2 || xdv[axis] < 2) return UNIRES_OK;
+    if (R.scl != 0.f && R.dim_thick != axis) return UNIRES_OK;
+    if (R.dim_x.numel() >= (1ull << 30)) return UNIRES_OK;
+    const unsigned xyz = (unsigned)R.dim_x.y * (unsigned)R.dim_x.z, xz = (unsigned)R.dim_x.z;
+    if (axis == 2) sx = xyz, sy = xz, R.ctab_step = 1;
+    if (axis == 1) sx = xyz, sy = 0, R.ctab_step = xz;
+    if (axis == 0) sx = 0, sy = xz, R.ctab_step = xyz;
+    const int gn = gdv[axis];
+    if (gn + 32 > 4000) return UNIRES_OK;
+    std::vector<float> host((size_t)gn * 4);
+    for (int v = 0; v < 2; ++v) {
+      if (!R.ctab_dev[v] || R.ctab_cap < gn) {
+        if (R.ctab_dev[v]) (void)hipFree(R.ctab_dev[v]);
+        R.ctab_dev[v] = nullptr;
+        if (hipMalloc((void **)&R.ctab_dev[v], host.size() * sizeof(float)) != hipSuccess)
+          return fail(UNIRES_ERR_ALLOC, "hipMalloc conv table");
+      }
+      splat2_convtab(R.Tf, v ? make_scaling(R.scl, R.dim_thick) : Scaling{1.f, 1.f, -1}, axis, gn,
+                     xdv[axis], host.data());
+      if (hipMemcpy(R.ctab_dev[v], host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) !=
+          hipSuccess)
+        return fail(UNIRES_ERR_HIP, "hipMemcpy conv table");
+    }
+    R.ctab_n = gn;
+    R.ctab_cap = std::max(R.ctab_cap, gn);
+  }
+  (void)splat2_build(R.sched, R.Af, R.Afinv, R.dim_gf, pl->dy, pl->fov_tol, R.safe, axis, sx, sy);
+  (void)hipGetLastError();
+  return UNIRES_OK;
+}
+
+static void free_sched(Repeat &R) {
+  splat2_free(R.sched);
+  for (int v = 0; v < 2; ++v)
+    if (R.ctab_dev[v]) (void)hipFree(R.ctab_dev[v]), R.ctab_dev[v] = nullptr;
+  R.ctab_n = R.ctab_cap = 0;
 }
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -437,8 +504,9 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
   }
   for (Repeat &R : pl->reps) {
     int rc = upload_ztabs(pl, R);
+    if (!rc) rc = build_sched(pl, R);
     if (rc) {
-      for (Repeat &Q : pl->reps) free_ztabs(Q);
+      for (Repeat &Q : pl->reps) free_ztabs(Q), free_sched(Q);
       (void)hipFree(pl->ws);
       delete pl;
       return rc;
@@ -454,7 +522,7 @@ extern "C" int unires_plan_destroy(unires_plan_t *plan) {
   if (plan->precM) (void)hipFree(plan->precM);
   if (plan->cg_exec) (void)hipGraphExecDestroy(plan->cg_exec);
   fftpre_destroy(plan->fft);
-  for (Repeat &R : plan->reps) free_ztabs(R);
+  for (Repeat &R : plan->reps) free_ztabs(R), free_sched(R);
   delete plan;
   return UNIRES_OK;
 }
@@ -479,8 +547,15 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   if (tmp.dim_gf.z != plan->reps[n].dim_gf.z) free_ztabs(plan->reps[n]);
   tmp.ztab_dev[0] = plan->reps[n].ztab_dev[0];
   tmp.ztab_dev[1] = plan->reps[n].ztab_dev[1];
+  // the schedule and conv tables keep their device allocations; contents are rebuilt below
+  tmp.sched = plan->reps[n].sched;
+  tmp.ctab_dev[0] = plan->reps[n].ctab_dev[0];
+  tmp.ctab_dev[1] = plan->reps[n].ctab_dev[1];
+  tmp.ctab_cap = plan->reps[n].ctab_cap;
   plan->reps[n] = tmp;
-  return upload_ztabs(plan, plan->reps[n]);
+  rc = upload_ztabs(plan, plan->reps[n]);
+  if (!rc) rc = build_sched(plan, plan->reps[n]);
+  return rc;
 }
 
 extern "C" int64_t unires_plan_workspace_bytes(const unires_plan_t *plan) {
@@ -551,6 +626,13 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
     if (!launch_gather2(src, zt, A, R.Afinv, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
       return ep.partials ? gather2_blocks(pl->dy) : 0;
   }
+  if (!use_tile && mode == nullptr && R.sched.valid && (src.convup != 0) == (R.sched.axis >= 0)) {
+    const float4 *tab = src.convup ? (const float4 *)R.ctab_dev[src.S.dim >= 0 ? 1 : 0] : nullptr;
+    const size_t numel = src.convup ? src.xd.numel() : src.gd.numel();
+    if (!launch_splat2(R.sched, src.data, numel, tab, R.ctab_n, R.ctab_step, A, alpha, pl->fov_tol, ep,
+                       out, pl->dy, done, st))
+      return ep.partials ? splat2_blocks(pl->dy) : 0;
+  }
   if (!use_tile &&
       !launch_splat(src, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
     return ep.partials ? splat_blocks(pl->dy, A) : 0;
@@ -559,6 +641,10 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
     PushSrc d = src;
     d.data = launch_conv_up_sep(src.data, src.xd, src.T, src.S, src.gd, pl->gbuf, pl->gbuf2, st);
     d.convup = 0;
+    if (mode == nullptr && R.sched.valid && R.sched.axis < 0 &&
+        !launch_splat2(R.sched, d.data, d.gd.numel(), nullptr, 0, 1, A, alpha, pl->fov_tol, ep, out,
+                       pl->dy, done, st))
+      return ep.partials ? splat2_blocks(pl->dy) : 0;
     if (!launch_splat(d, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
       return ep.partials ? splat_blocks(pl->dy, A) : 0;
     (void)launch_push_tile(d, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st);
