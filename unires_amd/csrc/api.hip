@@ -271,7 +271,7 @@ struct Repeat {
   SplatSched sched;
   float *ctab_dev[2] = {nullptr, nullptr};
   int ctab_n = 0, ctab_cap = 0;
-  unsigned ctab_step = 1;
+  unsigned ctab_step = 1, src_stride = 1;
 };
 
 struct unires_plan {
@@ -384,7 +384,9 @@ static int build_sched(unires_plan *pl, Repeat &R) {
   R.sched.valid = false;
   if (pl->regime == UNIRES_REGIME_IDENTITY) return UNIRES_OK;
   int axis = -1;
-  unsigned sx = (unsigned)R.dim_gf.y * (unsigned)R.dim_gf.z, sy = (unsigned)R.dim_gf.z;
+  int rows_y = R.dim_gf.y;
+  R.src_stride = (unsigned)R.dim_gf.z;
+  R.ctab_step = 1;
   const bool direct = pl->regime == UNIRES_REGIME_DENOISE || R.sep;
   if (!direct) {
     int nconv = 0;
@@ -401,11 +403,11 @@ static int build_sched(unires_plan *pl, Repeat &R) {
     if (R.scl != 0.f && R.dim_thick != axis) return UNIRES_OK;
     if (R.dim_x.numel() >= (1ull << 30)) return UNIRES_OK;
     const unsigned xyz = (unsigned)R.dim_x.y * (unsigned)R.dim_x.z, xz = (unsigned)R.dim_x.z;
-    if (axis == 2) sx = xyz, sy = xz, R.ctab_step = 1;
-    if (axis == 1) sx = xyz, sy = 0, R.ctab_step = xz;
-    if (axis == 0) sx = 0, sy = xz, R.ctab_step = xyz;
+    if (axis == 2) rows_y = R.dim_x.y, R.src_stride = xz, R.ctab_step = 1;
+    if (axis == 1) R.src_stride = xyz, R.ctab_step = xz;  // source offset ui * xyz + koff(uj) * xz + k
+    if (axis == 0) R.src_stride = xz, R.ctab_step = xyz;  // source offset uj * xz + koff(ui) * xyz + k
     const int gn = gdv[axis];
-    if (gn + 32 > 4000) return UNIRES_OK;
+    if (gn + 64 > 1400) return UNIRES_OK;  // LDS copy of the table
     std::vector<float> host((size_t)gn * 4);
     for (int v = 0; v < 2; ++v) {
       if (!R.ctab_dev[v] || R.ctab_cap < gn) {
@@ -423,7 +425,7 @@ static int build_sched(unires_plan *pl, Repeat &R) {
     R.ctab_n = gn;
     R.ctab_cap = std::max(R.ctab_cap, gn);
   }
-  (void)splat2_build(R.sched, R.Af, R.Afinv, R.dim_gf, pl->dy, pl->fov_tol, R.safe, axis, sx, sy);
+  (void)splat2_build(R.sched, R.Af, R.Afinv, R.dim_gf, pl->dy, pl->fov_tol, R.safe, axis, rows_y);
   (void)hipGetLastError();
   return UNIRES_OK;
 }
@@ -629,7 +631,7 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
   if (!use_tile && mode == nullptr && R.sched.valid && (src.convup != 0) == (R.sched.axis >= 0)) {
     const float4 *tab = src.convup ? (const float4 *)R.ctab_dev[src.S.dim >= 0 ? 1 : 0] : nullptr;
     const size_t numel = src.convup ? src.xd.numel() : src.gd.numel();
-    if (!launch_splat2(R.sched, src.data, numel, tab, R.ctab_n, R.ctab_step, A, alpha, pl->fov_tol, ep,
+    if (!launch_splat2(R.sched, src.data, numel, tab, R.ctab_n, R.src_stride, R.ctab_step, A, alpha, ep,
                        out, pl->dy, done, st))
       return ep.partials ? splat2_blocks(pl->dy) : 0;
   }
@@ -642,7 +644,7 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
     d.data = launch_conv_up_sep(src.data, src.xd, src.T, src.S, src.gd, pl->gbuf, pl->gbuf2, st);
     d.convup = 0;
     if (mode == nullptr && R.sched.valid && R.sched.axis < 0 &&
-        !launch_splat2(R.sched, d.data, d.gd.numel(), nullptr, 0, 1, A, alpha, pl->fov_tol, ep, out,
+        !launch_splat2(R.sched, d.data, d.gd.numel(), nullptr, 0, R.src_stride, 1, A, alpha, ep, out,
                        pl->dy, done, st))
       return ep.partials ? splat2_blocks(pl->dy) : 0;
     if (!launch_splat(d, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st))

@@ -6,9 +6,16 @@
 //   * the lanes of a segment sit in DIFFERENT z planes (the build kernel cuts a row wherever two
 //     consecutive points share floor(gz)), and a group touches one plane per lane: the lower
 //     plane of every point first, the upper plane second;
-//   * the two segments of an instruction come from rows >= row_sep apart (host-checked for the
-//     affine: some coordinate of any two of their points differs by >= 2).
+//   * the segments packed into one instruction either come from rows >= row_sep apart
+//     (host-checked for the affine: some coordinate of any two of their points differs by >= 2)
+//     or occupy z-plane ranges that do not touch.
 // The schedule is fixed, so results are bit-reproducible.
+//
+// What the hardware charges (tools/mb_valu.hip, tools/mb_lds.hip, MI355X): a wave64 add / mul
+// issues in 2 clocks, FMA / convert / shift / compare in 4; an 8-cell read-add-write costs the CU's
+// LDS ~43 clocks; every VMEM wave-instruction costs the texture addresser ~16 clocks however
+// well it coalesces.  Hence: segment descriptors go through an LDS ring (one coalesced global load
+// per 32 segments), not per-lane global loads; ONE 8-byte source load per lane and instruction.
 #include "splat2.hpp"
 
 #include <math.h>
@@ -26,9 +33,17 @@ struct S2Tile {
   static constexpr int SX = TX + 2, SY = TY + 2, SZ = TZ + 2, N = SX * SY * SZ;
   static constexpr int XS = SY * SZ, YS = SZ;
 };
-constexpr int kS2Waves = 4;  // waves (= independent tiles in flight) per workgroup
+constexpr int kS2Waves = 4;   // waves (= independent tiles in flight) per workgroup
+constexpr int kS2MaxSeg = 8;  // segments per instruction
 
 #define S2_FENCE() asm volatile("" ::: "memory")
+// phase-ablation switches: compiled in only with -DUNIRES_ABLATE (then UNIRES_S2_DBG selects bits:
+// 1 no splat, 2 no epilogue, 4 no LDS updates, 8 no source loads); product builds carry none of it
+#ifdef UNIRES_ABLATE
+#define S2_ABL(bit) ((P.dbg & (bit)) != 0)
+#else
+#define S2_ABL(bit) (false)
+#endif
 
 // coordinate of grid point k of a row with base (rx, ry, rz): identical, bit for bit, to
 // affine_along() / affine_point() (the pull kernels), so that At is the exact adjoint of A
@@ -64,24 +79,30 @@ struct S2BuildArgs {
   Dim3i gd, dd;
   float tol;
   int row_sep;
-  unsigned sx, sy;
-  int tabsel;
+  int axis, rows_y;
 };
 
 struct S2Seg {
-  short ui, uj, k0, len;
+  short ui, uj, k0;
+  unsigned char len, lzmin, lzmax, pad;  // local z planes touched: [lzmin, lzmax + 1]
 };
 
-// One wave per tile.  FILL = false: counts[t] = number of entries; FILL = true: counts holds the
-// exclusive prefix sum and the entries are written.  stats[0] += points, stats[1] += instructions.
+__device__ __forceinline__ unsigned s2_rowcode(const S2BuildArgs &B, int ui, int uj) {
+  return (B.axis == 0 || B.axis == 1) ? ((unsigned)ui << 9) | (unsigned)uj
+                                      : (unsigned)ui * (unsigned)B.rows_y + (unsigned)uj;
+}
+
+// One wave per tile.  FILL = false: counts[t] = {entries, instructions}; FILL = true: counts holds
+// the exclusive prefix sums and the entries / masks are written.
 template <bool FILL>
 __global__ void __launch_bounds__(kWave)
-    k_splat2_build(S2BuildArgs B, unsigned *__restrict__ counts, S2Entry *__restrict__ entries,
-                   int *__restrict__ err, unsigned long long *__restrict__ stats) {
+    k_splat2_build(S2BuildArgs B, uint2 *__restrict__ counts, S2Entry *__restrict__ entries,
+                   unsigned long long *__restrict__ masks, int *__restrict__ err,
+                   unsigned long long *__restrict__ stats) {
   using T = S2Tile;
   constexpr int L = T::L, kSegs = 384;
   __shared__ S2Seg segs[kSegs];
-  __shared__ unsigned char flag[kSegs];
+  __shared__ unsigned short member[kWave][kS2MaxSeg];
   const int lane = threadIdx.x;
   const Dim3i dd = B.dd;
   const int t = blockIdx.x;
@@ -151,10 +172,12 @@ __global__ void __launch_bounds__(kWave)
     bool more = k1 >= k0;
     while (__any(more)) {
       int e = cur;
+      float za = 0.f, zb = 0.f;
       if (more) {
         float gx, gy, gz;
         s2_point(B.A, rb.x, rb.y, rb.z, (float)cur, gx, gy, gz);
         float plz = floorf(gz);
+        za = plz;
         while (e + 1 <= k1 && e + 1 - cur < L) {
           s2_point(B.A, rb.x, rb.y, rb.z, (float)(e + 1), gx, gy, gz);
           const float lz = floorf(gz);
@@ -162,10 +185,15 @@ __global__ void __launch_bounds__(kWave)
           plz = lz;
           ++e;
         }
+        zb = plz;
       }
       const unsigned long long m = __ballot(more);
       const int pos = nseg + __popcll(m & lt_mask);
-      if (more && pos < kSegs) segs[pos] = S2Seg{(short)ui, (short)uj, (short)cur, (short)(e - cur + 1)};
+      if (more && pos < kSegs) {
+        const int la = (int)za - (g.z0 - 1), lb = (int)zb - (g.z0 - 1);
+        segs[pos] = S2Seg{(short)ui, (short)uj, (short)cur, (unsigned char)(e - cur + 1),
+                          (unsigned char)min(la, lb), (unsigned char)max(la, lb), 0};
+      }
       nseg += __popcll(m);
       cur = e + 1;
       more = more && cur <= k1;
@@ -177,94 +205,104 @@ __global__ void __launch_bounds__(kWave)
   }
   S2_FENCE();
   __syncthreads();
-  // pairing: segment p with segment p + half (rows about half a tile apart); a pair whose rows
-  // are closer than row_sep is split into two single-segment instructions
-  const int half = (nseg + 1) / 2;
-  int nconf = 0;
-  for (int p0 = 0; p0 < half; p0 += kWave) {
-    const int p = p0 + lane;
-    bool conf = false;
-    if (p < half && p + half < nseg) {
-      const S2Seg a = segs[p], b = segs[p + half];
-      conf = max(abs(a.ui - b.ui), abs(a.uj - b.uj)) < B.row_sep;
+  // first-fit packing: lane b is instruction b of the tile.  A segment joins the first instruction
+  // with enough free lanes, fewer than kS2MaxSeg members and no member it could collide with.
+  int used = 0, nmem = 0, nbins = 0;
+  for (int s = 0; s < nseg; ++s) {
+    const S2Seg q = segs[s];
+    bool ok = lane <= nbins && used + q.len <= kWave && nmem < kS2MaxSeg;
+    for (int j = 0; j < nmem; ++j) {
+      const S2Seg m = segs[member[lane][j]];
+      const bool rows_close = max(abs(m.ui - q.ui), abs(m.uj - q.uj)) < B.row_sep;
+      const bool planes_touch = (int)m.lzmin <= (int)q.lzmax + 1 && (int)q.lzmin <= (int)m.lzmax + 1;
+      ok = ok && !(rows_close && planes_touch);
     }
-    const unsigned long long m = __ballot(conf);
-    if (p < half) flag[p] = conf ? (unsigned char)1 : (unsigned char)0;
-    // index of this conflict among the tile's conflicts, stored for the fill pass
-    if (conf) segs[p + half].len = (short)(segs[p + half].len | ((nconf + __popcll(m & lt_mask)) << 6));
-    nconf += __popcll(m);
+    const unsigned long long m = __ballot(ok);
+    if (m == 0ull) {  // more than 64 instructions in one tile
+      if (lane == 0) atomicExch(err, 1);
+      break;
+    }
+    const int chosen = __ffsll((long long)m) - 1;
+    if (lane == chosen) {
+      member[lane][nmem++] = (unsigned short)s;
+      used += q.len;
+    }
+    nbins = max(nbins, chosen + 1);
   }
-  const int ninstr = half + nconf;
+  const int nent = lane < nbins ? nmem + (used < kWave ? 1 : 0) : 0;
+  // inclusive prefix sum of nent over lanes
+  int incl = nent;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int v = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl += v;
+  }
+  const int total_ent = __shfl(incl, kWave - 1, kWave);
   if (!FILL) {
-    if (lane == 0) counts[t] = 2u * (unsigned)ninstr;
+    if (lane == 0) counts[t] = make_uint2((unsigned)total_ent, (unsigned)nbins);
     return;
   }
-  S2_FENCE();
-  __syncthreads();
-  S2Entry *out = entries + counts[t];
-  auto make = [&](const S2Seg s, int len) {
-    const RowBase rb = affine_row(B.A, (float)s.ui, (float)s.uj);
-    S2Entry e;
-    e.rx = rb.x, e.ry = rb.y, e.rz = rb.z;
-    e.k0f = (float)s.k0;
-    e.srcoff = (unsigned)s.ui * B.sx + (unsigned)s.uj * B.sy;
-    const unsigned tabidx = (unsigned)(B.tabsel ? s.uj : s.ui);
-    e.kl = (unsigned)s.k0 | ((unsigned)len << 12) | (tabidx << 18);
-    return e;
-  };
-  const S2Entry empty{0.f, 0.f, 0.f, 0.f, 0u, 0u};
+  const uint2 base = counts[t];
   unsigned long long pts = 0;
-  for (int p0 = 0; p0 < half; p0 += kWave) {
-    const int p = p0 + lane;
-    if (p >= half) continue;
-    const S2Seg a = segs[p];
-    out[2 * p] = make(a, a.len & 63);
-    pts += (unsigned long long)(a.len & 63);
-    S2Entry eb = empty;
-    if (p + half < nseg) {
-      const S2Seg b = segs[p + half];
-      const int blen = b.len & 63;
-      pts += (unsigned long long)blen;
-      if (flag[p]) {
-        const int ci = b.len >> 6;
-        out[2 * (half + ci)] = make(b, blen);
-        out[2 * (half + ci) + 1] = empty;
-      } else {
-        eb = make(b, blen);
-      }
+  if (lane < nbins) {
+    S2Entry *out = entries + base.x + (incl - nent);
+    unsigned long long mask = 0ull;
+    int start = 0;
+    for (int j = 0; j < nmem; ++j) {
+      const S2Seg q = segs[member[lane][j]];
+      const RowBase rb = affine_row(B.A, (float)q.ui, (float)q.uj);
+      S2Entry e;
+      e.rx = rb.x, e.ry = rb.y, e.rz = rb.z;
+      e.pk = s2_rowcode(B, q.ui, q.uj) | ((unsigned)(q.k0 - start + 64) << kS2RowBits);
+      out[j] = e;
+      if (start > 0) mask |= 1ull << (start - 1);
+      start += q.len;
+      pts += q.len;
     }
-    out[2 * p + 1] = eb;
+    if (used < kWave) {
+      out[nmem] = S2Entry{0.f, 0.f, 0.f, kS2RowIdle | (64u << kS2RowBits)};
+      if (used > 0) mask |= 1ull << (used - 1);
+    }
+    masks[base.y + lane] = mask;
   }
   if (stats) {
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) pts += __shfl_down(pts, off, kWave);
     if (lane == 0) {
       atomicAdd(stats, pts);
-      atomicAdd(stats + 1, (unsigned long long)ninstr);
+      atomicAdd(stats + 1, (unsigned long long)nbins);
     }
   }
 }
 
 void splat2_free(SplatSched &S) {
   if (S.entries) (void)hipFree(S.entries);
+  if (S.masks) (void)hipFree(S.masks);
   if (S.tile_off) (void)hipFree(S.tile_off);
   if (S.scratch) (void)hipFree(S.scratch);
   S = SplatSched();
 }
 
 int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, Dim3i dd, float tol,
-                 const SplatSafety &safe, int axis, unsigned sx, unsigned sy) {
+                 const SplatSafety &safe, int axis, int rows_y) {
   S.valid = false;
   static const bool off = getenv("UNIRES_NO_SPLAT2") != nullptr;
+  static const bool verbose = getenv("UNIRES_SPLAT2_VERBOSE") != nullptr;
   if (off) return 1;
   if (safe.use_atomics) return 1;
   if (dd.x > 4000 || dd.y > 4000 || dd.z > 4000 || gd.x > 4000 || gd.y > 4000 || gd.z > 4000) return 1;
   if (!fits_fast_index(gd) || !fits_fast_index(dd) || dd.numel() >= (1ull << 30)) return 1;
+  // the row code must fit its 19 bits (all ones is reserved)
+  if (axis == 0 || axis == 1) {
+    if (gd.x > 1023 || gd.y > 511) return 1;
+  } else if ((long long)gd.x * rows_y >= (long long)kS2RowIdle || rows_y < gd.y) {
+    return 1;
+  }
   const int nt = s2_ntiles(dd);
   if ((size_t)nt + 1 > S.cap_tiles) {
     if (S.tile_off) (void)hipFree(S.tile_off);
     S.tile_off = nullptr;
-    if (hipMalloc((void **)&S.tile_off, ((size_t)nt + 1) * sizeof(unsigned)) != hipSuccess) return 1;
+    if (hipMalloc((void **)&S.tile_off, ((size_t)nt + 1) * sizeof(uint2)) != hipSuccess) return 1;
     S.cap_tiles = (size_t)nt + 1;
   }
   if (!S.scratch && hipMalloc((void **)&S.scratch, 4 * sizeof(unsigned long long)) != hipSuccess) return 1;
@@ -273,50 +311,57 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
   unsigned long long *stats_dev = S.scratch + 1;
   S2BuildArgs B;
   B.A = A, B.Ainv = Ainv, B.gd = gd, B.dd = dd, B.tol = tol, B.row_sep = safe.row_sep;
-  B.sx = sx, B.sy = sy, B.tabsel = axis == 1 ? 1 : 0;
+  B.axis = axis, B.rows_y = rows_y;
   hipLaunchKernelGGL(k_splat2_build<false>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off,
-                     (S2Entry *)nullptr, err_dev, (unsigned long long *)nullptr);
-  std::vector<unsigned> h((size_t)nt + 1);
-  if (hipMemcpy(h.data(), S.tile_off, (size_t)nt * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess)
+                     (S2Entry *)nullptr, (unsigned long long *)nullptr, err_dev,
+                     (unsigned long long *)nullptr);
+  std::vector<uint2> h((size_t)nt + 1);
+  if (hipMemcpy(h.data(), S.tile_off, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess)
     return 1;
-  unsigned run = 0;
+  unsigned re = 0, ri = 0;
   for (int i = 0; i < nt; ++i) {
-    const unsigned c = h[i];
-    h[i] = run;
-    run += c;
+    const uint2 c = h[i];
+    h[i] = make_uint2(re, ri);
+    re += c.x, ri += c.y;
   }
-  h[nt] = run;
-  if (run + 8 > S.cap_entries) {
+  h[nt] = make_uint2(re, ri);
+  constexpr size_t kPad = 160;  // entries read (never used) past the end by the ring prefetch
+  if ((size_t)re + kPad > S.cap_entries) {
     if (S.entries) (void)hipFree(S.entries);
     S.entries = nullptr;
-    const size_t cap = (size_t)run + run / 8 + 64;
+    const size_t cap = (size_t)re + re / 8 + kPad;
     if (hipMalloc((void **)&S.entries, cap * sizeof(S2Entry)) != hipSuccess) return 1;
     S.cap_entries = cap;
   }
-  if (hipMemcpy(S.tile_off, h.data(), ((size_t)nt + 1) * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess)
+  if ((size_t)ri + 8 > S.cap_instr) {
+    if (S.masks) (void)hipFree(S.masks);
+    S.masks = nullptr;
+    const size_t cap = (size_t)ri + ri / 8 + 8;
+    if (hipMalloc((void **)&S.masks, cap * sizeof(unsigned long long)) != hipSuccess) return 1;
+    S.cap_instr = cap;
+  }
+  if (hipMemcpy(S.tile_off, h.data(), ((size_t)nt + 1) * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess)
     return 1;
-  // a few entries past the end are read (never used) by the prefetch of the last tile
-  (void)hipMemset(S.entries + run, 0, 8 * sizeof(S2Entry));
+  (void)hipMemset(S.entries + re, 0xff, kPad * sizeof(S2Entry));
+  (void)hipMemset(S.masks + ri, 0, 8 * sizeof(unsigned long long));
   hipLaunchKernelGGL(k_splat2_build<true>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off, S.entries,
-                     err_dev, stats_dev);
+                     S.masks, err_dev, stats_dev);
   int herr = 0;
   unsigned long long hs[2] = {0, 0};
   if (hipMemcpy(&herr, err_dev, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 1;
   if (hipMemcpy(hs, stats_dev, sizeof(hs), hipMemcpyDeviceToHost) != hipSuccess) return 1;
-  static const bool verbose = getenv("UNIRES_SPLAT2_VERBOSE") != nullptr;
   if (herr) {
-    if (verbose) fprintf(stderr, "[splat2] a tile exceeds the segment list: general kernel used\n");
+    if (verbose) fprintf(stderr, "[splat2] a tile exceeds the segment / instruction lists: general kernel used\n");
     return 1;
   }
   S.ntiles = nt;
-  S.total = run;
   S.axis = axis;
   S.fill = hs[1] ? (double)hs[0] / (64.0 * (double)hs[1]) : 0.0;
   S.valid = true;
   if (verbose)
-    fprintf(stderr, "[splat2] %d tiles, %llu instructions, %llu points (%.2f per output voxel), lane fill %.3f, "
-            "schedule %.1f MB, row_sep %d\n", nt, hs[1], hs[0], (double)hs[0] / (double)dd.numel(), S.fill,
-            run * sizeof(S2Entry) / 1e6, safe.row_sep);
+    fprintf(stderr, "[splat2] %d tiles, %llu instructions, %u segments, %llu points (%.2f per output voxel), "
+            "lane fill %.3f, schedule %.1f MB, row_sep %d\n", nt, hs[1], re, hs[0],
+            (double)hs[0] / (double)dd.numel(), S.fill, (re * sizeof(S2Entry) + ri * 8.0) / 1e6, safe.row_sep);
   return 0;
 }
 
@@ -348,12 +393,14 @@ void splat2_convtab(const Taps &T, const Scaling &S, int axis, int gn, int xdn, 
 struct S2Args {
   const float *src;
   size_t src_bytes;
-  const float4 *tab;  // conv_up table (AXIS >= 0)
-  int gn;             // entries in it
-  int tabn;           // LDS table length (gn + L, padded with zeros)
-  unsigned tab_step;  // elements between the two x-space values of a grid voxel (AXIS 0 / 1)
+  const float4 *tab;     // conv_up table (AXIS >= 0)
+  int gn;                // entries in it
+  int tabn;              // LDS table length (padded with zeros: idle lanes index past gn)
+  unsigned row_stride4;  // bytes per unit of the row code (see launch_splat2)
+  unsigned tab_step4;    // bytes between the two x-space values of a grid voxel
   const S2Entry *entries;
-  const unsigned *tile_off;
+  const unsigned long long *masks;
+  const uint2 *tile_off;
   int ntiles;
   Affine A;
   float alpha;
@@ -364,38 +411,33 @@ struct S2Args {
   int accumulate;
   double *partials;
   const float *objb;
-  int dbg;  // UNIRES_S2_DBG ablation bits (0 in production): 1 no splat, 2 no epilogue, 4 no LDS updates, 8 no source loads
+  int dbg;  // UNIRES_S2_DBG ablation bits (read only by -DUNIRES_ABLATE builds)
 };
-
-__device__ __forceinline__ S2Entry s2_load_entry(const S2Entry *p) {
-  S2Entry e;
-  __builtin_memcpy(&e, p, sizeof(e));
-  return e;
-}
 
 template <int AXIS>
 __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int *__restrict__ done) {
   if (done && *done) return;
   using T = S2Tile;
-  constexpr int TX = T::TX, TY = T::TY, TZ = T::TZ, L = T::L, G = kWave / L;
+  constexpr int TX = T::TX, TY = T::TY, L = T::L, G = kWave / L;
   constexpr int SY = T::SY, SZ = T::SZ, N = T::N, XS = T::XS, YS = T::YS;
   constexpr bool CONV = AXIS >= 0;
   __shared__ __align__(16) float acc_all[kS2Waves][N];
-  extern __shared__ float tabs[];  // CONV: byte offsets | w0 | w1, tabn entries each
+  __shared__ __align__(16) uint4 ring_all[kS2Waves][kWave];  // 2 chunks of 32 segment entries
+  extern __shared__ float4 tabs[];  // CONV: {byte offset, alpha w0, alpha w1, -}, tabn entries
   const int lane = threadIdx.x & (kWave - 1), grp = lane / L, gl = lane & (L - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *acc = acc_all[wave];
+  uint4 *ring = ring_all[wave];
   const Dim3i dd = P.dd;
   const float *__restrict__ pin = P.p;
   float *__restrict__ dst = P.dst;
   if (CONV) {
-    const unsigned step = AXIS == 2 ? 1u : P.tab_step;
+    const unsigned step4 = AXIS == 2 ? 4u : P.tab_step4;
     for (int i = threadIdx.x; i < P.tabn; i += kWave * kS2Waves) {
       float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i < P.gn) e = P.tab[i];
-      tabs[i] = __int_as_float((int)(4u * step * (unsigned)__float_as_int(e.x)));
-      tabs[P.tabn + i] = P.alpha * e.y;
-      tabs[2 * P.tabn + i] = P.alpha * e.z;
+      tabs[i] = make_float4(__int_as_float((int)(step4 * (unsigned)__float_as_int(e.x))), P.alpha * e.y,
+                            P.alpha * e.z, 0.f);
     }
     __syncthreads();
   }
@@ -410,64 +452,87 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
   const int slots = ((gridDim.x + nxcd - 1 - xcd) / nxcd) * kS2Waves;
   const float c0 = P.A.m[2], c1 = P.A.m[6], c2 = P.A.m[10];
   const float t0 = P.A.m[3], t1 = P.A.m[7], t2 = P.A.m[11];
-  const float glf = (float)gl;
-  const unsigned gl4 = 4u * (unsigned)gl;
+  const int lane_m64 = lane - 64;
   double dot = 0.0;
   for (int tl = slot; tl < per_xcd; tl += slots) {
     const int t = xcd * per_xcd + tl;
     if (t >= ntiles) break;
     const S2TileGeom g = s2_tile(t, dd);
     const int x0 = g.x0, y0 = g.y0, z0 = g.z0, ex = g.ex, ey = g.ey, ez = g.ez;
+    const uint2 off0 = P.tile_off[t], off1 = P.tile_off[t + 1];
+    const int ninstr = (int)(off1.y - off0.y);
+    const uint4 *E = reinterpret_cast<const uint4 *>(P.entries) + off0.x;
+    // lane l keeps the segment-start mask of instruction l (a tile has at most 64 of them)
+    const unsigned long long mymask = lane < ninstr ? P.masks[off0.y + lane] : 0ull;
+    const int mlo_v = (int)(unsigned)mymask, mhi_v = (int)(unsigned)(mymask >> 32);
     S2_FENCE();
+    // segment ring: chunks 0 and 1 now, chunk 2 in flight in registers
+    ring[lane] = E[lane];
+    uint4 pre = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < 32) pre = E[64 + lane];
     for (int i = lane; i < N / 4; i += kWave)
       reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float xb = (float)(x0 - 1), yb = (float)(y0 - 1), zb = (float)(z0 - 1);
-    const unsigned off0 = P.tile_off[t], off1 = P.tile_off[t + 1];
-    const int ninstr = (int)((off1 - off0) >> 1);
-    const S2Entry *E = P.entries + off0 + grp;
+    int chunk_lo = 0;  // the ring holds chunks chunk_lo and chunk_lo + 1 (32 entries each)
+    int eb = 0;        // first entry of the next instruction, relative to the tile
     S2_FENCE();
     constexpr int kU = 4;
-    auto load = [&](S2Entry(&e)[kU], int p0) {
-#pragma unroll
-      for (int u = 0; u < kU; ++u) e[u] = s2_load_entry(E + 2 * (p0 + u));  // (8 spare entries past the end)
-    };
-    auto process = [&](const S2Entry(&e)[kU], int p0) {
-      float val[kU];
-      bool act[kU];
-      float kf[kU];
-      // ---- source values: conv_up regenerated on the fly from x-space ----
+    for (int p0 = S2_ABL(1) ? ninstr : 0; p0 < ninstr; p0 += kU) {
+      unsigned mlo[kU], mhi[kU];
+      int ebu[kU];
+      int need = eb;
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        const unsigned kl = e[u].kl;
-        const int len = (p0 + u < ninstr) ? (int)((kl >> 12) & 63u) : 0;
-        act[u] = gl < len;
-        kf[u] = e[u].k0f + glf;
-        const unsigned k4 = 4u * (kl & 0xfffu) + gl4;  // byte offset of grid z
-        const unsigned so4 = 4u * e[u].srcoff;
-        if (P.dbg & 8) {
+        // (a batch slot past the tile's last instruction replays that instruction, switched off)
+        const int pi = min(p0 + u, ninstr - 1);
+        mlo[u] = (unsigned)__builtin_amdgcn_readlane(mlo_v, pi);
+        mhi[u] = (unsigned)__builtin_amdgcn_readlane(mhi_v, pi);
+        ebu[u] = (p0 + u < ninstr || u == 0) ? need : ebu[u > 0 ? u - 1 : 0];
+        if (p0 + u < ninstr) need += __popc(mlo[u]) + __popc(mhi[u]) + 1;
+      }
+      if (need > 32 * (chunk_lo + 2)) {  // advance the ring by one chunk (the oldest one is dead)
+        S2_FENCE();
+        if (lane < 32) ring[(chunk_lo & 1) * 32 + lane] = pre;
+        ++chunk_lo;
+        if (lane < 32) pre = E[32 * (chunk_lo + 2) + lane];
+        S2_FENCE();
+      }
+      eb = need;
+      float val[kU], kf[kU], rx[kU], ry[kU], rz[kU];
+      bool act[kU];
+      // ---- decode + source values (conv_up regenerated on the fly from x-space) ----
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int sl = (int)__builtin_amdgcn_mbcnt_hi(mhi[u], __builtin_amdgcn_mbcnt_lo(mlo[u], 0u));
+        const uint4 e = ring[(ebu[u] + sl) & 63];
+        rx[u] = __uint_as_float(e.x), ry[u] = __uint_as_float(e.y), rz[u] = __uint_as_float(e.z);
+        const unsigned code = e.w & kS2RowIdle;
+        act[u] = code != kS2RowIdle && p0 + u < ninstr;
+        const int k = (int)(e.w >> kS2RowBits) + lane_m64;
+        kf[u] = (float)k;
+        if (S2_ABL(8)) {
           val[u] = 1.f;
         } else if (AXIS == 2) {
-          const float koff = tabs[k4 >> 2], w0 = tabs[P.tabn + (k4 >> 2)], w1 = tabs[2 * P.tabn + (k4 >> 2)];
-          const unsigned a = so4 + (unsigned)__float_as_int(koff);
-          const float pa = buf_load(rsrc, a, 0), pb = buf_load(rsrc, a + 4u, 0);
-          val[u] = w0 * pa + w1 * pb;
+          const float4 tb = tabs[k];
+          const unsigned a = __umul24(code, P.row_stride4) + (unsigned)__float_as_int(tb.x);
+          const uint2 pr = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a, 0, 0));
+          val[u] = tb.y * __uint_as_float(pr.x) + tb.z * __uint_as_float(pr.y);
         } else if (AXIS == 0 || AXIS == 1) {
-          const unsigned ti = kl >> 18;
-          const float koff = tabs[ti], w0 = tabs[P.tabn + ti], w1 = tabs[2 * P.tabn + ti];
-          const unsigned a = so4 + (unsigned)__float_as_int(koff) + k4;
-          const float pa = buf_load(rsrc, a, 0), pb = buf_load(rsrc, a + 4u * P.tab_step, 0);
-          val[u] = w0 * pa + w1 * pb;
+          const unsigned ui = code >> 9, uj = code & 511u;
+          const float4 tb = tabs[AXIS == 0 ? ui : uj];
+          const unsigned a = __umul24(AXIS == 0 ? uj : ui, P.row_stride4) + (unsigned)__float_as_int(tb.x) +
+                             4u * (unsigned)k;
+          val[u] = tb.y * buf_load(rsrc, a, 0) + tb.z * buf_load(rsrc, a + P.tab_step4, 0);
         } else {
-          val[u] = P.alpha * buf_load(rsrc, so4 + k4, 0);
+          val[u] = P.alpha * buf_load(rsrc, __umul24(code, P.row_stride4) + 4u * (unsigned)k, 0);
         }
       }
       // ---- the splat proper ----
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        float gx, gy, gz;
-        gx = fmaf(c0, kf[u], e[u].rx) + t0;
-        gy = fmaf(c1, kf[u], e[u].ry) + t1;
-        gz = fmaf(c2, kf[u], e[u].rz) + t2;
+        const float gx = fmaf(c0, kf[u], rx[u]) + t0;
+        const float gy = fmaf(c1, kf[u], ry[u]) + t1;
+        const float gz = fmaf(c2, kf[u], rz[u]) + t2;
         // local coordinates: the subtraction of the (integer) tile base is exact
         const float lxf = gx - xb, lyf = gy - yb, lzf = gz - zb;
         const float wx1 = __builtin_amdgcn_fractf(lxf), wy1 = __builtin_amdgcn_fractf(lyf),
@@ -480,8 +545,8 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
         const float vx0 = v * wx0, vx1 = v * wx1;
         const float a00 = vx0 * wy0, a01 = vx0 * wy1, a10 = vx1 * wy0, a11 = vx1 * wy1;
         S2_FENCE();
-        if (P.dbg & 4) dot += (double)(a00 + a01 + a10 + a11 + (float)cell);
-        if (act[u] && !(P.dbg & 4)) {
+        if (S2_ABL(4)) dot += (double)(a00 + a01 + a10 + a11 + (float)cell);
+        if (act[u] && !S2_ABL(4)) {
           float *q = acc + cell;
           {
             const float o00 = q[0], o01 = q[YS], o10 = q[XS], o11 = q[XS + YS];
@@ -497,25 +562,12 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
         }
         S2_FENCE();
       }
-    };
-    if (ninstr > 0 && !(P.dbg & 1)) {
-      S2Entry ea[kU], eb[kU];
-      load(ea, 0);
-      for (int p0 = 0; p0 < ninstr; p0 += 2 * kU) {
-        const bool more = p0 + kU < ninstr;
-        if (more) load(eb, p0 + kU);
-        process(ea, p0);
-        if (more) {
-          if (p0 + 2 * kU < ninstr) load(ea, p0 + 2 * kU);
-          process(eb, p0 + kU);
-        }
-      }
     }
     S2_FENCE();
     // ---- epilogue: q = [q +] acc + a0 p + c DtD p ; dot += p*q  (one row per lane group) ----
+    if (S2_ABL(2)) continue;
     constexpr int RPX = TY / G;  // instructions per x slab of the tile
     static_assert((TX * RPX) % 4 == 0, "fast epilogue unrolls four instructions");
-    if (P.dbg & 2) continue;
     const bool fast_xy = pin != nullptr && !P.accumulate && x0 > 0 && y0 > 0 &&
                          x0 + TX < dd.x && y0 + TY < dd.y && dd.numel() < (1ull << 29);
     if (fast_xy) {
@@ -605,25 +657,27 @@ static int s2_grid(Dim3i dd) {
 int splat2_blocks(Dim3i dd) { return s2_grid(dd) * kS2Waves; }  // partials written
 
 int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const float4 *tab_dev, int gn,
-                  unsigned tab_step, const Affine &A, float alpha, float tol, const PushEpilogue &ep, float *dst,
-                  Dim3i dd, const int *done, hipStream_t st) {
-  (void)tol;
+                  unsigned row_stride, unsigned tab_step, const Affine &A, float alpha,
+                  const PushEpilogue &ep, float *dst, Dim3i dd, const int *done, hipStream_t st) {
   if (!S.valid || S.ntiles != s2_ntiles(dd)) return 1;
   if (S.axis >= 0 && !tab_dev) return 1;
-  S2Args P;
   if (src_numel >= (1ull << 30)) return 1;  // 32-bit byte offsets into the source
+  if ((unsigned long long)row_stride * 4ull >= (1ull << 24)) return 1;  // 24-bit multiply
+  S2Args P;
   P.src = src;
-  P.src_bytes = src_numel * sizeof(float);  // buffer range check: idle lanes may point past a row
-  P.tab = tab_dev, P.gn = gn, P.tabn = S.axis >= 0 ? gn + S2Tile::L : 0, P.tab_step = tab_step;
-  P.entries = S.entries, P.tile_off = S.tile_off, P.ntiles = S.ntiles;
+  P.src_bytes = src_numel * sizeof(float);  // buffer range check: idle lanes may point anywhere
+  P.tab = tab_dev, P.gn = gn;
+  P.tabn = S.axis >= 0 ? gn + kWave : 0;
+  P.row_stride4 = 4u * row_stride, P.tab_step4 = 4u * tab_step;
+  P.entries = S.entries, P.masks = S.masks, P.tile_off = S.tile_off, P.ntiles = S.ntiles;
   P.A = A, P.alpha = alpha;
   P.p = ep.p, P.a0 = ep.a0, P.cx = ep.cx, P.cy = ep.cy, P.cz = ep.cz;
   P.dst = dst, P.dd = dd, P.accumulate = ep.accumulate, P.partials = ep.partials, P.objb = ep.objb;
   static const int dbg = getenv("UNIRES_S2_DBG") ? atoi(getenv("UNIRES_S2_DBG")) : 0;
   P.dbg = dbg;
   const dim3 grid(s2_grid(dd)), block(kWave * kS2Waves);
-  const size_t lds = S.axis >= 0 ? 3 * (size_t)P.tabn * sizeof(float) : 0;
-  if (lds > 48 * 1024) return 1;
+  const size_t lds = S.axis >= 0 ? (size_t)P.tabn * sizeof(float4) : 0;
+  if (lds > 24 * 1024) return 1;
   switch (S.axis) {
     case 0: hipLaunchKernelGGL((k_splat2<0>), grid, block, lds, st, P, done); break;
     case 1: hipLaunchKernelGGL((k_splat2<1>), grid, block, lds, st, P, done); break;
