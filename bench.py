@@ -175,13 +175,21 @@ def time_matvec(x, y, rho, sett, reps=16, ring=2):
     return e0.elapsed_time(e1) * 1e-3 / (reps * C)
 
 
-def cpu_baseline(wl, seconds_budget=25.0):
-    """CPU oracle ("port" of the reference composition) on one channel of the same
-    workload: fixed-iteration CG, as many iterations as fit the budget (>= 1)."""
-    from oracle import nitorch_restated as N
+def host_cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def oracle_channel(wl, dim_y, seed=0):
+    """One channel of workload ``wl`` at size ``dim_y`` as oracle structs (+ the raw pieces)."""
     from oracle import unires_restated as O
-    dim_y, thick = wl['dim_y'], wl['thick']
-    gen = torch.Generator().manual_seed(0)
+    thick = wl['thick']
+    gen = torch.Generator().manual_seed(seed)
     mat_y = torch.eye(4, dtype=torch.float64)
     scale = [1.0, 1.0, float(thick)] if wl['axes'] is not None else [float(thick)] * 3
     if wl['axes'] is None:
@@ -189,28 +197,127 @@ def cpu_baseline(wl, seconds_budget=25.0):
     mat_x = mat_y @ torch.diag(torch.tensor(scale + [1.0], dtype=torch.float64))
     dim_x = tuple(int(math.floor(d / s)) for d, s in zip(dim_y, scale))
     u = torch.rand(6, generator=gen) * 2 - 1
-    po = O.proj_info(dim_y, mat_y, dim_x, mat_x,
-                     rigid=rigid_matrix((u[:3] * 5.0).tolist(), (u[3:] * 0.1).tolist()))
-    xc = [O.make_input(torch.rand(dim_x, generator=gen) * 400, mat_x, torch.tensor(1 / 75.0 ** 2), po)]
-    yc = O.make_output(torch.zeros(dim_y), mat_y, torch.tensor(4.0 * math.sqrt(1 / 3.0) / 400.0))
-    vx = N.voxel_size(mat_y).float()
-    rho = torch.tensor(0.9)
+    rigid = rigid_matrix((u[:3] * 5.0).tolist(), (u[3:] * 0.1).tolist())
+    po = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid)
+    dat_x = torch.rand(dim_x, generator=gen) * 400
+    tau, lam = 1 / 75.0 ** 2, 4.0 * math.sqrt(1 / 3.0) / 400.0
+    xc = [O.make_input(dat_x, mat_x, torch.tensor(tau), po)]
+    yc = O.make_output(torch.zeros(dim_y), mat_y, torch.tensor(lam))
+    b = torch.rand(dim_y, generator=gen)
+    return dict(mat_y=mat_y, mat_x=mat_x, dim_x=dim_x, rigid=rigid, xc=xc, yc=yc, b=b, tau=tau, lam=lam,
+                dat_x=dat_x, po=po)
+
+
+def oracle_lhs(wl, P, rho=0.9):
+    from oracle import nitorch_restated as N
+    from oracle import unires_restated as O
     regime = wl.get('regime', 'sr')
     method = 'super-resolution' if regime == 'sr' else 'denoising'
-    lhs = lambda d: O.proj('AtA', d, xc, yc, method=method, do=regime != 'id', rho=rho, vx_y=vx)
-    b = torch.rand(dim_y, generator=gen)
+    vx = N.voxel_size(P['mat_y']).float()
+    return lambda d: O.proj('AtA', d, P['xc'], P['yc'], method=method, do=regime != 'id',
+                            rho=torch.tensor(rho), vx_y=vx)
+
+
+def fov_tie_voxels(wl, P, eps=1e-4, reach=2):
+    """Output voxels that a grid point within ``eps`` of an in-FOV threshold can reach.  The
+    reference's mask is discontinuous there: which side a float32 coordinate falls on depends on
+    the last-ulp rounding of the coordinate arithmetic (torch-CPU matmul vs FMA chain), so the
+    matvec legitimately differs by one grid point's worth in these voxels."""
+    from oracle import nitorch_restated as N
+    from oracle import unires_restated as O
+    regime = wl.get('regime', 'sr')
+    method = 'super-resolution' if regime == 'sr' else 'denoising'
+    mat, dim = O.proj_matrix(P['po'], method)
+    g = N.affine_grid(mat.float(), dim)
+    dim_y = tuple(P['b'].shape)
+    near = torch.zeros(g.shape[:3], dtype=torch.bool)
+    for d, n in enumerate(dim_y):
+        for thr in (-5e-2, n - 1 + 5e-2):
+            near |= (g[..., d] - thr).abs() < eps
+    pts = g[near]
+    bad = torch.zeros(dim_y, dtype=torch.bool)
+    for pt in pts:
+        lo = [int(max(0, math.floor(float(v)) - reach + 1)) for v in pt]
+        hi = [int(min(n, math.floor(float(v)) + reach + 1)) for v, n in zip(pt, dim_y)]
+        if all(h > l for l, h in zip(lo, hi)):
+            bad[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = True
+    return bad, int(near.sum())
+
+
+def matvec_parity(wl, P, q_cpu, device, rho=0.9):
+    """float32 agreement of the HIP matvec with the oracle on the same operator and input
+    (relative L2 error, gate 1e-4, and max-abs error)."""
+    import unires_amd as U
+    from unires_amd._project import _channel_plan
+    regime = wl.get('regime', 'sr')
+    method = 'super-resolution' if regime == 'sr' else 'denoising'
+    dim_y = tuple(P['b'].shape)
+    po_g = U._proj_info(dim_y, P['mat_y'], P['dim_x'], P['mat_x'], rigid=P['rigid'], prof_ip=0, prof_tp=0,
+                        device=device)
+    xg = [U._input(P['dat_x'].to(device), P['mat_x'], P['tau'], po_g)]
+    yg = U._output(torch.zeros(dim_y, device=device), P['mat_y'], P['lam'])
+    plan = _channel_plan(xg, yg, method, regime != 'id')
+    q_gpu = plan.matvec(P['b'].to(device), rho, P['lam']).cpu()
+    diff = (q_gpu.double() - q_cpu.double())
+    ties, n_near = fov_tie_voxels(wl, P)
+    keep = ~ties
+    return {'rel_err': float(diff.norm() / q_cpu.double().norm()),
+            'max_abs': float(diff.abs().max()), 'ref_max_abs': float(q_cpu.abs().max()),
+            'rel_err_away_from_fov_ties': float(diff[keep].norm() / q_cpu.double()[keep].norm()),
+            'max_abs_away_from_fov_ties': float(diff[keep].abs().max()),
+            'fov_tie_grid_points': n_near, 'fov_tie_voxels_excluded': int(ties.sum()),
+            'what': 'HIP ata_matvec vs oracle _proj(AtA) on the same %dx%dx%d operator and input; '
+                    '"away from ties" leaves out the output voxels within reach of grid points whose '
+                    'coordinate lies within 1e-4 of an in-FOV threshold (the reference mask is '
+                    'discontinuous there)' % dim_y}
+
+
+def cpu_baseline(wl, seconds_budget=25.0, device=None):
+    """CPU oracle ("port" of the reference composition) on one channel of the same
+    workload: fixed-iteration CG, as many iterations as fit the budget (>= 1).
+
+    The first oracle matvec is also the full-size parity check of SURVEY 8(d): the HIP matvec
+    runs on the SAME operator and the SAME input and the float32 relative / max-abs error is
+    reported next to the timing (gate 1e-4).  A single-thread timing of the same operator on a
+    problem of half the linear size gives the n = 1 figure (a 256^3 single-thread matvec would
+    take minutes)."""
+    from oracle import nitorch_restated as N
+    dim_y = wl['dim_y']
+    P = oracle_channel(wl, dim_y)
+    lhs = oracle_lhs(wl, P)
     t0 = time.perf_counter()
-    lhs(b)  # one matvec to size the sample
+    q_cpu = lhs(P['b'])  # one matvec: sizes the sample AND is the parity reference
     t_mv = time.perf_counter() - t0
+    parity = matvec_parity(wl, P, q_cpu, device) if device is not None else None
     n_it = max(1, min(20, int(seconds_budget / max(t_mv, 1e-3)) - 1))
     t0 = time.perf_counter()
-    N.cg(lhs, b, yc.dat, max_iter=n_it, tolerance=0, stop='max_gain')
+    N.cg(lhs, P['b'], P['yc'].dat, max_iter=n_it, tolerance=0, stop='max_gain')
     dt = time.perf_counter() - t0
+    cores = torch.get_num_threads()
+    # n = 1 thread: same operator shape at half the linear size, one matvec
+    small = tuple(max(16, d // 2) for d in dim_y)
+    Ps = oracle_channel(wl, small, seed=1)
+    lhs_s = oracle_lhs(wl, Ps)
+    torch.set_num_threads(1)
+    try:
+        t0 = time.perf_counter()
+        lhs_s(Ps['b'])
+        t1 = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(cores)
+    nvox = dim_y[0] * dim_y[1] * dim_y[2]
+    nvox_s = small[0] * small[1] * small[2]
     # cg(tolerance=0) does n_it + 1 matvecs for n_it iterations; report iterations/s
-    return dict(value=n_it / dt, unit='cg_iters/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d CG iterations (tol=0) of one %dx%dx%d channel, oracle/unires_restated '
-                       '(torch-CPU, unfused as the reference composes it); matvec %.2f s'
-                       % (n_it, dim_y[0], dim_y[1], dim_y[2], t_mv))
+    out = dict(value=n_it / dt, unit='cg_iters/s', cores=cores, kind='port', cpu_model=host_cpu_model(),
+               sample='%d CG iterations (tol=0) of one %dx%dx%d channel, oracle/unires_restated '
+                      '(torch-CPU, unfused as the reference composes it); matvec %.2f s'
+                      % (n_it, dim_y[0], dim_y[1], dim_y[2], t_mv),
+               matvec_s=t_mv, matvec_Mvox_per_s=nvox / t_mv / 1e6,
+               single_thread={'cores': 1, 'matvec_s': t1, 'matvec_Mvox_per_s': nvox_s / t1 / 1e6,
+                              'sample': 'one matvec of a %dx%dx%d channel (same operator shape)' % small})
+    if parity is not None:
+        out['parity'] = parity
+    return out
 
 
 def time_steps(step, steps, warmup):
@@ -265,6 +372,21 @@ def variants(name, x, y, z, w, rho, tmp, sett, device):
     return out
 
 
+def spawn_ranks(n, argv, dry_run=False):
+    """`python bench.py --gpus N` without a launcher: run N ranks (one per GPU, RCCL) through
+    torch.distributed.run on 127.0.0.1, exactly as the driver's command line does."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    if dry_run:
+        return cmd
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -277,8 +399,13 @@ def main():
                     help='run the channels of the y-update one after the other on one stream '
                          '(profiling aid: per-kernel durations then carry no overlap)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0)
+    ap.add_argument('--admm-iters', type=int, default=50,
+                    help='ADMM iterations of the subjects/sec leg (one subject = this many iterations)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started as plain `python bench.py --gpus N`: re-launch as N ranks, one per GPU
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     from unires_amd import batch
@@ -330,19 +457,31 @@ def main():
     C = wl['C']
     iters_per_step = C * sett.cgs_max_iter
     total_iters = world * args.steps * iters_per_step
+    # subjects/sec: EVERY rank runs n_admm full ADMM iterations (y-update C x 20 CG,
+    # objective, z- and w-update) of its own subject between barriers; time = max over ranks
+    n_admm = max(1, args.admm_iters)
+    sett.tolerance = 1e-4
+    obj = torch.zeros((n_admm + 1, 3), dtype=torch.float64, device=device)
+    U._update_admm(x, y, z, w, rho, tmp, obj, 0, sett)  # warm-up (plans, graphs)
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+        torch.cuda.synchronize()
+    ta = time.perf_counter()
+    for it in range(1, n_admm + 1):
+        U._update_admm(x, y, z, w, rho, tmp, obj, it, sett)
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+        torch.cuda.synchronize()
+    t_subject = time.perf_counter() - ta
+    if dist:
+        t = torch.tensor([t_subject], dtype=torch.float64, device=device)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        t_subject = float(t.item())
     out = None
     if rank == 0:
         t_mv = time_matvec(x, y, rho, sett)
-        # one complete ADMM iteration (y-update + objective + z + w), for subjects/sec
-        sett.tolerance = 1e-4
-        obj = torch.zeros((4, 3), dtype=torch.float64, device=device)
-        U._update_admm(x, y, z, w, rho, tmp, obj, 0, sett)
-        torch.cuda.synchronize()
-        ta = time.perf_counter()
-        for it in range(1, 4):
-            U._update_admm(x, y, z, w, rho, tmp, obj, it, sett)
-        torch.cuda.synchronize()
-        t_admm = (time.perf_counter() - ta) / 3
         b_mv = alg_bytes_matvec(x[0], wl['dim_y'], sett.do_proj)
         achieved = b_mv / t_mv / 1e9
         out = {
@@ -356,10 +495,10 @@ def main():
                        'step': 'one y-update of one subject: C x (RHS + 20 CG iterations)',
                        'channel_streams': bool(getattr(sett, 'channel_streams', True)),
                        'parallelism': 'one subject per GPU, no data-path collective'},
-            'subjects_per_sec': world / (50.0 * t_admm),
-            'subjects_per_sec_note': 'subject = 50 full ADMM iterations (y-update C x 20 CG, objective, '
-                                     'z- and w-update); ADMM iteration timed on rank 0: %.2f ms'
-                                     % (t_admm * 1e3),
+            'subjects_per_sec': world / t_subject,
+            'subjects_per_sec_note': 'subject = %d full ADMM iterations (y-update C x 20 CG, objective, z- and '
+                                     'w-update) run on every rank between barriers, max over ranks: %.3f s '
+                                     '(%.2f ms per ADMM iteration)' % (n_admm, t_subject, t_subject / n_admm * 1e3),
             'roofline': {'bound': 'hbm', 'kernel': 'ata_matvec (per launch, mean over channels, cold operands)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.workload),
@@ -368,7 +507,7 @@ def main():
         if world == 1 and not args.no_variants:
             out['variants'] = variants(args.workload, x, y, z, w, rho, tmp, sett, device)
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(wl, args.cpu_seconds)
+            out['cpu_baseline'] = cpu_baseline(wl, args.cpu_seconds, device=device)
         print(json.dumps(out))
         sys.stdout.flush()
     if dist:

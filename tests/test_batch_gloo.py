@@ -68,3 +68,35 @@ def test_single_process_needs_no_process_group():
     from unires_amd import batch
     out = batch.run_batch(3, lambda s: s * 2.0)
     assert out['results'] == {0: 0.0, 1: 2.0, 2: 4.0} and out['world_size'] == 1
+
+
+def test_bench_self_spawn_launches_one_rank_per_gpu(tmp_path):
+    """`python bench.py --gpus N` without a launcher re-launches itself through
+    torch.distributed.run (bench.spawn_ranks).  The command line it builds is run here for real -
+    two gloo ranks on CPU - with a probe script in place of bench.py."""
+    import subprocess
+    import sys
+    import bench
+    cmd = bench.spawn_ranks(2, ['--gpus', '2', '--steps', '3'], dry_run=True)
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '2'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ['--gpus', '2', '--steps', '3']
+    probe = tmp_path / 'probe.py'
+    probe.write_text(
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch, torch.distributed as dist\n"
+        "from unires_amd import batch\n"
+        "rank, world, local = batch.init_from_env(backend='gloo')\n"
+        "t = torch.tensor([float(rank + 1)], dtype=torch.float64)\n"
+        "dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "dist.barrier()\n"
+        "if rank == 0:\n"
+        "    print('n_gpus=%%d max=%%g args=%%s' %% (world, t.item(), ' '.join(sys.argv[1:])))\n"
+        "dist.destroy_process_group()\n" % os.path.dirname(os.path.abspath(bench.__file__)))
+    cmd[i] = str(probe)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'n_gpus=2 max=2 args=--gpus 2 --steps 3' in out.stdout

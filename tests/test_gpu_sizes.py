@@ -1,0 +1,80 @@
+"""HIP-vs-oracle parity at sizes between the toy problems and the BASELINE configurations:
+mid-size volumes (seconds of CPU oracle) for every regime / tile-tail shape the BASELINE
+configs have, and the FULL 256^3 configuration-3 geometry for one channel (one oracle operator
+application, ~10 s on the GPU box's host cores).  Gate: 1e-4 relative (north_star).
+
+The reference's in-FOV mask (nitorch extrapolate=False, +-5e-2) is discontinuous: a float32
+grid coordinate that lies within a few ulps of a threshold falls on one side or the other
+depending on the rounding of the coordinate arithmetic (torch-CPU matmul in the oracle, FMA
+chain in the kernels).  Small test problems are drawn away from such ties
+(tests/helpers.fov_margin); at 256^3 every geometry has a few, so the gate is applied to the
+output voxels out of reach of tie points, and the all-voxel error is bounded by the energy those
+few points can carry."""
+import math
+
+import pytest
+import torch
+
+import bench
+from oracle import nitorch_restated as N
+from oracle import unires_restated as O
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+GATE = 1e-4
+
+
+def _check(dev, wlname, dim_y, seed, rhs=True):
+    from unires_amd._project import _channel_plan
+    import unires_amd as U
+    wl = dict(bench.WORKLOADS[wlname])
+    P = bench.oracle_channel(wl, dim_y, seed=seed)
+    q_cpu = bench.oracle_lhs(wl, P)(P['b'])
+    par = bench.matvec_parity(wl, P, q_cpu, dev)
+    assert par['rel_err_away_from_fov_ties'] < GATE, par
+    # a tie point flips one grid sample: all-voxel error stays tiny, bounded by their number
+    n_vox = dim_y[0] * dim_y[1] * dim_y[2]
+    assert par['rel_err'] < GATE + 4.0 * math.sqrt((par['fov_tie_grid_points'] + 1) / n_vox), par
+    assert par['fov_tie_voxels_excluded'] < 0.01 * n_vox
+    if not rhs:
+        return par
+    regime = wl.get('regime', 'sr')
+    method = 'super-resolution' if regime == 'sr' else 'denoising'
+    g = torch.Generator().manual_seed(seed + 100)
+    z = 0.05 * torch.randn((3,) + tuple(dim_y), generator=g)
+    w = 0.05 * torch.randn((3,) + tuple(dim_y), generator=g)
+    vx = N.voxel_size(P['mat_y']).float()
+    ref_b = O.y_rhs(P['xc'], P['yc'], z, w, torch.tensor(0.9), vx, method, regime != 'id')
+    po_g = U._proj_info(dim_y, P['mat_y'], P['dim_x'], P['mat_x'], rigid=P['rigid'], prof_ip=0, prof_tp=0,
+                        device=dev)
+    xg = [U._input(P['dat_x'].to(dev), P['mat_x'], P['tau'], po_g)]
+    yg = U._output(torch.zeros(dim_y, device=dev), P['mat_y'], P['lam'])
+    plan = _channel_plan(xg, yg, method, regime != 'id')
+    b = plan.rhs([xg[0].dat], w.to(dev), z.to(dev), 0.9, P['lam']).cpu()
+    ties, _ = bench.fov_tie_voxels(wl, P)
+    keep = ~ties
+    assert rel_err(b[keep], ref_b[keep]) < GATE
+    return par
+
+
+@pytest.mark.parametrize('wlname,dim_y', [
+    ('cfg3_256c3_thick6z', (96, 90, 102)),   # R2, thick z, tilted rigid, tile tails in x / y / z
+    ('cfg4_384c4_iso2', (96, 90, 100)),      # R2, ratio 2,2,2 (0.5 mm recon)
+    ('cfg2_181c3_1mm', (91, 109, 91)),       # R1 (pull / push only), half of 181 x 217 x 181
+    ('cfg1_181c1_denoise', (91, 109, 91)),   # R0 (A = I)
+])
+def test_midsize_matvec_and_rhs_match_oracle(dev, wlname, dim_y):
+    _check(dev, wlname, dim_y, seed=3)
+
+
+def test_full_size_config3_matvec_matches_oracle(dev):
+    """BASELINE configs[2] geometry, one channel, 256^3: one oracle operator application."""
+    par = _check(dev, 'cfg3_256c3_thick6z', (256, 256, 256), seed=0, rhs=False)
+    print('256^3 parity:', par)
+
+
+def test_full_size_config1_shape_matches_oracle(dev):
+    """181 x 217 x 181 (BrainWeb shape, non-multiple-of-tile tails), R1 and R0."""
+    _check(dev, 'cfg2_181c3_1mm', (181, 217, 181), seed=1, rhs=False)
+    _check(dev, 'cfg1_181c1_denoise', (181, 217, 181), seed=1, rhs=False)
