@@ -18,6 +18,7 @@
 #include "fftpre.hpp"
 #include "fused.hpp"
 #include "ops.hpp"
+#include "pull2.hpp"
 #include "splat2.hpp"
 
 using namespace unires;
@@ -272,6 +273,7 @@ struct Repeat {
   float *ctab_dev[2] = {nullptr, nullptr};
   int ctab_n = 0, ctab_cap = 0;
   unsigned ctab_step = 1, src_stride = 1;
+  PullPlan pplan;  // LDS-window pull: per-workgroup geometry of this operator (pull2.hip)
 };
 
 struct unires_plan {
@@ -316,6 +318,7 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
   if (!(in->tau > 0.f)) return fail(UNIRES_ERR_ARG, "tau must be positive");
   memset(&out, 0, sizeof(out));
   out.sched = SplatSched();
+  out.pplan = PullPlan();
   out.ctab_step = 1;
   out.tau = in->tau;
   out.scl = in->scl;
@@ -426,12 +429,20 @@ static int build_sched(unires_plan *pl, Repeat &R) {
     R.ctab_cap = std::max(R.ctab_cap, gn);
   }
   (void)splat2_build(R.sched, R.Af, R.Afinv, R.dim_gf, pl->dy, pl->fov_tol, R.safe, axis, rows_y);
+  // the pull of the same operator (denoising: plain pull onto the grid; super-resolution: + conv_down)
+  if (pl->regime == UNIRES_REGIME_DENOISE)
+    (void)pull2_build(R.pplan, pl->dy, R.A, R.T, R.dim_g, R.dim_g);
+  else if (!R.sep)
+    (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tf, R.dim_x, R.dim_gf);
+  else
+    R.pplan.valid = false;
   (void)hipGetLastError();
   return UNIRES_OK;
 }
 
 static void free_sched(Repeat &R) {
   splat2_free(R.sched);
+  pull2_free(R.pplan);
   for (int v = 0; v < 2; ++v)
     if (R.ctab_dev[v]) (void)hipFree(R.ctab_dev[v]), R.ctab_dev[v] = nullptr;
   R.ctab_n = R.ctab_cap = 0;
@@ -551,6 +562,7 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   tmp.ztab_dev[1] = plan->reps[n].ztab_dev[1];
   // the schedule and conv tables keep their device allocations; contents are rebuilt below
   tmp.sched = plan->reps[n].sched;
+  tmp.pplan = plan->reps[n].pplan;
   tmp.ctab_dev[0] = plan->reps[n].ctab_dev[0];
   tmp.ctab_dev[1] = plan->reps[n].ctab_dev[1];
   tmp.ctab_cap = plan->reps[n].ctab_cap;
@@ -583,7 +595,9 @@ static PushSrc push_src(const Repeat &R, const float *data, bool convup, float s
 static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, const int *done,
                            hipStream_t st) {
   if (pl->regime == UNIRES_REGIME_DENOISE) {
-    launch_pull(in, pl->dy, R.A, pl->gbuf, R.dim_g, pl->fov_tol, done, st);
+    if (launch_pull_conv2(R.pplan, in, pl->dy, R.A, R.T, Scaling{1.f, 1.f, -1}, pl->gbuf, R.dim_g, R.dim_g,
+                          pl->fov_tol, done, st))
+      launch_pull(in, pl->dy, R.A, pl->gbuf, R.dim_g, pl->fov_tol, done, st);
     return push_src(R, pl->gbuf, false, 0.f);
   }
   // S(2 scl) once between conv and conv^T  (unires/_project.py:175-177)
@@ -593,7 +607,8 @@ static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, co
     launch_conv_down_sep(pl->gbuf, R.dim_gf, R.Tf, S2, pl->xbuf, R.dim_x, pl->gbuf, pl->gbuf2, done, st);
     return push_src(R, pl->xbuf, true, 0.f);
   }
-  if (launch_pull_conv(in, pl->dy, R.Af, R.Tf, S2, pl->xbuf, R.dim_x, R.dim_gf, pl->fov_tol, done,
+  if (launch_pull_conv2(R.pplan, in, pl->dy, R.Af, R.Tf, S2, pl->xbuf, R.dim_x, R.dim_gf, pl->fov_tol, done, st) &&
+      launch_pull_conv(in, pl->dy, R.Af, R.Tf, S2, pl->xbuf, R.dim_x, R.dim_gf, pl->fov_tol, done,
                        st)) {
     launch_pull(in, pl->dy, R.A, pl->gbuf, R.dim_g, pl->fov_tol, done, st);
     launch_conv_down(pl->gbuf, R.dim_g, R.T, S2, pl->xbuf, R.dim_x, done, st);
@@ -691,13 +706,17 @@ extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, con
   }
   if (op == UNIRES_OP_A) {
     if (plan->regime == UNIRES_REGIME_DENOISE) {
-      launch_pull(in, plan->dy, R.A, out, R.dim_g, plan->fov_tol, nullptr, st);
+      if (launch_pull_conv2(R.pplan, in, plan->dy, R.A, R.T, Scaling{1.f, 1.f, -1}, out, R.dim_g, R.dim_g,
+                            plan->fov_tol, nullptr, st))
+        launch_pull(in, plan->dy, R.A, out, R.dim_g, plan->fov_tol, nullptr, st);
     } else {
       if (R.sep && plan->gbuf2) {
         launch_pull(in, plan->dy, R.Af, plan->gbuf, R.dim_gf, plan->fov_tol, nullptr, st);
         launch_conv_down_sep(plan->gbuf, R.dim_gf, R.Tf, make_scaling(R.scl, R.dim_thick), out,
                              R.dim_x, plan->gbuf, plan->gbuf2, nullptr, st);
-      } else if (launch_pull_conv(in, plan->dy, R.Af, R.Tf, make_scaling(R.scl, R.dim_thick), out,
+      } else if (launch_pull_conv2(R.pplan, in, plan->dy, R.Af, R.Tf, make_scaling(R.scl, R.dim_thick), out,
+                                   R.dim_x, R.dim_gf, plan->fov_tol, nullptr, st) &&
+                 launch_pull_conv(in, plan->dy, R.Af, R.Tf, make_scaling(R.scl, R.dim_thick), out,
                                   R.dim_x, R.dim_gf, plan->fov_tol, nullptr, st)) {
         launch_pull(in, plan->dy, R.A, plan->gbuf, R.dim_g, plan->fov_tol, nullptr, st);
         launch_conv_down(plan->gbuf, R.dim_g, R.T, make_scaling(R.scl, R.dim_thick), out, R.dim_x,

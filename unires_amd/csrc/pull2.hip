@@ -1,0 +1,363 @@
+// pull2.hip - k_pull_conv2: xs = S . conv_down_z . pull_M (p) with the trilinear gather served
+// from LDS instead of the texture addresser.
+//
+// What the hardware charges (tools/mb_pull.hip, MI355X): a wave-level global gather costs the
+// texture addresser ~16 clocks however well its 64 addresses coalesce, so the 4 corner-pair loads
+// of a trilinear sample bound a 256^3 pull at ~50 us; the same 8 values read from LDS cost the
+// CU ~18 clocks per 64 samples.  So a workgroup stages the part of p its grid rows can touch with
+// coalesced 16-byte loads and samples from LDS.
+//
+//   workgroup = TI x TJ grid rows x one 64-lane chunk of grid z (lanes along grid z)
+//   window    = for every group of 4 z planes of p, a W x H patch of (x, y) columns whose origin
+//               follows the rows as they drift (a SHEARED box: an axis-aligned bounding box of
+//               rows tilted by 0.1 rad would be 3-4x larger).  Origins come from the closed-form
+//               extremes of  x = px_i i + px_j j + s_x gz + c_x  over the workgroup's rows and the
+//               group's planes.  They depend only on the operator, so a one-off kernel tabulates
+//               them per workgroup (PullPlan, built with the plan) and the hot kernel starts with
+//               three scalar loads instead of a page of uniform float arithmetic.
+//   staging   = buffer_load_dwordx4 ... lds (LDS-DMA): the window is laid out so that item n of
+//               the load order is 16 bytes n of the LDS window - no VGPR round trip, no ds_write.
+//   conv_down = the slice profile runs on the pulled values of 8 rows at a time through a small
+//               padded LDS scratch; chunks are cut at multiples of the stride so every x-space
+//               voxel is produced by exactly one workgroup.
+// The coordinate arithmetic is affine_row / affine_along, bit for bit the splat's, so the pair
+// stays an exact adjoint.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "pull2.hpp"
+
+namespace unires {
+
+constexpr int kP2SZ = 72, kP2SZ4 = kP2SZ / 4;  // z planes of a window (64 + drift + 2 + alignment)
+constexpr int kP2Items = 8;                     // 16-byte window pieces staged per thread (at most)
+constexpr int kP2TI = 8, kP2TJ = 8;             // grid rows per workgroup
+
+struct P2Geom {
+  Affine A;
+  Dim3i sd, gd;
+  int sk, m;         // stride along grid z, conv windows (x-space voxels) per chunk
+  int nbj, nbc;      // workgroups along j and chunks along z (block = (bi * nbj + bj) * nbc + bc)
+  // sheared-plane form of the affine: x = pxi i + pxj j + sx gz + cx  (same for y)
+  float pxi, pxj, sx, cx, pyi, pyj, sy, cy;
+};
+
+// per-workgroup record: {Z0, plane groups in use, all-inside flag, -} then the 18 window origins
+constexpr int kP2Rec = 4 + 2 * kP2SZ4;
+
+__global__ void k_pull2_plan(P2Geom G, int nblk, int *__restrict__ rec) {
+  const int blk = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blk >= nblk) return;
+  constexpr int TI = kP2TI, TJ = kP2TJ, SZ4 = kP2SZ4;
+  const int bc = blk % G.nbc, bj = (blk / G.nbc) % G.nbj, bi = blk / (G.nbc * G.nbj);
+  const int i0 = bi * TI, j0 = bj * TJ;
+  const int i1 = min(i0 + TI, G.gd.x) - 1, j1 = min(j0 + TJ, G.gd.y) - 1;
+  const int k0 = bc * G.m * G.sk;
+  const int npts = min(kWave, G.gd.z - k0);
+  // z extent of the workgroup's samples: 8 vertices of the (i, j, k) box
+  float zmin = 1e30f, zmax = -1e30f;
+  bool inside = true;  // every sample has all 8 corners inside the volume (no FOV mask needed)
+  for (int c = 0; c < 8; ++c) {
+    float gx, gy, gz;
+    affine_point(G.A, (float)((c & 4) ? i1 : i0), (float)((c & 2) ? j1 : j0),
+                 (float)((c & 1) ? k0 + npts - 1 : k0), gx, gy, gz);
+    zmin = fminf(zmin, gz), zmax = fmaxf(zmax, gz);
+    inside = inside && gx >= 0.01f && gx <= (float)(G.sd.x - 1) - 0.01f && gy >= 0.01f &&
+             gy <= (float)(G.sd.y - 1) - 0.01f && gz >= 0.01f && gz <= (float)(G.sd.z - 1) - 0.01f;
+  }
+  const int Z0 = 4 * (int)floorf(floorf(zmin - 0.01f) * 0.25f);
+  const int ngrp = min(SZ4, ((int)floorf(zmax + 0.01f) + 1 - Z0) / 4 + 1);
+  int *r = rec + (size_t)blk * kP2Rec;
+  r[0] = Z0, r[1] = ngrp, r[2] = inside ? 1 : 0, r[3] = 0;
+  const float fi0 = (float)i0, fi1 = (float)i1, fj0 = (float)j0, fj1 = (float)j1;
+  for (int g = 0; g < SZ4; ++g) {
+    // samples whose lower or upper corner plane falls in this group: gz in [Zg - 1, Zg + 4)
+    const float za = (float)(Z0 + 4 * g - 1), zb = (float)(Z0 + 4 * g + 4);
+    const float xlo = G.cx + fminf(G.pxi * fi0, G.pxi * fi1) + fminf(G.pxj * fj0, G.pxj * fj1) +
+                      fminf(G.sx * za, G.sx * zb);
+    const float ylo = G.cy + fminf(G.pyi * fi0, G.pyi * fi1) + fminf(G.pyj * fj0, G.pyj * fj1) +
+                      fminf(G.sy * za, G.sy * zb);
+    r[4 + 2 * g] = (int)floorf(xlo - 0.02f);
+    r[5 + 2 * g] = (int)floorf(ylo - 0.02f);
+  }
+}
+
+struct P2Args {
+  const float *src;
+  const int *rec;
+  P2Geom G;
+  float kz[UNIRES_MAX_TAPS];
+  int nk;            // taps along grid z (1 with sk 1: no conv)
+  float se, so;      // even / odd x-space slice scaling along z (1, 1: none)
+  float *dst;
+  Dim3i xd;
+  float tol;
+  int W;             // window extent along x (cells); along y it is the template parameter H
+  int dbg;           // UNIRES_P2_DBG ablation bits (measurement only): 1 no staging, 2 no sampling, 4 no conv / store
+};
+
+// NK, SK > 0: compile-time slice profile (7 taps stride 6 is the 6 mm / 1 mm case); 0: run-time
+template <int H, int NK, int SK>
+__global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__restrict__ done) {
+  if (done && *done) return;
+  constexpr int SZ = kP2SZ, SZ4 = kP2SZ4, NW = kBlock / kWave, TI = kP2TI, TJ = kP2TJ;
+  constexpr int ROWS = TI * TJ, RPW = ROWS / NW, HALF = 8, SCR = kWave + 1;
+  static_assert(ROWS % NW == 0 && RPW % HALF == 0, "rows per wave");
+  extern __shared__ __align__(16) float win[];  // W * H columns x SZ planes
+  __shared__ int tab[SZ4 + 2];                  // per plane group: -(ox * H + oy) * SZ, in floats
+  __shared__ int2 org[SZ4];
+  __shared__ float scr[NW][HALF][SCR];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const P2Geom &G = P.G;
+  // (each XCD walks one contiguous run of workgroups: neighbours share window columns in its L2)
+  const int blk = xcd_chunked_block((int)blockIdx.x, (int)gridDim.x);
+  const int bc = blk % G.nbc, bj = (blk / G.nbc) % G.nbj, bi = blk / (G.nbc * G.nbj);
+  const int i0 = bi * TI, j0 = bj * TJ;
+  const int kk0 = bc * G.m, k0 = kk0 * G.sk;
+  const int npts = min(kWave, G.gd.z - k0);  // grid points of this chunk along z
+  const Dim3i sd = G.sd;
+  const int *rec = P.rec + (size_t)blk * kP2Rec;
+  const int Z0 = rec[0], ngrp = rec[1];
+  const bool inside = rec[2] != 0;
+  if (tid < SZ4) {
+    const int ox = rec[4 + 2 * tid], oy = rec[5 + 2 * tid];
+    org[tid] = make_int2(ox, oy);
+    tab[tid] = -(ox * H + oy) * SZ;
+  }
+  __syncthreads();
+  // ---- stage the window: one 16-byte piece (4 planes of one column) per item; item n of the
+  // load order lands on bytes 16 n of the window.  Pieces outside the volume come from an
+  // out-of-range buffer offset (zeros, no branch). ----
+  if (!(P.dbg & 1)) {
+    const int nitem = P.W * H * SZ4;
+    const bool zsafe = Z0 >= 0 && Z0 + 4 * ngrp <= sd.z;  // every piece inside the volume along z
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(P.src, sd.numel() * sizeof(float));
+    constexpr unsigned kOob = 0xfffffff0u;
+    if (zsafe) {
+#pragma unroll
+      for (int n = 0; n < kP2Items; ++n) {
+        const int base = n * kBlock + wave * kWave;  // wave-uniform: LDS-DMA writes base + lane
+        if (base >= nitem) break;
+        const int it = base + lane;
+        const int zg = it % SZ4, slot = it / SZ4;  // (compile-time divisors)
+        const int cxl = slot / H, cyl = slot - cxl * H;
+        const int2 o = org[zg];
+        const int x = o.x + cxl, y = o.y + cyl, z = Z0 + 4 * zg;
+        const bool ok = zg < ngrp && x >= 0 && x < sd.x && y >= 0 && y < sd.y;
+        const unsigned off = 4u * (unsigned)((x * sd.y + y) * sd.z + z);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rs, (__attribute__((address_space(3))) void *)(win + 4 * base), 16, ok ? off : kOob, 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      for (int it = tid; it < nitem; it += kBlock) {
+        const int zg = it % SZ4, slot = it / SZ4;
+        const int cxl = slot / H, cyl = slot - cxl * H;
+        const int2 o = org[zg];
+        const int x = o.x + cxl, y = o.y + cyl, z = Z0 + 4 * zg;
+        const bool ok = zg < ngrp && x >= 0 && x < sd.x && y >= 0 && y < sd.y;
+        const unsigned off = 4u * (unsigned)((x * sd.y + y) * sd.z + z);
+        float4 v;
+        v.x = buf_load(rs, ok && z >= 0 && z < sd.z ? off : kOob, 0);
+        v.y = buf_load(rs, ok && z + 1 >= 0 && z + 1 < sd.z ? off + 4u : kOob, 0);
+        v.z = buf_load(rs, ok && z + 2 >= 0 && z + 2 < sd.z ? off + 8u : kOob, 0);
+        v.w = buf_load(rs, ok && z + 3 >= 0 && z + 3 < sd.z ? off + 12u : kOob, 0);
+        *reinterpret_cast<float4 *>(win + 4 * it) = v;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- pull: one grid row per wave pass, lanes along grid z; conv_down every 8 rows ----
+  const float kf = (float)(k0 + min(lane, npts - 1));
+  const float c0 = G.A.m[2], c1 = G.A.m[6], c2 = G.A.m[10];
+  const float t0 = G.A.m[3], t1 = G.A.m[7], t2 = G.A.m[11];
+  const float bx = (float)(sd.x - 1), by = (float)(sd.y - 1), bz = (float)(sd.z - 1);
+  const float fZ0 = (float)Z0;
+  const int xdy = P.xd.y, xdz = P.xd.z;
+  const int nk = NK > 0 ? NK : P.nk, sk = SK > 0 ? SK : G.sk;
+  const bool plain = nk == 1 && sk == 1;
+  const int nout = min(G.m, xdz - kk0);
+  const float inv_m = 1.f / (float)G.m;
+#pragma unroll 1
+  for (int h0 = 0; h0 < RPW; h0 += HALF) {
+    float hv[HALF];
+#pragma unroll
+    for (int r = 0; r < HALF; ++r) {
+      const int row = wave * RPW + h0 + r;
+      const int i = min(i0 + row / TJ, G.gd.x - 1), j = min(j0 + row % TJ, G.gd.y - 1);
+      const RowBase rb = affine_row(G.A, (float)i, (float)j);
+      const float gx = fmaf(c0, kf, rb.x) + t0, gy = fmaf(c1, kf, rb.y) + t1, gz = fmaf(c2, kf, rb.z) + t2;
+      const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+      const float wx = gx - fx, wy = gy - fy, wz = gz - fz;
+      const int zl = (int)(fz - fZ0);
+      const int xy = (int)fmaf(fx, (float)(H * SZ), fy * (float)SZ);
+      const int a0 = xy + zl + tab[zl >> 2], a1 = xy + zl + 1 + tab[(zl + 1) >> 2];
+      float v = 0.f;
+      if (!(P.dbg & 2)) {
+        const float p000 = win[a0], p010 = win[a0 + SZ], p100 = win[a0 + H * SZ], p110 = win[a0 + (H + 1) * SZ];
+        const float p001 = win[a1], p011 = win[a1 + SZ], p101 = win[a1 + H * SZ], p111 = win[a1 + (H + 1) * SZ];
+        const float q00 = fmaf(wz, p001 - p000, p000), q01 = fmaf(wz, p011 - p010, p010);
+        const float q10 = fmaf(wz, p101 - p100, p100), q11 = fmaf(wz, p111 - p110, p110);
+        const float q0 = fmaf(wy, q01 - q00, q00), q1 = fmaf(wy, q11 - q10, q10);
+        v = fmaf(wx, q1 - q0, q0);
+      }
+      if (!inside) {  // zero bound comes from the zero-filled window; the in-FOV mask is explicit
+        const bool in = gx > -P.tol && gx < bx + P.tol && gy > -P.tol && gy < by + P.tol && gz > -P.tol &&
+                        gz < bz + P.tol;
+        v = in ? v : 0.f;
+      }
+      hv[r] = lane < npts ? v : 0.f;
+    }
+    if (P.dbg & 4) {
+      if (hv[0] + hv[HALF - 1] == 123.f) P.dst[0] = 1.f;
+      continue;
+    }
+    if (plain) {  // no slice profile: the pulled rows are the output
+#pragma unroll
+      for (int r = 0; r < HALF; ++r) {
+        const int row = wave * RPW + h0 + r;
+        const int i = i0 + row / TJ, j = j0 + row % TJ;
+        if (i < G.gd.x && j < G.gd.y && lane < npts)
+          P.dst[((size_t)i * xdy + j) * xdz + k0 + lane] = hv[r] * P.se;
+      }
+      continue;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private scratch: no barrier needed
+#pragma unroll
+    for (int r = 0; r < HALF; ++r) scr[wave][r][lane] = hv[r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int it = lane; it < HALF * G.m; it += kWave) {
+      const int r = (int)(((float)it + 0.5f) * inv_m), win_i = it - r * G.m;  // exact: it < 2^20
+      const int row = wave * RPW + h0 + r;
+      const int i = i0 + row / TJ, j = j0 + row % TJ;
+      const float *h = &scr[wave][r][win_i * sk];
+      float acc = 0.f;
+      if (NK > 0) {
+#pragma unroll
+        for (int t = 0; t < NK; ++t) acc += h[t] * P.kz[t];
+      } else {
+        for (int t = 0; t < nk; ++t) acc += h[t] * P.kz[t];
+      }
+      const int kk = kk0 + win_i;
+      acc *= (kk & 1) ? P.so : P.se;
+      if (win_i < nout && i < G.gd.x && j < G.gd.y) P.dst[((size_t)i * xdy + j) * xdz + kk] = acc;
+    }
+  }
+}
+
+static bool same_geom(const P2Geom &a, const P2Geom &b) { return memcmp(&a, &b, sizeof(P2Geom)) == 0; }
+
+void pull2_free(PullPlan &Q) {
+  if (Q.rec) (void)hipFree(Q.rec);
+  Q = PullPlan();
+}
+
+// Geometry of the operator for this kernel; false: outside its domain.
+static bool p2_geometry(Dim3i sd, const Affine &A, const Taps &T, const Scaling &S, Dim3i xd, Dim3i gd,
+                        P2Geom &G, int &W, int &H) {
+  // conv only along z (or none at all), scaling only along z
+  for (int d = 0; d < 2; ++d)
+    if (!(T.n[d] == 1 && T.s[d] == 1 && T.t[d][0] == 1.f)) return false;
+  if (S.dim >= 0 && S.dim != 2) return false;
+  if (T.n[2] > 32 || T.n[2] > kWave - 8 || T.s[2] > T.n[2]) return false;
+  if (gd.x != xd.x || gd.y != xd.y || gd.z != (xd.z - 1) * T.s[2] + T.n[2]) return false;
+  if (sd.numel() >= (1ull << 30) || !fits_fast_index(sd)) return false;
+  const double a22 = A.m[10];
+  if (!(fabs(a22) > 0.5)) return false;
+  constexpr int TI = kP2TI, TJ = kP2TJ;
+  memset(&G, 0, sizeof(G));
+  G.A = A, G.sd = sd, G.gd = gd;
+  const double sxd = A.m[2] / a22, syd = A.m[6] / a22;
+  G.pxi = (float)(A.m[0] - sxd * A.m[8]), G.pxj = (float)(A.m[1] - sxd * A.m[9]);
+  G.pyi = (float)(A.m[4] - syd * A.m[8]), G.pyj = (float)(A.m[5] - syd * A.m[9]);
+  G.sx = (float)sxd, G.sy = (float)syd;
+  G.cx = (float)(A.m[3] - sxd * A.m[11]), G.cy = (float)(A.m[7] - syd * A.m[11]);
+  // window extents: span of the rows over a plane group (z in [Zg - 1, Zg + 4)), + floor, + the
+  // upper corner, + rounding margin
+  const double ex = (TI - 1) * fabs(G.pxi) + (TJ - 1) * fabs(G.pxj) + 5.0 * fabs(sxd) + 0.05;
+  const double ey = (TI - 1) * fabs(G.pyi) + (TJ - 1) * fabs(G.pyj) + 5.0 * fabs(syd) + 0.05;
+  W = (int)floor(ex) + 3;
+  const int Hn = (int)floor(ey) + 3;
+  // z planes: span of gz over the workgroup + floor + upper corner + alignment of Z0 to 4
+  const double ez = (TI - 1) * fabs((double)A.m[8]) + (TJ - 1) * fabs((double)A.m[9]) + 63.0 * fabs(a22) + 0.05;
+  if ((int)floor(ez) + 2 + 3 + 1 > kP2SZ) return false;
+  if (W > 24 || Hn > 16) return false;
+  H = Hn <= 10 ? 10 : (Hn <= 12 ? 12 : 16);
+  if (W * H * kP2SZ4 > kP2Items * kBlock) return false;
+  if ((size_t)W * H * kP2SZ * sizeof(float) > 56 * 1024) return false;
+  G.sk = T.s[2];
+  G.m = (kWave - T.n[2]) / T.s[2] + 1;  // whole conv windows inside 64 grid points
+  G.nbj = (gd.y + TJ - 1) / TJ;
+  G.nbc = (xd.z + G.m - 1) / G.m;
+  return true;
+}
+
+static long long p2_blocks(const P2Geom &G) {
+  return (long long)((G.gd.x + kP2TI - 1) / kP2TI) * G.nbj * G.nbc;
+}
+
+int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd, Dim3i gd) {
+  Q.valid = false;
+  static const bool off = getenv("UNIRES_NO_PULL2") != nullptr;
+  if (off) return 1;
+  P2Geom G;
+  int W, H;
+  if (!p2_geometry(sd, A, T, Scaling{1.f, 1.f, -1}, xd, gd, G, W, H)) return 1;
+  const long long nblk = p2_blocks(G);
+  if (nblk > 0x3fffffffll) return 1;
+  if ((size_t)nblk > Q.cap) {
+    if (Q.rec) (void)hipFree(Q.rec);
+    Q.rec = nullptr;
+    if (hipMalloc((void **)&Q.rec, (size_t)nblk * kP2Rec * sizeof(int)) != hipSuccess) return 1;
+    Q.cap = (size_t)nblk;
+  }
+  hipLaunchKernelGGL(k_pull2_plan, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, G, (int)nblk, Q.rec);
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  static_assert(sizeof(P2Geom) <= sizeof(Q.key), "PullPlan key too small");
+  memset(Q.key, 0, sizeof(Q.key));
+  memcpy(Q.key, &G, sizeof(G));
+  Q.valid = true;
+  return 0;
+}
+
+// Non-zero return: operator outside this kernel's domain / no plan for it (nothing launched).
+int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affine &A, const Taps &T,
+                      const Scaling &S, float *dst, Dim3i xd, Dim3i gd, float tol, const int *done,
+                      hipStream_t st) {
+  if (!Q.valid) return 1;
+  P2Args P;
+  int W, H;
+  if (!p2_geometry(sd, A, T, S, xd, gd, P.G, W, H)) return 1;
+  P2Geom key;
+  memcpy(&key, Q.key, sizeof(key));
+  if (!same_geom(key, P.G)) return 1;  // the plan was built for another operator
+  P.src = src, P.rec = Q.rec;
+  for (int i = 0; i < UNIRES_MAX_TAPS; ++i) P.kz[i] = i < T.n[2] ? T.t[2][i] : 0.f;
+  P.nk = T.n[2];
+  P.se = S.dim == 2 ? S.e : 1.f, P.so = S.dim == 2 ? S.o : 1.f;
+  P.dst = dst, P.xd = xd, P.tol = tol, P.W = W;
+  static const int dbg = getenv("UNIRES_P2_DBG") ? atoi(getenv("UNIRES_P2_DBG")) : 0;
+  P.dbg = dbg;
+  const size_t lds = (size_t)W * H * kP2SZ * sizeof(float);
+  const dim3 grid((unsigned)p2_blocks(P.G)), block(kBlock);
+  const bool k76 = T.n[2] == 7 && T.s[2] == 6;
+#define P2_LAUNCH(HH)                                                                     \
+  do {                                                                                    \
+    if (k76)                                                                              \
+      hipLaunchKernelGGL((k_pull_conv2<HH, 7, 6>), grid, block, lds, st, P, done);        \
+    else                                                                                  \
+      hipLaunchKernelGGL((k_pull_conv2<HH, 0, 0>), grid, block, lds, st, P, done);        \
+  } while (0)
+  if (H == 10)
+    P2_LAUNCH(10);
+  else if (H == 12)
+    P2_LAUNCH(12);
+  else
+    P2_LAUNCH(16);
+#undef P2_LAUNCH
+  return 0;
+}
+
+}  // namespace unires
