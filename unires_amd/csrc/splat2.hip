@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -71,6 +72,14 @@ static int s2_ntiles(Dim3i dd) {
   return ((dd.x + T::TX - 1) / T::TX) * ((dd.y + T::TY - 1) / T::TY) * ((dd.z + T::TZ - 1) / T::TZ);
 }
 
+static int s2_grid(Dim3i dd) {
+  const int nt = s2_ntiles(dd);
+  static const int cap = getenv("UNIRES_SPLAT2_BLOCKS") ? atoi(getenv("UNIRES_SPLAT2_BLOCKS")) : 1024;
+  const int want = (nt + kS2Waves - 1) / kS2Waves;
+  return want < cap ? want : cap;
+}
+
+
 // --------------------------------------------------------------------------
 // schedule build
 // --------------------------------------------------------------------------
@@ -97,7 +106,7 @@ __device__ __forceinline__ unsigned s2_rowcode(const S2BuildArgs &B, int ui, int
 template <bool FILL>
 __global__ void __launch_bounds__(kWave)
     k_splat2_build(S2BuildArgs B, uint2 *__restrict__ counts, S2Entry *__restrict__ entries,
-                   unsigned long long *__restrict__ masks, int *__restrict__ err,
+                   ulonglong2 *__restrict__ masks, int *__restrict__ err,
                    unsigned long long *__restrict__ stats) {
   using T = S2Tile;
   constexpr int L = T::L, kSegs = 384;
@@ -205,31 +214,72 @@ __global__ void __launch_bounds__(kWave)
   }
   S2_FENCE();
   __syncthreads();
-  // first-fit packing: lane b is instruction b of the tile.  A segment joins the first instruction
-  // with enough free lanes, fewer than kS2MaxSeg members and no member it could collide with.
-  int used = 0, nmem = 0, nbins = 0;
-  for (int s = 0; s < nseg; ++s) {
+  // ---- packing into 64-lane instructions: lane b is instruction b of the tile ----
+  // ALIGNED mode (every segment walks one z plane per point, i.e. |dz/dk| <= 1): within each
+  // 32-lane half, lane position = z plane (31 - plane when z decreases along the row).  The
+  // accumulator's x / y strides are multiples of 32 words, so the LDS bank of an update is its z
+  // plane: lanes of one half then never collide on a bank, whatever rows they come from.
+  // Otherwise segments are simply laid end to end.  Either way a segment joins the first
+  // instruction that has room, fewer than kS2MaxSeg members and no member it could collide with
+  // (rows closer than row_sep whose plane ranges touch).
+  __shared__ unsigned short order[kSegs];
+  bool al = true;
+  for (int s0 = 0; s0 < nseg; s0 += kWave) {
+    const int s = s0 + lane;
+    if (s < nseg) al = al && ((int)segs[s].lzmax - (int)segs[s].lzmin + 1 == (int)segs[s].len);
+  }
+  const bool aligned = __all(al) && T::SZ == 32;
+  const bool zdown = c2 < 0.f;
+  auto seg_pos = [&](const S2Seg q) { return aligned ? (zdown ? 31 - (int)q.lzmax : (int)q.lzmin) : 0; };
+  // stable counting sort by first lane position (one lane: deterministic schedule)
+  if (lane == 0) {
+    int cnt[33];
+    for (int i = 0; i < 33; ++i) cnt[i] = 0;
+    for (int s = 0; s < nseg; ++s) ++cnt[seg_pos(segs[s]) + 1];
+    for (int i = 0; i < 32; ++i) cnt[i + 1] += cnt[i];
+    for (int s = 0; s < nseg; ++s) order[cnt[seg_pos(segs[s])]++] = (unsigned short)s;
+  }
+  S2_FENCE();
+  __syncthreads();
+  unsigned occ0 = 0u, occ1 = 0u;  // aligned: occupied lanes of each half; else: lanes used so far in occ0
+  int nmem = 0, nbins = 0;
+  for (int si = 0; si < nseg; ++si) {
+    const int s = order[si];
     const S2Seg q = segs[s];
-    bool ok = lane <= nbins && used + q.len <= kWave && nmem < kS2MaxSeg;
+    const int a = seg_pos(q);
+    const unsigned pm = (q.len >= 32 ? 0xffffffffu : ((1u << q.len) - 1u)) << a;
+    bool free = true;
     for (int j = 0; j < nmem; ++j) {
-      const S2Seg m = segs[member[lane][j]];
+      const S2Seg m = segs[member[lane][j] & 0x7fff];
       const bool rows_close = max(abs(m.ui - q.ui), abs(m.uj - q.uj)) < B.row_sep;
       const bool planes_touch = (int)m.lzmin <= (int)q.lzmax + 1 && (int)q.lzmin <= (int)m.lzmax + 1;
-      ok = ok && !(rows_close && planes_touch);
+      free = free && !(rows_close && planes_touch);
     }
-    const unsigned long long m = __ballot(ok);
+    free = free && lane <= nbins && nmem < kS2MaxSeg;
+    bool ok0, ok1;
+    if (aligned) {
+      ok0 = free && (occ0 & pm) == 0u, ok1 = free && (occ1 & pm) == 0u;
+    } else {
+      ok0 = free && (int)occ0 + q.len <= kWave, ok1 = false;
+    }
+    const unsigned long long m = __ballot(ok0 || ok1);
     if (m == 0ull) {  // more than 64 instructions in one tile
       if (lane == 0) atomicExch(err, 1);
       break;
     }
     const int chosen = __ffsll((long long)m) - 1;
     if (lane == chosen) {
-      member[lane][nmem++] = (unsigned short)s;
-      used += q.len;
+      const int half = ok0 ? 0 : 1;
+      member[lane][nmem++] = (unsigned short)(s | (half << 15));
+      if (aligned) {
+        if (half == 0) occ0 |= pm; else occ1 |= pm;
+      } else {
+        occ0 += q.len;
+      }
     }
     nbins = max(nbins, chosen + 1);
   }
-  const int nent = lane < nbins ? nmem + (used < kWave ? 1 : 0) : 0;
+  const int nent = lane < nbins ? nmem : 0;
   // inclusive prefix sum of nent over lanes
   int incl = nent;
 #pragma unroll
@@ -246,24 +296,35 @@ __global__ void __launch_bounds__(kWave)
   unsigned long long pts = 0;
   if (lane < nbins) {
     S2Entry *out = entries + base.x + (incl - nent);
-    unsigned long long mask = 0ull;
-    int start = 0;
+    // members in lane order (aligned: by half, then position; else: as packed)
+    int start_of[kS2MaxSeg];
+    int run = 0;
     for (int j = 0; j < nmem; ++j) {
-      const S2Seg q = segs[member[lane][j]];
+      const S2Seg q = segs[member[lane][j] & 0x7fff];
+      start_of[j] = aligned ? 32 * (member[lane][j] >> 15) + seg_pos(q) : run;
+      run += q.len;
+    }
+    for (int i = 1; i < nmem; ++i)  // insertion sort of (start, member) pairs
+      for (int j = i; j > 0 && start_of[j] < start_of[j - 1]; --j) {
+        const int ts = start_of[j];
+        start_of[j] = start_of[j - 1], start_of[j - 1] = ts;
+        const unsigned short tm = member[lane][j];
+        member[lane][j] = member[lane][j - 1], member[lane][j - 1] = tm;
+      }
+    unsigned long long starts = 0ull, active = 0ull;
+    for (int j = 0; j < nmem; ++j) {
+      const S2Seg q = segs[member[lane][j] & 0x7fff];
+      const int start = start_of[j];
       const RowBase rb = affine_row(B.A, (float)q.ui, (float)q.uj);
       S2Entry e;
       e.rx = rb.x, e.ry = rb.y, e.rz = rb.z;
       e.pk = s2_rowcode(B, q.ui, q.uj) | ((unsigned)(q.k0 - start + 64) << kS2RowBits);
       out[j] = e;
-      if (start > 0) mask |= 1ull << (start - 1);
-      start += q.len;
+      if (j > 0) starts |= 1ull << (start - 1);  // lanes >= start count it: slot = popcount below lane
+      active |= (q.len >= 64 ? ~0ull : ((1ull << q.len) - 1ull)) << start;
       pts += q.len;
     }
-    if (used < kWave) {
-      out[nmem] = S2Entry{0.f, 0.f, 0.f, kS2RowIdle | (64u << kS2RowBits)};
-      if (used > 0) mask |= 1ull << (used - 1);
-    }
-    masks[base.y + lane] = mask;
+    masks[base.y + lane] = make_ulonglong2(starts, active);
   }
   if (stats) {
 #pragma unroll
@@ -313,7 +374,7 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
   B.A = A, B.Ainv = Ainv, B.gd = gd, B.dd = dd, B.tol = tol, B.row_sep = safe.row_sep;
   B.axis = axis, B.rows_y = rows_y;
   hipLaunchKernelGGL(k_splat2_build<false>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off,
-                     (S2Entry *)nullptr, (unsigned long long *)nullptr, err_dev,
+                     (S2Entry *)nullptr, (ulonglong2 *)nullptr, err_dev,
                      (unsigned long long *)nullptr);
   std::vector<uint2> h((size_t)nt + 1);
   if (hipMemcpy(h.data(), S.tile_off, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess)
@@ -337,13 +398,13 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
     if (S.masks) (void)hipFree(S.masks);
     S.masks = nullptr;
     const size_t cap = (size_t)ri + ri / 8 + 8;
-    if (hipMalloc((void **)&S.masks, cap * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (hipMalloc((void **)&S.masks, cap * sizeof(ulonglong2)) != hipSuccess) return 1;
     S.cap_instr = cap;
   }
   if (hipMemcpy(S.tile_off, h.data(), ((size_t)nt + 1) * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess)
     return 1;
   (void)hipMemset(S.entries + re, 0xff, kPad * sizeof(S2Entry));
-  (void)hipMemset(S.masks + ri, 0, 8 * sizeof(unsigned long long));
+  (void)hipMemset(S.masks + ri, 0, 8 * sizeof(ulonglong2));
   hipLaunchKernelGGL(k_splat2_build<true>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off, S.entries,
                      S.masks, err_dev, stats_dev);
   int herr = 0;
@@ -361,7 +422,7 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
   if (verbose)
     fprintf(stderr, "[splat2] %d tiles, %llu instructions, %u segments, %llu points (%.2f per output voxel), "
             "lane fill %.3f, schedule %.1f MB, row_sep %d\n", nt, hs[1], re, hs[0],
-            (double)hs[0] / (double)dd.numel(), S.fill, (re * sizeof(S2Entry) + ri * 8.0) / 1e6, safe.row_sep);
+            (double)hs[0] / (double)dd.numel(), S.fill, (re * sizeof(S2Entry) + ri * 16.0) / 1e6, safe.row_sep);
   return 0;
 }
 
@@ -399,7 +460,7 @@ struct S2Args {
   unsigned row_stride4;  // bytes per unit of the row code (see launch_splat2)
   unsigned tab_step4;    // bytes between the two x-space values of a grid voxel
   const S2Entry *entries;
-  const unsigned long long *masks;
+  const ulonglong2 *masks;  // per instruction: {segment starts, active lanes}
   const uint2 *tile_off;
   int ntiles;
   Affine A;
@@ -435,7 +496,7 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
     const unsigned step4 = AXIS == 2 ? 4u : P.tab_step4;
     for (int i = threadIdx.x; i < P.tabn; i += kWave * kS2Waves) {
       float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < P.gn) e = P.tab[i];
+      if (i >= 64 && i - 64 < P.gn) e = P.tab[i - 64];
       tabs[i] = make_float4(__int_as_float((int)(step4 * (unsigned)__float_as_int(e.x))), P.alpha * e.y,
                             P.alpha * e.z, 0.f);
     }
@@ -444,7 +505,9 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(P.src, P.src_bytes);
   const int ntiles = P.ntiles;
   // XCD-aware persistent schedule: workgroup b sits on XCD b % 8; each XCD walks one contiguous
-  // run of tiles so that neighbouring tiles (shared stencil halos, schedule lines) share an L2
+  // run of tiles so that neighbouring tiles (shared stencil halos, schedule lines) share an L2.
+  // (Tried and dropped: a contiguous, cost-balanced range of tiles per wave - 103 us instead of
+  // 95 us: waves that sweep the run together share cache lines, waves far apart do not.)
   const int nxcd = min(8, (int)gridDim.x);
   const int per_xcd = (ntiles + nxcd - 1) / nxcd;
   const int xcd = blockIdx.x % nxcd;
@@ -463,8 +526,9 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
     const int ninstr = (int)(off1.y - off0.y);
     const uint4 *E = reinterpret_cast<const uint4 *>(P.entries) + off0.x;
     // lane l keeps the segment-start mask of instruction l (a tile has at most 64 of them)
-    const unsigned long long mymask = lane < ninstr ? P.masks[off0.y + lane] : 0ull;
-    const int mlo_v = (int)(unsigned)mymask, mhi_v = (int)(unsigned)(mymask >> 32);
+    const ulonglong2 mymask = lane < ninstr ? P.masks[off0.y + lane] : make_ulonglong2(0ull, 0ull);
+    const int mlo_v = (int)(unsigned)mymask.x, mhi_v = (int)(unsigned)(mymask.x >> 32);
+    const int alo_v = (int)(unsigned)mymask.y, ahi_v = (int)(unsigned)(mymask.y >> 32);
     S2_FENCE();
     // segment ring: chunks 0 and 1 now, chunk 2 in flight in registers
     ring[lane] = E[lane];
@@ -477,7 +541,15 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
     int eb = 0;        // first entry of the next instruction, relative to the tile
     S2_FENCE();
     constexpr int kU = 4;
-    for (int p0 = S2_ABL(1) ? ninstr : 0; p0 < ninstr; p0 += kU) {
+    // A batch = kU instructions.  fetch(): segment-start masks -> mbcnt -> segment entry (LDS ring)
+    // -> conv_up table -> ONE source load per lane and instruction, all issued back to back;
+    // splat(): coordinates, weights and the two LDS update groups.  Two batches are in flight: the
+    // source loads of batch b + 1 travel while batch b is splatted.
+    struct Batch {
+      float w0[kU], w1[kU], s0[kU], s1[kU], kf[kU], rx[kU], ry[kU], rz[kU];
+      unsigned long long amask[kU];
+    };
+    auto fetch = [&](Batch &Bt, int p0) {
       unsigned mlo[kU], mhi[kU];
       int ebu[kU];
       int need = eb;
@@ -487,6 +559,9 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
         const int pi = min(p0 + u, ninstr - 1);
         mlo[u] = (unsigned)__builtin_amdgcn_readlane(mlo_v, pi);
         mhi[u] = (unsigned)__builtin_amdgcn_readlane(mhi_v, pi);
+        Bt.amask[u] = p0 + u < ninstr ? ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ahi_v, pi) << 32) |
+                                            (unsigned)__builtin_amdgcn_readlane(alo_v, pi)
+                                      : 0ull;
         ebu[u] = (p0 + u < ninstr || u == 0) ? need : ebu[u > 0 ? u - 1 : 0];
         if (p0 + u < ninstr) need += __popc(mlo[u]) + __popc(mhi[u]) + 1;
       }
@@ -498,41 +573,41 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
         S2_FENCE();
       }
       eb = need;
-      float val[kU], kf[kU], rx[kU], ry[kU], rz[kU];
-      bool act[kU];
-      // ---- decode + source values (conv_up regenerated on the fly from x-space) ----
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const int sl = (int)__builtin_amdgcn_mbcnt_hi(mhi[u], __builtin_amdgcn_mbcnt_lo(mlo[u], 0u));
         const uint4 e = ring[(ebu[u] + sl) & 63];
-        rx[u] = __uint_as_float(e.x), ry[u] = __uint_as_float(e.y), rz[u] = __uint_as_float(e.z);
+        Bt.rx[u] = __uint_as_float(e.x), Bt.ry[u] = __uint_as_float(e.y), Bt.rz[u] = __uint_as_float(e.z);
         const unsigned code = e.w & kS2RowIdle;
-        act[u] = code != kS2RowIdle && p0 + u < ninstr;
+        // (idle lanes in front of an instruction's first segment see k < its k0: the tables carry 64
+        // zero entries in front for them)
         const int k = (int)(e.w >> kS2RowBits) + lane_m64;
-        kf[u] = (float)k;
+        Bt.kf[u] = (float)k;
+        Bt.w0[u] = P.alpha, Bt.w1[u] = 0.f, Bt.s0[u] = 1.f, Bt.s1[u] = 0.f;
         if (S2_ABL(8)) {
-          val[u] = 1.f;
         } else if (AXIS == 2) {
-          const float4 tb = tabs[k];
+          const float4 tb = tabs[k + 64];
           const unsigned a = __umul24(code, P.row_stride4) + (unsigned)__float_as_int(tb.x);
           const uint2 pr = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a, 0, 0));
-          val[u] = tb.y * __uint_as_float(pr.x) + tb.z * __uint_as_float(pr.y);
+          Bt.w0[u] = tb.y, Bt.w1[u] = tb.z, Bt.s0[u] = __uint_as_float(pr.x), Bt.s1[u] = __uint_as_float(pr.y);
         } else if (AXIS == 0 || AXIS == 1) {
           const unsigned ui = code >> 9, uj = code & 511u;
-          const float4 tb = tabs[AXIS == 0 ? ui : uj];
+          const float4 tb = tabs[(AXIS == 0 ? ui : uj) + 64];
           const unsigned a = __umul24(AXIS == 0 ? uj : ui, P.row_stride4) + (unsigned)__float_as_int(tb.x) +
                              4u * (unsigned)k;
-          val[u] = tb.y * buf_load(rsrc, a, 0) + tb.z * buf_load(rsrc, a + P.tab_step4, 0);
+          Bt.w0[u] = tb.y, Bt.w1[u] = tb.z;
+          Bt.s0[u] = buf_load(rsrc, a, 0), Bt.s1[u] = buf_load(rsrc, a + P.tab_step4, 0);
         } else {
-          val[u] = P.alpha * buf_load(rsrc, __umul24(code, P.row_stride4) + 4u * (unsigned)k, 0);
+          Bt.s0[u] = buf_load(rsrc, __umul24(code, P.row_stride4) + 4u * (unsigned)k, 0);
         }
       }
-      // ---- the splat proper ----
+    };
+    auto splat = [&](const Batch &Bt) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        const float gx = fmaf(c0, kf[u], rx[u]) + t0;
-        const float gy = fmaf(c1, kf[u], ry[u]) + t1;
-        const float gz = fmaf(c2, kf[u], rz[u]) + t2;
+        const float gx = fmaf(c0, Bt.kf[u], Bt.rx[u]) + t0;
+        const float gy = fmaf(c1, Bt.kf[u], Bt.ry[u]) + t1;
+        const float gz = fmaf(c2, Bt.kf[u], Bt.rz[u]) + t2;
         // local coordinates: the subtraction of the (integer) tile base is exact
         const float lxf = gx - xb, lyf = gy - yb, lzf = gz - zb;
         const float wx1 = __builtin_amdgcn_fractf(lxf), wy1 = __builtin_amdgcn_fractf(lyf),
@@ -541,12 +616,12 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
         // cell index in float (exact: small integers), one conversion
         const float cf = fmaf(lxf - wx1, (float)XS, fmaf(lyf - wy1, (float)YS, lzf - wz1));
         const int cell = (int)cf;
-        const float v = val[u];
+        const float v = Bt.w0[u] * Bt.s0[u] + Bt.w1[u] * Bt.s1[u];
         const float vx0 = v * wx0, vx1 = v * wx1;
         const float a00 = vx0 * wy0, a01 = vx0 * wy1, a10 = vx1 * wy0, a11 = vx1 * wy1;
         S2_FENCE();
         if (S2_ABL(4)) dot += (double)(a00 + a01 + a10 + a11 + (float)cell);
-        if (act[u] && !S2_ABL(4)) {
+        if (__builtin_amdgcn_inverse_ballot_w64(Bt.amask[u]) && !S2_ABL(4)) {
           float *q = acc + cell;
           {
             const float o00 = q[0], o01 = q[YS], o10 = q[XS], o11 = q[XS + YS];
@@ -562,58 +637,75 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
         }
         S2_FENCE();
       }
+    };
+    if (ninstr > 0 && !S2_ABL(1)) {
+      Batch ba, bb;
+      fetch(ba, 0);
+      for (int p0 = 0; p0 < ninstr; p0 += 2 * kU) {
+        const bool more = p0 + kU < ninstr;
+        if (more) fetch(bb, p0 + kU);
+        splat(ba);
+        if (more) {
+          if (p0 + 2 * kU < ninstr) fetch(ba, p0 + 2 * kU);
+          splat(bb);
+        }
+      }
     }
     S2_FENCE();
     // ---- epilogue: q = [q +] acc + a0 p + c DtD p ; dot += p*q  (one row per lane group) ----
     if (S2_ABL(2)) continue;
-    constexpr int RPX = TY / G;  // instructions per x slab of the tile
-    static_assert((TX * RPX) % 4 == 0, "fast epilogue unrolls four instructions");
     const bool fast_xy = pin != nullptr && !P.accumulate && x0 > 0 && y0 > 0 &&
                          x0 + TX < dd.x && y0 + TY < dd.y && dd.numel() < (1ull << 29);
     if (fast_xy) {
-      // interior tiles (all x/y stencil neighbours inside the volume): buffer addressing with a
-      // per-lane byte offset computed once per tile + scalar row offsets; 28 loads in flight
-      const size_t sxe = (size_t)dd.y * dd.z, sye = dd.z;
-      const int kc = min(z0 + gl, dd.z - 1);
-      const bool actz = gl < ez, lzf = kc > 0, hzf = kc + 1 < dd.z;
-      const unsigned e0 = 4u * (unsigned)(((x0 - 1) * dd.y + y0 - 1 + grp) * dd.z + kc);
-      const unsigned em = lzf ? e0 - 4u : e0, ep = hzf ? e0 + 4u : e0;
-      const unsigned sxb = 4u * (unsigned)sxe, syb = 4u * (unsigned)sye;
+      // Interior tiles (all x / y stencil neighbours inside the volume).  Lane gl of a group holds
+      // z plane z0 - 1 + gl of the aproned tile; group g owns x slabs 4g .. 4g + 3.  Every row of p
+      // the group's stencils touch is loaded ONCE (32 loads per tile instead of 7 per output row);
+      // the z neighbours come from the adjacent lanes (DPP wave shifts), the x / y neighbours from
+      // the other registers.  Buffer addressing: a per-lane byte offset computed once per tile +
+      // scalar row offsets.
+      static_assert(TX == 8 && TY == 4 && G == 2, "epilogue register window is written for 8 x 4 tiles");
+      const int kz = z0 - 1 + gl;
+      const bool out_z = gl >= 1 && gl <= ez, lz_ok = kz > 0, hz_ok = kz + 1 < dd.z;
+      const unsigned sxb = 4u * (unsigned)(dd.y * dd.z), syb = 4u * (unsigned)dd.z;
+      const unsigned e0 = 4u * (unsigned)(((x0 + 4 * grp - 1) * dd.y + y0 - 1) * dd.z + kz);
       const __amdgpu_buffer_rsrc_t rp = make_rsrc(pin, dd.numel() * 4),
                                    rd = make_rsrc(dst, dd.numel() * 4),
                                    rb = make_rsrc(P.objb ? P.objb : pin, dd.numel() * 4);
-      const float *arow = acc + (SY + 1 + grp) * SZ + gl + 1;
+      const float *arow = acc + ((4 * grp + 1) * SY + 1) * SZ + gl;
+      float pv[6][6];  // pv[s + 1][ly + 1]: x slab s = -1 .. 4, row ly = -1 .. 4 (corners unused)
+#pragma unroll
+      for (int sa = 0; sa < 6; ++sa)
+#pragma unroll
+        for (int la = 0; la < 6; ++la) {
+          const bool halo_x = sa == 0 || sa == 5, halo_y = la == 0 || la == 5;
+          pv[sa][la] = (halo_x && halo_y) ? 0.f : buf_load(rp, e0, (unsigned)sa * sxb + (unsigned)la * syb);
+        }
       auto rows = [&](auto obj_tag) {
         constexpr bool OBJ = decltype(obj_tag)::value;
-#pragma unroll 1
-        for (int it = 0; it < TX * RPX; it += 4) {
-          const int it0 = __builtin_amdgcn_readfirstlane(it);
-          float c[4], vxp[4], vxm[4], vyp[4], vym[4], vzp[4], vzm[4], ob[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const unsigned ro = (unsigned)((it0 + j) / RPX + 1) * sxb +
-                                (unsigned)(((it0 + j) % RPX) * G + 1) * syb;
-            c[j] = buf_load(rp, e0, ro);
-            vxp[j] = buf_load(rp, e0, ro + sxb), vxm[j] = buf_load(rp, e0, ro - sxb);
-            vyp[j] = buf_load(rp, e0, ro + syb), vym[j] = buf_load(rp, e0, ro - syb);
-            vzp[j] = buf_load(rp, ep, ro), vzm[j] = buf_load(rp, em, ro);
-            if (OBJ) ob[j] = buf_load(rb, e0, ro);
+        for (int sa = 1; sa <= 4; ++sa) {
+          float ob[4];
+          if (OBJ) {
+#pragma unroll
+            for (int la = 1; la <= 4; ++la) ob[la - 1] = buf_load(rb, e0, (unsigned)sa * sxb + (unsigned)la * syb);
           }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int lx = (it0 + j) / RPX, ly2 = ((it0 + j) % RPX) * G;
-            const unsigned ro = (unsigned)(lx + 1) * sxb + (unsigned)(ly2 + 1) * syb;
-            float q = arow[(lx * SY + ly2) * SZ];
-            const float xf = vxp[j] - c[j], xbk = c[j] - vxm[j], yf = vyp[j] - c[j], ybk = c[j] - vym[j];
-            const float zf = (hzf ? vzp[j] : 0.f) - c[j], zbk = lzf ? c[j] - vzm[j] : 0.f;
+          for (int la = 1; la <= 4; ++la) {
+            const float c = pv[sa][la];
+            const float vzm = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), 0x138, 0xf, 0xf, false));
+            const float vzp = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), 0x130, 0xf, 0xf, false));
+            float q = arow[((sa - 1) * SY + (la - 1)) * SZ];
+            const float xf = pv[sa + 1][la] - c, xbk = c - pv[sa - 1][la];
+            const float yf = pv[sa][la + 1] - c, ybk = c - pv[sa][la - 1];
+            const float zf = (hz_ok ? vzp : 0.f) - c, zbk = lz_ok ? c - vzm : 0.f;
             const float st = P.cx * (xbk - xf) + P.cy * (ybk - yf) + P.cz * (zbk - zf);
-            q += P.a0 * c[j] + st;
-            if (actz) {
+            q += P.a0 * c + st;
+            if (out_z) {
               if (OBJ) {
-                dot += (double)obj_term(q, ob[j], c[j]);
+                dot += (double)obj_term(q, ob[la - 1], c);
               } else {
-                buf_store(q, rd, e0, ro);
-                dot += (double)__fmul_rn(c[j], q);
+                buf_store(q, rd, e0, (unsigned)sa * sxb + (unsigned)la * syb);
+                dot += (double)__fmul_rn(c, q);
               }
             }
           }
@@ -647,13 +739,6 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
   }
 }
 
-static int s2_grid(Dim3i dd) {
-  const int nt = s2_ntiles(dd);
-  static const int cap = getenv("UNIRES_SPLAT2_BLOCKS") ? atoi(getenv("UNIRES_SPLAT2_BLOCKS")) : 1024;
-  const int want = (nt + kS2Waves - 1) / kS2Waves;
-  return want < cap ? want : cap;
-}
-
 int splat2_blocks(Dim3i dd) { return s2_grid(dd) * kS2Waves; }  // partials written
 
 int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const float4 *tab_dev, int gn,
@@ -667,7 +752,7 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
   P.src = src;
   P.src_bytes = src_numel * sizeof(float);  // buffer range check: idle lanes may point anywhere
   P.tab = tab_dev, P.gn = gn;
-  P.tabn = S.axis >= 0 ? gn + kWave : 0;
+  P.tabn = S.axis >= 0 ? gn + 2 * kWave : 0;
   P.row_stride4 = 4u * row_stride, P.tab_step4 = 4u * tab_step;
   P.entries = S.entries, P.masks = S.masks, P.tile_off = S.tile_off, P.ntiles = S.ntiles;
   P.A = A, P.alpha = alpha;

@@ -22,12 +22,12 @@ constexpr unsigned kS2RowBits = 19, kS2RowIdle = (1u << kS2RowBits) - 1u;
 
 struct S2Entry {     // one segment of an instruction (16 bytes)
   float rx, ry, rz;  // affine_row(A, ui, uj): the row part of the coordinate arithmetic
-  unsigned pk;       // row code (19 bits; all ones = idle tail) | (k0 - first lane + 64) << 19
+  unsigned pk;       // row code (19 bits) | (k0 - first lane + 64) << 19
 };
 
 struct SplatSched {
   S2Entry *entries = nullptr;            // device
-  unsigned long long *masks = nullptr;   // device: per instruction, bit l-1 set <=> a segment starts at lane l
+  ulonglong2 *masks = nullptr;           // device, per instruction: {bit l-1 set <=> a segment starts at lane l, active lanes}
   uint2 *tile_off = nullptr;             // device, ntiles + 1 {entry offset, instruction offset}
   unsigned long long *scratch = nullptr; // device: {error flag, points, instructions} of a build
   size_t cap_entries = 0, cap_instr = 0, cap_tiles = 0;
