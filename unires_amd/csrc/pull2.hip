@@ -170,6 +170,16 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   }
   __syncthreads();
   // ---- pull: one grid row per wave pass, lanes along grid z; conv_down every 8 rows ----
+  // Measured alternatives that did NOT pay on config 3 (this form: 55 us):
+  //  * a 96-word column stride (bank = z plane, LDS bank conflicts 48 % -> 4 % of the LDS cycles):
+  //    64 us - the window grows by a third, fewer workgroups fit, and LDS was not the limiter;
+  //  * computing all addresses / weights before the barrier, while the LDS-DMA is in flight: 65 us -
+  //    the waves of a workgroup then do their VALU work together and their LDS reads together
+  //    instead of interleaving them;
+  //  * persistent workgroups looping over work items (1024 - 2560 of them): 61 - 70 us - the
+  //    hardware dispatcher balances 10 240 short workgroups better than a static loop does;
+  //  * 4 x 8 instead of 8 x 8 rows per workgroup: the same 55 us (more workgroups per CU, more
+  //    window overlap).
   const float kf = (float)(k0 + min(lane, npts - 1));
   const float c0 = G.A.m[2], c1 = G.A.m[6], c2 = G.A.m[10];
   const float t0 = G.A.m[3], t1 = G.A.m[7], t2 = G.A.m[11];
