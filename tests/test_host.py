@@ -153,3 +153,27 @@ def test_fit_schedule_and_gain():
     from unires_amd.optim import get_gain
     assert abs(float(get_gain([5.481, 4.983, 4.706], 'decreasing')) - 0.3574) < 1e-3  # demo trace
     assert float(get_gain([1.0])) == float('inf')
+
+
+def test_device_guard_finds_the_tensor_device_and_is_transparent_on_cpu():
+    """Every library entry point runs under _ops.on_device: the device of its tensors becomes the
+    current HIP device for the call (plan workspace, streams).  Without a CUDA tensor in the
+    arguments the wrapper must be a plain call."""
+    import torch
+    from types import SimpleNamespace
+    from unires_amd import _ops, _update, _plan
+    calls = []
+
+    @_ops.on_device
+    def f(a, b=None):
+        calls.append((a, b))
+        return 7
+
+    assert f(torch.zeros(2), b=[SimpleNamespace(dat=torch.zeros(1))]) == 7 and len(calls) == 1
+    assert _ops._find_device(torch.zeros(3)) is None
+    assert _ops._find_device([[SimpleNamespace(dat=torch.zeros(1))]]) is None
+    fake = SimpleNamespace(device=torch.device('cuda', 3))
+    assert _ops._find_device([fake]) == torch.device('cuda', 3)
+    # the decorated entry points keep their names / docstrings
+    assert _update._update_y.__name__ == '_update_y' and 'UPDATE: y' in _update._update_y.__doc__
+    assert _plan.ChannelPlan.matvec.__name__ == 'matvec'

@@ -13,7 +13,50 @@ FOV_TOL = 5e-2  # nitorch's in-FOV tolerance for extrapolate=False (SURVEY 8(a) 
 
 
 def _stream():
+    """The caller's current HIP stream ON THE CURRENT DEVICE.  Every entry point runs under
+    ``on_device`` below, so "current device" is the device of the tensors it was handed."""
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _find_device(obj, depth=0):
+    """Device of the first CUDA tensor reachable from the arguments (tensors, lists of tensors,
+    _input / _output structs, plans)."""
+    if isinstance(obj, torch.Tensor):
+        return obj.device if obj.is_cuda else None
+    dev = getattr(obj, 'device', None)
+    if isinstance(dev, torch.device) and dev.type == 'cuda':
+        return dev
+    if depth < 3:
+        if isinstance(obj, (list, tuple)):
+            for o in obj:
+                d = _find_device(o, depth + 1)
+                if d is not None:
+                    return d
+        dat = getattr(obj, 'dat', None)
+        if isinstance(dat, torch.Tensor) and dat.is_cuda:
+            return dat.device
+    return None
+
+
+def on_device(fn):
+    """Run ``fn`` with the device of its tensors as the current HIP device: the library allocates
+    plan workspace with hipMalloc and launches on the current device's stream, so a call made
+    while another GPU is current would otherwise land on the wrong one (one process per GPU is the
+    normal mode, but nothing should depend on it)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = None
+        for a in list(args) + list(kwargs.values()):
+            dev = _find_device(a)
+            if dev is not None:
+                break
+        if dev is None or (dev.index is not None and dev.index == torch.cuda.current_device()):
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapped
 
 
 def _vol(t, name='dat'):
@@ -38,6 +81,7 @@ def _taps_arg(taps):
     return arr, keep, i3([len(k) for k in keep])
 
 
+@on_device
 def pull_affine(src, M, gdim, fov_tol=FOV_TOL):
     """grid_pull(src, affine_grid(M, gdim)) - linear, zero bound, extrapolate=False."""
     s, lead = _vol(src, 'src')
@@ -47,6 +91,7 @@ def pull_affine(src, M, gdim, fov_tol=FOV_TOL):
     return out.reshape(lead + tuple(gdim))
 
 
+@on_device
 def pull_grad_affine(src, M, gdim, fov_tol=FOV_TOL):
     """grid_grad(src, affine_grid(M, gdim)) -> (gdim, 3): spatial gradient of the trilinear sample."""
     s, lead = _vol(src, 'src')
@@ -56,6 +101,7 @@ def pull_grad_affine(src, M, gdim, fov_tol=FOV_TOL):
     return out.reshape(lead + tuple(gdim) + (3,))
 
 
+@on_device
 def push_affine(src, M, ddim, alpha=1.0, out=None, fov_tol=FOV_TOL):
     """grid_push(src, affine_grid(M, src.shape), shape=ddim); out += if given."""
     s, lead = _vol(src, 'src')
@@ -69,6 +115,7 @@ def push_affine(src, M, ddim, alpha=1.0, out=None, fov_tol=FOV_TOL):
     return out if acc else out.reshape(lead + tuple(ddim))
 
 
+@on_device
 def conv_down(src, taps, stride, scl=0.0, scl_dim=0):
     """F.conv3d(src, outer(taps), stride=stride) [+ even/odd scaling]."""
     s, lead = _vol(src, 'src')
@@ -85,6 +132,7 @@ def conv_down(src, taps, stride, scl=0.0, scl_dim=0):
     return out.reshape(lead + tuple(ddim))
 
 
+@on_device
 def conv_up(src, taps, stride, scl=0.0, scl_dim=0):
     """F.conv_transpose3d(S(scl) src, outer(taps), stride=stride)."""
     s, lead = _vol(src, 'src')
@@ -104,6 +152,7 @@ def _vx3(vx):
     return tuple(float(v) for v in vx)
 
 
+@on_device
 def grad_fwd_zero(dat, vx=None):
     s, _ = _vol(dat)
     out = torch.empty((3,) + tuple(s.shape), dtype=torch.float32, device=s.device)
@@ -112,6 +161,7 @@ def grad_fwd_zero(dat, vx=None):
     return out
 
 
+@on_device
 def div_fwd_zero(dat3, vx=None):
     if dat3.dim() != 4 or dat3.shape[0] != 3:
         raise ValueError('unires_amd: divergence input must be (3,X,Y,Z)')
@@ -124,6 +174,7 @@ def div_fwd_zero(dat3, vx=None):
     return out
 
 
+@on_device
 def dtd(dat, vx=None, a=0.0, c=1.0):
     """a*dat + c*DtD(dat)."""
     s, lead = _vol(dat)

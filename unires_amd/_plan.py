@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 from ._lib import (REGIME_DENOISE, REGIME_IDENTITY, REGIME_SUPERRES, Repeat, check, f3, i3)
-from ._ops import FOV_TOL, _ptr, _stream, _vol
+from ._ops import FOV_TOL, _ptr, _stream, _vol, on_device
 from .spatial import _m12, voxel_size
 
 
@@ -55,8 +55,16 @@ def _repeat_desc(po, tau, method, regime, keep):
 class ChannelPlan:
     """One channel's fused operator. ``xs``: list of (po, tau) per repeat."""
 
-    def __init__(self, dim_y, vx_y, repeats, method, do_proj, fov_tol=FOV_TOL):
+    def __init__(self, dim_y, vx_y, repeats, method, do_proj, fov_tol=FOV_TOL, device=None):
         self.lib = _lib.load()
+        # the plan's workspace lives on ONE device: the one current when it is created
+        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        with torch.cuda.device(self.device):
+            self._create(dim_y, vx_y, repeats, method, do_proj, fov_tol)
+
+    def _create(self, dim_y, vx_y, repeats, method, do_proj, fov_tol):
         self.dim_y = tuple(int(d) for d in dim_y)
         self.regime = regime_of(method, do_proj)
         self.method = method
@@ -80,7 +88,11 @@ class ChannelPlan:
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
-            self.lib.unires_plan_destroy(self._h)
+            try:
+                with torch.cuda.device(self.device):
+                    self.lib.unires_plan_destroy(self._h)
+            except Exception:  # interpreter shutdown
+                self.lib.unires_plan_destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -89,6 +101,7 @@ class ChannelPlan:
     def workspace_bytes(self):
         return int(self.lib.unires_plan_workspace_bytes(self._h))
 
+    @on_device
     def set_repeat(self, n, po, tau):
         keep = []
         r = _repeat_desc(po, tau, self.method, self.regime, keep)
@@ -101,6 +114,7 @@ class ChannelPlan:
                              % (name, tuple(v.shape), self.dim_y))
         return v
 
+    @on_device
     def proj_apply(self, n, operator, dat):
         """_proj_apply(operator, dat, po_n) without tau."""
         if operator not in _lib.OP:
@@ -116,6 +130,7 @@ class ChannelPlan:
                                          _stream()))
         return out.reshape(lead + tuple(out_dim))
 
+    @on_device
     def matvec(self, p, rho, lam, out=None, dot=None):
         """q = sum tau AtA p + rho lam^2 DtD p; ``dot``: 0-d float64 device tensor or None."""
         p = self._y(p, 'p')
@@ -125,6 +140,7 @@ class ChannelPlan:
                                          _ptr(dot) if dot is not None else None, _stream()))
         return out
 
+    @on_device
     def rhs(self, x_dats, w_c, z_c, rho, lam, out=None):
         """b = sum tau At x - lam Dt(w - rho z)   (unires/_update.py:124-133)."""
         xs = [_vol(t, 'x')[0] for t in x_dats]
@@ -144,6 +160,7 @@ class ChannelPlan:
                                            float(lam), _ptr(out), _stream()))
         return out
 
+    @on_device
     def rhs_cached(self, x_dats, w_c, z_c, rho, lam, out):
         """Same b as :meth:`rhs`, but sum_n tau_n At x_n is kept on the plan and only
         recomputed when an observation tensor changed (the plan itself is rebuilt when a
@@ -163,6 +180,7 @@ class ChannelPlan:
                                            float(rho), float(lam), _ptr(out), _stream()))
         return out
 
+    @on_device
     def precond_build(self, rho, lam, mode='jacobi', out=None):
         """Diagonal of unires/_update.py:80-102 for this channel, kept in the plan for
         ``cg(precond='jacobi')``; ``out`` (dim_y tensor) optionally receives a copy."""
@@ -174,6 +192,7 @@ class ChannelPlan:
                                             _ptr(out) if out is not None else None, _stream()))
         return out
 
+    @on_device
     def precond_apply(self, v, out=None):
         """out = precond(v) for the preconditioner last built on this plan (identity: copy)."""
         v = self._y(v, 'v')
@@ -182,6 +201,7 @@ class ChannelPlan:
         check(self.lib.unires_precond_apply(self._h, _ptr(v), _ptr(out), _stream()))
         return out
 
+    @on_device
     def cg(self, b, x, rho, lam, max_iter=20, tolerance=1e-3, stop='max_gain', sync=True,
            precond='none'):
         """In-place CG on x (must be contiguous (X,Y,Z)).  Returns (iters, obj) when

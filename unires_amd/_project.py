@@ -166,7 +166,7 @@ def _channel_plan(x, y, method, do, vx_y=None):
     if vx_y is None:
         vx_y = voxel_size(y.mat)
     vx = [float(v) for v in torch.as_tensor(vx_y).detach().cpu().tolist()]
-    plan = ChannelPlan(y.dim, vx, [(xn.po, xn.tau) for xn in x], method, do)
+    plan = ChannelPlan(y.dim, vx, [(xn.po, xn.tau) for xn in x], method, do, device=y.dat.device)
     y._plan = (sig, plan)
     return plan
 

@@ -21,7 +21,7 @@ import torch
 
 from . import _lib, _ops
 from ._lib import check, i3
-from ._ops import _ptr, _stream
+from ._ops import _ptr, _stream, on_device
 from ._project import _apply_scaling, _proj_info, _taps
 from .spatial import _m12
 
@@ -96,6 +96,7 @@ def _grid_matrix(po, rigid, method):
     return torch.linalg.solve(po.mat_y, torch.as_tensor(rigid, dtype=_F64).cpu().mm(mat)), dim
 
 
+@on_device
 def _rigid_terms(dat_x, dat_y, po, tau, rigid, sett, diff=False):
     """ll and, if ``diff``, the raw ingredients of the derivatives: gr3 (dim,3) = grid_grad,
     dg (dim) = residual in grid space."""
@@ -121,6 +122,7 @@ def _rigid_terms(dat_x, dat_y, po, tau, rigid, sett, diff=False):
     return ll, gr3, d.reshape(dim).contiguous()
 
 
+@on_device
 def _rigid_match(dat_x, dat_y, po, tau, rigid, sett, CtC=None, diff=False, verbose=0):
     """Rigid matching term with the reference's return shapes (unires/_update.py:448-538):
     ll, gr (dim, 3) = grid_grad * residual, Hes (dim, 6) = outer(grid_grad) [* CtC]."""
@@ -140,6 +142,7 @@ def _ctc(po, dim, device):
     return _ops.conv_up(_ops.conv_down(ones, _taps(po), po.ratio), _taps(po), po.ratio).contiguous()
 
 
+@on_device
 def _update_rigid_channel(xc, yc, sett, max_niter_gn=1, num_linesearch=4, verbose=0, samp=3, c=1):
     """Updates the rigid parameters of all images of one channel (unires/_update.py:541-710)."""
     lib = _lib.load()
@@ -202,6 +205,7 @@ def _update_rigid_channel(xc, yc, sett, max_niter_gn=1, num_linesearch=4, verbos
     return xc, sll
 
 
+@on_device
 def _update_rigid(x, y, sett, mean_correct=True, max_niter_gn=1, num_linesearch=4, verbose=0, samp=3):
     """Updates each input image's registration parameters x[c][n].rigid_q by Gauss-Newton and
     refreshes x[c][n].po.rigid (unires/_update.py:198-266).  Returns (x, sll)."""

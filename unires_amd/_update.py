@@ -6,7 +6,7 @@ import torch
 
 from . import _lib
 from ._lib import check, f3, i3
-from ._ops import _ptr, _stream
+from ._ops import _ptr, _stream, on_device
 from ._project import _channel_plan, _proj
 from .spatial import voxel_size
 
@@ -43,6 +43,7 @@ class _Precond:
         return v if self.M is None else v / self.M
 
 
+@on_device
 def _precond(x, y, rho, sett):
     """Compute CG preconditioner (unires/_update.py:80-102): Jacobi,
     M = tau AtA(1) + 2 rho lam^2 sum(1/vx^2) for one channel (x = x[c], y = y[c])."""
@@ -54,6 +55,7 @@ def _precond(x, y, rho, sett):
     return _Precond(plan, M, 'jacobi')
 
 
+@on_device
 def _update_y(x, y, z, w, rho, tmp, sett, info=None):
     """UPDATE: y  (unires/_update.py:118-152).  Per channel: assemble
     b = sum_n tau_n At x_n - lam Dt(w - rho z) and solve
@@ -126,6 +128,7 @@ def _chan_args(y):
     return ptrs, lams
 
 
+@on_device
 def _update_zw(y, z, w, rho, tmp, sett):
     """UPDATE z and w  (unires/_update.py:160-193): joint-TV shrinkage and dual ascent,
     two fused kernels per channel instead of three im_gradient passes and a dozen
@@ -143,6 +146,7 @@ def _update_zw(y, z, w, rho, tmp, sett):
     return z, w, tmp
 
 
+@on_device
 def _compute_nll(x, y, sett, rho, sum_dtype=torch.float64):
     """Negative model log-likelihood (unires/_update.py:396-427); returns 0-d float64
     device tensors (nll_yx, nll_xy, nll_y) without synchronising."""
@@ -163,6 +167,7 @@ def _compute_nll(x, y, sett, rho, sum_dtype=torch.float64):
     return nll_xy + nll_y, nll_xy, nll_y
 
 
+@on_device
 def _update_scaling(x, y, sett, max_niter_gn=1, num_linesearch=4, verbose=0):
     """Updates the even/odd slice scaling parameter of every observation by Gauss-Newton
     (unires/_update.py:270-393).  ``A y`` comes from the fused pull+conv kernel, the five masked
@@ -221,6 +226,7 @@ def _update_scaling(x, y, sett, max_niter_gn=1, num_linesearch=4, verbose=0):
     return x, sll
 
 
+@on_device
 def _update_admm(x, y, z, w, rho, tmp, obj, n_iter, sett, info=None):
     """One ADMM iteration (unires/_update.py:105-195): y-update (CG), objective,
     z-update, w-update - same order, same in-place semantics, `tmp` returned as the

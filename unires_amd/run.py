@@ -6,7 +6,7 @@ import torch
 
 from . import _lib
 from ._lib import check, i3
-from ._ops import _ptr, _stream
+from ._ops import _ptr, _stream, on_device
 from ._rigid import _update_rigid
 from ._update import _admm_aux, _step_size, _update_admm, _update_scaling
 from .optim import get_gain
@@ -27,6 +27,7 @@ def _get_sched(N, sett):
     return sett
 
 
+@on_device
 def _clean_fov(x, y):
     """Zero the voxels of y[c] outside the field of view of any of its observations
     (unires/run.py:150-164)."""
@@ -40,6 +41,7 @@ def _clean_fov(x, y):
     return y
 
 
+@on_device
 def fit(x, y, sett):
     """Fit model (unires/run.py:24-207).  ``x[c][n]`` / ``y[c]`` are the _input / _output
     structs with device tensors, as left by the initialisation (``_init_y_dat``,
