@@ -273,6 +273,8 @@ struct Repeat {
   float *ctab_dev[2] = {nullptr, nullptr};
   int ctab_n = 0, ctab_cap = 0;
   unsigned ctab_step = 1, src_stride = 1;
+  float *xytab_dev[2] = {nullptr, nullptr};  // axis 3: conv_up tables along x and y (schedule build)
+  int xytab_cap[2] = {0, 0};
   PullPlan pplan;  // LDS-window pull: per-workgroup geometry of this operator (pull2.hip)
 };
 
@@ -399,18 +401,28 @@ static int build_sched(unires_plan *pl, Repeat &R) {
       ++nconv;
       axis = d;
     }
-    if (nconv > 1) return UNIRES_OK;  // conv_up along several axes: k_splat<3> / general kernels
-    if (axis < 0) axis = 2;           // all dirac: conv_up is the identity, any axis works
     const int xdv[3] = {R.dim_x.x, R.dim_x.y, R.dim_x.z}, gdv[3] = {R.dim_gf.x, R.dim_gf.y, R.dim_gf.z};
-    if ((R.Tf.n[axis] + R.Tf.s[axis] - 1) / R.Tf.s[axis] > 2 || xdv[axis] < 2) return UNIRES_OK;
-    if (R.scl != 0.f && R.dim_thick != axis) return UNIRES_OK;
     if (R.dim_x.numel() >= (1ull << 30)) return UNIRES_OK;
+    if (nconv > 1) {
+      // conv_up along several axes (isotropic down-sampling, BASELINE config 4): x / y parts per
+      // segment in the schedule, z part per lane
+      for (int d = 0; d < 3; ++d)
+        if ((R.Tf.n[d] + R.Tf.s[d] - 1) / R.Tf.s[d] > 2 || xdv[d] < 2) return UNIRES_OK;
+      if (R.scl != 0.f && R.dim_thick != 2) return UNIRES_OK;
+      axis = 3;
+    } else {
+      if (axis < 0) axis = 2;  // all dirac: conv_up is the identity, any axis works
+      if ((R.Tf.n[axis] + R.Tf.s[axis] - 1) / R.Tf.s[axis] > 2 || xdv[axis] < 2) return UNIRES_OK;
+      if (R.scl != 0.f && R.dim_thick != axis) return UNIRES_OK;
+    }
     const unsigned xyz = (unsigned)R.dim_x.y * (unsigned)R.dim_x.z, xz = (unsigned)R.dim_x.z;
+    const int taxis = axis == 3 ? 2 : axis;  // axis of the run-time (per-lane) table
     if (axis == 2) rows_y = R.dim_x.y, R.src_stride = xz, R.ctab_step = 1;
     if (axis == 1) R.src_stride = xyz, R.ctab_step = xz;  // source offset ui * xyz + koff(uj) * xz + k
     if (axis == 0) R.src_stride = xz, R.ctab_step = xyz;  // source offset uj * xz + koff(ui) * xyz + k
-    const int gn = gdv[axis];
-    if (gn + 64 > 1400) return UNIRES_OK;  // LDS copy of the table
+    if (axis == 3) R.src_stride = xz, R.ctab_step = xyz;  // (x-space row / slab strides)
+    const int gn = gdv[taxis];
+    if (gn + 128 > 1400) return UNIRES_OK;  // LDS copy of the table
     std::vector<float> host((size_t)gn * 4);
     for (int v = 0; v < 2; ++v) {
       if (!R.ctab_dev[v] || R.ctab_cap < gn) {
@@ -419,16 +431,32 @@ static int build_sched(unires_plan *pl, Repeat &R) {
         if (hipMalloc((void **)&R.ctab_dev[v], host.size() * sizeof(float)) != hipSuccess)
           return fail(UNIRES_ERR_ALLOC, "hipMalloc conv table");
       }
-      splat2_convtab(R.Tf, v ? make_scaling(R.scl, R.dim_thick) : Scaling{1.f, 1.f, -1}, axis, gn,
-                     xdv[axis], host.data());
+      splat2_convtab(R.Tf, v ? make_scaling(R.scl, R.dim_thick) : Scaling{1.f, 1.f, -1}, taxis, gn,
+                     xdv[taxis], host.data());
       if (hipMemcpy(R.ctab_dev[v], host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) !=
           hipSuccess)
         return fail(UNIRES_ERR_HIP, "hipMemcpy conv table");
     }
     R.ctab_n = gn;
     R.ctab_cap = std::max(R.ctab_cap, gn);
+    if (axis == 3) {
+      for (int d = 0; d < 2; ++d) {
+        std::vector<float> hx((size_t)gdv[d] * 4);
+        if (!R.xytab_dev[d] || R.xytab_cap[d] < gdv[d]) {
+          if (R.xytab_dev[d]) (void)hipFree(R.xytab_dev[d]);
+          R.xytab_dev[d] = nullptr;
+          if (hipMalloc((void **)&R.xytab_dev[d], hx.size() * sizeof(float)) != hipSuccess)
+            return fail(UNIRES_ERR_ALLOC, "hipMalloc conv table");
+          R.xytab_cap[d] = gdv[d];
+        }
+        splat2_convtab(R.Tf, Scaling{1.f, 1.f, -1}, d, gdv[d], xdv[d], hx.data());
+        if (hipMemcpy(R.xytab_dev[d], hx.data(), hx.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+          return fail(UNIRES_ERR_HIP, "hipMemcpy conv table");
+      }
+    }
   }
-  (void)splat2_build(R.sched, R.Af, R.Afinv, R.dim_gf, pl->dy, pl->fov_tol, R.safe, axis, rows_y);
+  (void)splat2_build(R.sched, R.Af, R.Afinv, R.dim_gf, pl->dy, pl->fov_tol, R.safe, axis, rows_y,
+                     (const float4 *)R.xytab_dev[0], (const float4 *)R.xytab_dev[1], R.dim_x);
   // the pull of the same operator (denoising: plain pull onto the grid; super-resolution: + conv_down)
   if (pl->regime == UNIRES_REGIME_DENOISE)
     (void)pull2_build(R.pplan, pl->dy, R.A, R.T, R.dim_g, R.dim_g);
@@ -443,8 +471,11 @@ static int build_sched(unires_plan *pl, Repeat &R) {
 static void free_sched(Repeat &R) {
   splat2_free(R.sched);
   pull2_free(R.pplan);
-  for (int v = 0; v < 2; ++v)
+  for (int v = 0; v < 2; ++v) {
     if (R.ctab_dev[v]) (void)hipFree(R.ctab_dev[v]), R.ctab_dev[v] = nullptr;
+    if (R.xytab_dev[v]) (void)hipFree(R.xytab_dev[v]), R.xytab_dev[v] = nullptr;
+    R.xytab_cap[v] = 0;
+  }
   R.ctab_n = R.ctab_cap = 0;
 }
 
@@ -566,6 +597,7 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   tmp.ctab_dev[0] = plan->reps[n].ctab_dev[0];
   tmp.ctab_dev[1] = plan->reps[n].ctab_dev[1];
   tmp.ctab_cap = plan->reps[n].ctab_cap;
+  for (int d = 0; d < 2; ++d) tmp.xytab_dev[d] = plan->reps[n].xytab_dev[d], tmp.xytab_cap[d] = plan->reps[n].xytab_cap[d];
   plan->reps[n] = tmp;
   rc = upload_ztabs(plan, plan->reps[n]);
   if (!rc) rc = build_sched(plan, plan->reps[n]);
@@ -646,8 +678,8 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
   if (!use_tile && mode == nullptr && R.sched.valid && (src.convup != 0) == (R.sched.axis >= 0)) {
     const float4 *tab = src.convup ? (const float4 *)R.ctab_dev[src.S.dim >= 0 ? 1 : 0] : nullptr;
     const size_t numel = src.convup ? src.xd.numel() : src.gd.numel();
-    if (!launch_splat2(R.sched, src.data, numel, tab, R.ctab_n, R.src_stride, R.ctab_step, A, alpha, ep,
-                       out, pl->dy, done, st))
+    if (!launch_splat2(R.sched, src.data, numel, tab, R.ctab_n, R.src_stride, R.ctab_step, R.src_stride,
+                       R.ctab_step, A, alpha, ep, out, pl->dy, done, st))
       return ep.partials ? splat2_blocks(pl->dy) : 0;
   }
   if (!use_tile &&
@@ -659,7 +691,7 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
     d.data = launch_conv_up_sep(src.data, src.xd, src.T, src.S, src.gd, pl->gbuf, pl->gbuf2, st);
     d.convup = 0;
     if (mode == nullptr && R.sched.valid && R.sched.axis < 0 &&
-        !launch_splat2(R.sched, d.data, d.gd.numel(), nullptr, 0, R.src_stride, 1, A, alpha, ep, out,
+        !launch_splat2(R.sched, d.data, d.gd.numel(), nullptr, 0, R.src_stride, 1, 0, 0, A, alpha, ep, out,
                        pl->dy, done, st))
       return ep.partials ? splat2_blocks(pl->dy) : 0;
     if (!launch_splat(d, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st))

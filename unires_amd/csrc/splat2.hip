@@ -89,6 +89,8 @@ struct S2BuildArgs {
   float tol;
   int row_sep;
   int axis, rows_y;
+  const float4 *xtab, *ytab;  // axis 3
+  Dim3i xd;
 };
 
 struct S2Seg {
@@ -97,7 +99,7 @@ struct S2Seg {
 };
 
 __device__ __forceinline__ unsigned s2_rowcode(const S2BuildArgs &B, int ui, int uj) {
-  return (B.axis == 0 || B.axis == 1) ? ((unsigned)ui << 9) | (unsigned)uj
+  return (B.axis == 0 || B.axis == 1 || B.axis == 3) ? ((unsigned)ui << 9) | (unsigned)uj
                                       : (unsigned)ui * (unsigned)B.rows_y + (unsigned)uj;
 }
 
@@ -106,7 +108,7 @@ __device__ __forceinline__ unsigned s2_rowcode(const S2BuildArgs &B, int ui, int
 template <bool FILL>
 __global__ void __launch_bounds__(kWave)
     k_splat2_build(S2BuildArgs B, uint2 *__restrict__ counts, S2Entry *__restrict__ entries,
-                   ulonglong2 *__restrict__ masks, int *__restrict__ err,
+                   S2Ext *__restrict__ ext, ulonglong2 *__restrict__ masks, int *__restrict__ err,
                    unsigned long long *__restrict__ stats) {
   using T = S2Tile;
   constexpr int L = T::L, kSegs = 384;
@@ -320,6 +322,15 @@ __global__ void __launch_bounds__(kWave)
       e.rx = rb.x, e.ry = rb.y, e.rz = rb.z;
       e.pk = s2_rowcode(B, q.ui, q.uj) | ((unsigned)(q.k0 - start + 64) << kS2RowBits);
       out[j] = e;
+      if (B.axis == 3) {  // x / y part of the conv_up of this row: 2 x 2 x-space columns
+        const float4 tx = B.xtab[q.ui], ty = B.ytab[q.uj];
+        S2Ext x;
+        x.base4 = 4u * (((unsigned)__float_as_int(tx.x) * (unsigned)B.xd.y + (unsigned)__float_as_int(ty.x)) *
+                        (unsigned)B.xd.z);
+        x.w00 = tx.y * ty.y, x.w01 = tx.y * ty.z, x.w10 = tx.z * ty.y, x.w11 = tx.z * ty.z;
+        x.pad[0] = x.pad[1] = x.pad[2] = 0u;
+        ext[base.x + (incl - nent) + j] = x;
+      }
       if (j > 0) starts |= 1ull << (start - 1);  // lanes >= start count it: slot = popcount below lane
       active |= (q.len >= 64 ? ~0ull : ((1ull << q.len) - 1ull)) << start;
       pts += q.len;
@@ -338,6 +349,7 @@ __global__ void __launch_bounds__(kWave)
 
 void splat2_free(SplatSched &S) {
   if (S.entries) (void)hipFree(S.entries);
+  if (S.ext) (void)hipFree(S.ext);
   if (S.masks) (void)hipFree(S.masks);
   if (S.tile_off) (void)hipFree(S.tile_off);
   if (S.scratch) (void)hipFree(S.scratch);
@@ -345,7 +357,8 @@ void splat2_free(SplatSched &S) {
 }
 
 int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, Dim3i dd, float tol,
-                 const SplatSafety &safe, int axis, int rows_y) {
+                 const SplatSafety &safe, int axis, int rows_y, const float4 *xtab, const float4 *ytab,
+                 Dim3i xd) {
   S.valid = false;
   static const bool off = getenv("UNIRES_NO_SPLAT2") != nullptr;
   static const bool verbose = getenv("UNIRES_SPLAT2_VERBOSE") != nullptr;
@@ -354,7 +367,8 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
   if (dd.x > 4000 || dd.y > 4000 || dd.z > 4000 || gd.x > 4000 || gd.y > 4000 || gd.z > 4000) return 1;
   if (!fits_fast_index(gd) || !fits_fast_index(dd) || dd.numel() >= (1ull << 30)) return 1;
   // the row code must fit its 19 bits (all ones is reserved)
-  if (axis == 0 || axis == 1) {
+  if (axis == 3 && (!xtab || !ytab)) return 1;
+  if (axis == 0 || axis == 1 || axis == 3) {
     if (gd.x > 1023 || gd.y > 511) return 1;
   } else if ((long long)gd.x * rows_y >= (long long)kS2RowIdle || rows_y < gd.y) {
     return 1;
@@ -373,8 +387,9 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
   S2BuildArgs B;
   B.A = A, B.Ainv = Ainv, B.gd = gd, B.dd = dd, B.tol = tol, B.row_sep = safe.row_sep;
   B.axis = axis, B.rows_y = rows_y;
+  B.xtab = xtab, B.ytab = ytab, B.xd = xd;
   hipLaunchKernelGGL(k_splat2_build<false>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off,
-                     (S2Entry *)nullptr, (ulonglong2 *)nullptr, err_dev,
+                     (S2Entry *)nullptr, (S2Ext *)nullptr, (ulonglong2 *)nullptr, err_dev,
                      (unsigned long long *)nullptr);
   std::vector<uint2> h((size_t)nt + 1);
   if (hipMemcpy(h.data(), S.tile_off, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess)
@@ -392,7 +407,13 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
     S.entries = nullptr;
     const size_t cap = (size_t)re + re / 8 + kPad;
     if (hipMalloc((void **)&S.entries, cap * sizeof(S2Entry)) != hipSuccess) return 1;
+    if (S.ext) (void)hipFree(S.ext);
+    S.ext = nullptr;
     S.cap_entries = cap;
+  }
+  if (axis == 3 && !S.ext) {
+    if (hipMalloc((void **)&S.ext, S.cap_entries * sizeof(S2Ext)) != hipSuccess) return 1;
+    (void)hipMemset(S.ext, 0, S.cap_entries * sizeof(S2Ext));
   }
   if ((size_t)ri + 8 > S.cap_instr) {
     if (S.masks) (void)hipFree(S.masks);
@@ -406,7 +427,7 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
   (void)hipMemset(S.entries + re, 0xff, kPad * sizeof(S2Entry));
   (void)hipMemset(S.masks + ri, 0, 8 * sizeof(ulonglong2));
   hipLaunchKernelGGL(k_splat2_build<true>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off, S.entries,
-                     S.masks, err_dev, stats_dev);
+                     S.ext, S.masks, err_dev, stats_dev);
   int herr = 0;
   unsigned long long hs[2] = {0, 0};
   if (hipMemcpy(&herr, err_dev, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 1;
@@ -460,6 +481,8 @@ struct S2Args {
   unsigned row_stride4;  // bytes per unit of the row code (see launch_splat2)
   unsigned tab_step4;    // bytes between the two x-space values of a grid voxel
   const S2Entry *entries;
+  const S2Ext *ext;      // AXIS 3
+  unsigned xs_sy4, xs_sx4;  // AXIS 3: bytes between x-space rows / slabs
   const ulonglong2 *masks;  // per instruction: {segment starts, active lanes}
   const uint2 *tile_off;
   int ntiles;
@@ -484,16 +507,18 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
   constexpr bool CONV = AXIS >= 0;
   __shared__ __align__(16) float acc_all[kS2Waves][N];
   __shared__ __align__(16) uint4 ring_all[kS2Waves][kWave];  // 2 chunks of 32 segment entries
+  __shared__ __align__(16) uint4 ring2_all[AXIS == 3 ? kS2Waves : 1][AXIS == 3 ? 2 * kWave : 1];  // their S2Ext
   extern __shared__ float4 tabs[];  // CONV: {byte offset, alpha w0, alpha w1, -}, tabn entries
   const int lane = threadIdx.x & (kWave - 1), grp = lane / L, gl = lane & (L - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *acc = acc_all[wave];
   uint4 *ring = ring_all[wave];
+  uint4 *ring2 = ring2_all[AXIS == 3 ? wave : 0];
   const Dim3i dd = P.dd;
   const float *__restrict__ pin = P.p;
   float *__restrict__ dst = P.dst;
   if (CONV) {
-    const unsigned step4 = AXIS == 2 ? 4u : P.tab_step4;
+    const unsigned step4 = (AXIS == 2 || AXIS == 3) ? 4u : P.tab_step4;  // the per-lane table runs along z
     for (int i = threadIdx.x; i < P.tabn; i += kWave * kS2Waves) {
       float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i >= 64 && i - 64 < P.gn) e = P.tab[i - 64];
@@ -534,6 +559,12 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
     ring[lane] = E[lane];
     uint4 pre = make_uint4(0u, 0u, 0u, 0u);
     if (lane < 32) pre = E[64 + lane];
+    const uint4 *X = reinterpret_cast<const uint4 *>(P.ext) + 2 * (size_t)off0.x;  // AXIS 3: 2 uint4 per entry
+    uint4 pre2 = make_uint4(0u, 0u, 0u, 0u);
+    if (AXIS == 3) {
+      ring2[lane] = X[lane], ring2[kWave + lane] = X[kWave + lane];
+      pre2 = X[2 * kWave + lane];  // chunk 2 = 32 entries = 64 uint4
+    }
     for (int i = lane; i < N / 4; i += kWave)
       reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float xb = (float)(x0 - 1), yb = (float)(y0 - 1), zb = (float)(z0 - 1);
@@ -568,8 +599,10 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
       if (need > 32 * (chunk_lo + 2)) {  // advance the ring by one chunk (the oldest one is dead)
         S2_FENCE();
         if (lane < 32) ring[(chunk_lo & 1) * 32 + lane] = pre;
+        if (AXIS == 3) ring2[(chunk_lo & 1) * 64 + lane] = pre2;
         ++chunk_lo;
         if (lane < 32) pre = E[32 * (chunk_lo + 2) + lane];
+        if (AXIS == 3) pre2 = X[64 * (chunk_lo + 2) + lane];
         S2_FENCE();
       }
       eb = need;
@@ -585,6 +618,24 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
         Bt.kf[u] = (float)k;
         Bt.w0[u] = P.alpha, Bt.w1[u] = 0.f, Bt.s0[u] = 1.f, Bt.s1[u] = 0.f;
         if (S2_ABL(8)) {
+        } else if (AXIS == 3) {
+          // conv_up along x, y and z: 2 x 2 x-space columns (per segment) x the z pair (per lane)
+          const uint4 xa = ring2[2 * ((ebu[u] + sl) & 63)], xb = ring2[2 * ((ebu[u] + sl) & 63) + 1];
+          const float4 tb = tabs[k + 64];
+          const unsigned a = xa.x + (unsigned)__float_as_int(tb.x);
+          const uint2 p00 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a, 0, 0));
+          const uint2 p01 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a + P.xs_sy4, 0, 0));
+          const uint2 p10 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a + P.xs_sx4, 0, 0));
+          const uint2 p11 =
+              __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a + P.xs_sx4 + P.xs_sy4, 0, 0));
+          const float z00 = tb.y * __uint_as_float(p00.x) + tb.z * __uint_as_float(p00.y);
+          const float z01 = tb.y * __uint_as_float(p01.x) + tb.z * __uint_as_float(p01.y);
+          const float z10 = tb.y * __uint_as_float(p10.x) + tb.z * __uint_as_float(p10.y);
+          const float z11 = tb.y * __uint_as_float(p11.x) + tb.z * __uint_as_float(p11.y);
+          Bt.w0[u] = 1.f;
+          Bt.s0[u] = __uint_as_float(xa.y) * z00 + __uint_as_float(xa.z) * z01 + __uint_as_float(xa.w) * z10 +
+                     __uint_as_float(xb.x) * z11;
+          (void)code;
         } else if (AXIS == 2) {
           const float4 tb = tabs[k + 64];
           const unsigned a = __umul24(code, P.row_stride4) + (unsigned)__float_as_int(tb.x);
@@ -742,10 +793,12 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
 int splat2_blocks(Dim3i dd) { return s2_grid(dd) * kS2Waves; }  // partials written
 
 int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const float4 *tab_dev, int gn,
-                  unsigned row_stride, unsigned tab_step, const Affine &A, float alpha,
+                  unsigned row_stride, unsigned tab_step, unsigned xs_sy, unsigned xs_sx, const Affine &A,
+                  float alpha,
                   const PushEpilogue &ep, float *dst, Dim3i dd, const int *done, hipStream_t st) {
   if (!S.valid || S.ntiles != s2_ntiles(dd)) return 1;
   if (S.axis >= 0 && !tab_dev) return 1;
+  if (S.axis == 3 && !S.ext) return 1;
   if (src_numel >= (1ull << 30)) return 1;  // 32-bit byte offsets into the source
   if ((unsigned long long)row_stride * 4ull >= (1ull << 24)) return 1;  // 24-bit multiply
   S2Args P;
@@ -754,7 +807,7 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
   P.tab = tab_dev, P.gn = gn;
   P.tabn = S.axis >= 0 ? gn + 2 * kWave : 0;
   P.row_stride4 = 4u * row_stride, P.tab_step4 = 4u * tab_step;
-  P.entries = S.entries, P.masks = S.masks, P.tile_off = S.tile_off, P.ntiles = S.ntiles;
+  P.entries = S.entries, P.ext = S.ext, P.xs_sy4 = 4u * xs_sy, P.xs_sx4 = 4u * xs_sx, P.masks = S.masks, P.tile_off = S.tile_off, P.ntiles = S.ntiles;
   P.A = A, P.alpha = alpha;
   P.p = ep.p, P.a0 = ep.a0, P.cx = ep.cx, P.cy = ep.cy, P.cz = ep.cz;
   P.dst = dst, P.dd = dd, P.accumulate = ep.accumulate, P.partials = ep.partials, P.objb = ep.objb;
@@ -767,6 +820,7 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
     case 0: hipLaunchKernelGGL((k_splat2<0>), grid, block, lds, st, P, done); break;
     case 1: hipLaunchKernelGGL((k_splat2<1>), grid, block, lds, st, P, done); break;
     case 2: hipLaunchKernelGGL((k_splat2<2>), grid, block, lds, st, P, done); break;
+    case 3: hipLaunchKernelGGL((k_splat2<3>), grid, block, lds, st, P, done); break;
     default: hipLaunchKernelGGL((k_splat2<-1>), grid, block, lds, st, P, done); break;
   }
   return 0;

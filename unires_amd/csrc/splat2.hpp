@@ -25,15 +25,22 @@ struct S2Entry {     // one segment of an instruction (16 bytes)
   unsigned pk;       // row code (19 bits) | (k0 - first lane + 64) << 19
 };
 
+struct S2Ext {  // axis 3 (conv_up along all three axes): per-segment x / y part of the conv_up
+  unsigned base4;          // byte offset of x-space voxel (kx, ky, 0)
+  float w00, w01, w10, w11;  // wx_a * wy_b for the 2 x 2 x-space columns that feed the row
+  unsigned pad[3];
+};
+
 struct SplatSched {
   S2Entry *entries = nullptr;            // device
+  S2Ext *ext = nullptr;                  // device, axis 3 only (same indexing as entries)
   ulonglong2 *masks = nullptr;           // device, per instruction: {bit l-1 set <=> a segment starts at lane l, active lanes}
   uint2 *tile_off = nullptr;             // device, ntiles + 1 {entry offset, instruction offset}
   unsigned long long *scratch = nullptr; // device: {error flag, points, instructions} of a build
   size_t cap_entries = 0, cap_instr = 0, cap_tiles = 0;
   int ntiles = 0;
   bool valid = false;
-  int axis = -1;      // -1 direct source; 0..2 conv_up along that axis
+  int axis = -1;      // -1 direct source; 0..2 conv_up along that axis; 3 along all three
   double fill = 0.0;  // active lanes / issued lanes (diagnostic)
 };
 
@@ -41,8 +48,10 @@ struct SplatSched {
 // Row code of a segment: axis 2 / -1: ui * rows_y + uj (the source row index); axis 0 / 1:
 // ui << 9 | uj.  Returns non-zero if the operator is outside the kernel's domain (schedule left
 // invalid; callers use the general kernels).
+// axis 3: xtab / ytab = device conv_up tables (splat2_convtab) along x and y, xd = x-space dims.
 int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, Dim3i dd, float tol,
-                 const SplatSafety &safe, int axis, int rows_y);
+                 const SplatSafety &safe, int axis, int rows_y, const float4 *xtab = nullptr,
+                 const float4 *ytab = nullptr, Dim3i xd = Dim3i{0, 0, 0});
 void splat2_free(SplatSched &S);
 
 int splat2_blocks(Dim3i dd);
@@ -51,7 +60,8 @@ int splat2_blocks(Dim3i dd);
 // (axis 0); tab_step: elements between the two x-space values of a grid voxel (axis 0 / 1).
 // Non-zero return: nothing launched.
 int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const float4 *tab_dev, int gn,
-                  unsigned row_stride, unsigned tab_step, const Affine &A, float alpha,
+                  unsigned row_stride, unsigned tab_step, unsigned xs_sy, unsigned xs_sx, const Affine &A,
+                  float alpha,
                   const PushEpilogue &ep, float *dst, Dim3i dd, const int *done, hipStream_t st);
 
 // host: conv_up table along `axis` (gn entries of 4 floats), same packing as gather2_ztab
