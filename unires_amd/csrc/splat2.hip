@@ -572,6 +572,10 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
     int eb = 0;        // first entry of the next instruction, relative to the tile
     S2_FENCE();
     constexpr int kU = 4;
+    // (Tried and dropped: a schedule whose groups of 2 / 4 consecutive instructions are mutually
+    // conflict-free, so that their LDS updates run as two rounds with all reads of a round in
+    // flight - the extra packing constraint costs lane fill (0.75 -> 0.65 / 0.40) and the round form
+    // 20-30 more VGPRs (occupancy 4 -> 3 waves per SIMD): 155 us instead of 88 us.)
     // A batch = kU instructions.  fetch(): segment-start masks -> mbcnt -> segment entry (LDS ring)
     // -> conv_up table -> ONE source load per lane and instruction, all issued back to back;
     // splat(): coordinates, weights and the two LDS update groups.  Two batches are in flight: the
