@@ -457,15 +457,19 @@ static int build_sched(unires_plan *pl, Repeat &R) {
   }
   (void)splat2_build(R.sched, R.Af, R.Afinv, R.dim_gf, pl->dy, pl->fov_tol, R.safe, axis, rows_y,
                      (const float4 *)R.xytab_dev[0], (const float4 *)R.xytab_dev[1], R.dim_x);
-  // the pull of the same operator (denoising: plain pull onto the grid; super-resolution: + conv_down)
-  if (pl->regime == UNIRES_REGIME_DENOISE)
-    (void)pull2_build(R.pplan, pl->dy, R.A, R.T, R.dim_g, R.dim_g);
-  else if (!R.sep)
-    (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tf, R.dim_x, R.dim_gf);
-  else
-    R.pplan.valid = false;
   (void)hipGetLastError();
   return UNIRES_OK;
+}
+
+// the pull of the same operator through the LDS-window kernel (denoising: plain pull onto the
+// grid; super-resolution: + conv_down); outside its domain the plan stays invalid
+static void build_pull(unires_plan *pl, Repeat &R) {
+  R.pplan.valid = false;
+  if (pl->regime == UNIRES_REGIME_DENOISE)
+    (void)pull2_build(R.pplan, pl->dy, R.A, R.T, R.dim_g, R.dim_g);
+  else if (pl->regime == UNIRES_REGIME_SUPERRES && !R.sep)
+    (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tf, R.dim_x, R.dim_gf);
+  (void)hipGetLastError();
 }
 
 static void free_sched(Repeat &R) {
@@ -549,6 +553,7 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
   for (Repeat &R : pl->reps) {
     int rc = upload_ztabs(pl, R);
     if (!rc) rc = build_sched(pl, R);
+    if (!rc) build_pull(pl, R);
     if (rc) {
       for (Repeat &Q : pl->reps) free_ztabs(Q), free_sched(Q);
       (void)hipFree(pl->ws);
@@ -601,6 +606,7 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   plan->reps[n] = tmp;
   rc = upload_ztabs(plan, plan->reps[n]);
   if (!rc) rc = build_sched(plan, plan->reps[n]);
+  if (!rc) build_pull(plan, plan->reps[n]);
   return rc;
 }
 

@@ -31,14 +31,18 @@
 namespace unires {
 
 constexpr int kP2SZ = 72, kP2SZ4 = kP2SZ / 4;  // z planes of a window (64 + drift + 2 + alignment)
-constexpr int kP2Items = 8;                     // 16-byte window pieces staged per thread (at most)
-constexpr int kP2TI = 8, kP2TJ = 8;             // grid rows per workgroup
+constexpr int kP2Items = 10;                    // 16-byte window pieces staged per thread (at most)
+constexpr int kP2TI = 8, kP2TJ = 8;             // grid rows per workgroup (profile along z only)
+constexpr int kP2Rows = 64;                     // ... and at most, in any layout
 
 struct P2Geom {
   Affine A;
   Dim3i sd, gd;
   int sk, m;         // stride along grid z, conv windows (x-space voxels) per chunk
   int nbj, nbc;      // workgroups along j and chunks along z (block = (bi * nbj + bj) * nbc + bc)
+  // rows of a workgroup: pi x pj grid rows = what oi x oj x-space rows need (stride si / sj,
+  // ni / nj taps along x / y; 8 x 8 rows, strides 1, when the profile runs along z only)
+  int pi, pj, oi, oj, si, sj, ni, nj;
   // sheared-plane form of the affine: x = pxi i + pxj j + sx gz + cx  (same for y)
   float pxi, pxj, sx, cx, pyi, pyj, sy, cy;
 };
@@ -49,10 +53,10 @@ constexpr int kP2Rec = 4 + 2 * kP2SZ4;
 __global__ void k_pull2_plan(P2Geom G, int nblk, int *__restrict__ rec) {
   const int blk = blockIdx.x * blockDim.x + threadIdx.x;
   if (blk >= nblk) return;
-  constexpr int TI = kP2TI, TJ = kP2TJ, SZ4 = kP2SZ4;
+  constexpr int SZ4 = kP2SZ4;
   const int bc = blk % G.nbc, bj = (blk / G.nbc) % G.nbj, bi = blk / (G.nbc * G.nbj);
-  const int i0 = bi * TI, j0 = bj * TJ;
-  const int i1 = min(i0 + TI, G.gd.x) - 1, j1 = min(j0 + TJ, G.gd.y) - 1;
+  const int i0 = bi * G.oi * G.si, j0 = bj * G.oj * G.sj;
+  const int i1 = min(i0 + G.pi, G.gd.x) - 1, j1 = min(j0 + G.pj, G.gd.y) - 1;
   const int k0 = bc * G.m * G.sk;
   const int npts = min(kWave, G.gd.z - k0);
   // z extent of the workgroup's samples: 8 vertices of the (i, j, k) box
@@ -87,9 +91,10 @@ struct P2Args {
   const float *src;
   const int *rec;
   P2Geom G;
-  float kz[UNIRES_MAX_TAPS];
+  float kz[UNIRES_MAX_TAPS], kx[UNIRES_MAX_TAPS], ky[UNIRES_MAX_TAPS];
   int nk;            // taps along grid z (1 with sk 1: no conv)
-  float se, so;      // even / odd x-space slice scaling along z (1, 1: none)
+  float se, so;      // even / odd x-space slice scaling (1, 1: none) ...
+  int sdim;          // ... along this x-space axis (-1: none)
   float *dst;
   Dim3i xd;
   float tol;
@@ -98,23 +103,27 @@ struct P2Args {
 };
 
 // NK, SK > 0: compile-time slice profile (7 taps stride 6 is the 6 mm / 1 mm case); 0: run-time
-template <int H, int NK, int SK>
+// GEN: profile along x and / or y as well (rows laid out pi x pj, separable conv over a
+// workgroup-wide scratch); otherwise 8 x 8 rows and a wave-private conv along z.
+template <int H, int NK, int SK, bool GEN>
 __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__restrict__ done) {
   if (done && *done) return;
   constexpr int SZ = kP2SZ, SZ4 = kP2SZ4, NW = kBlock / kWave, TI = kP2TI, TJ = kP2TJ;
-  constexpr int ROWS = TI * TJ, RPW = ROWS / NW, HALF = 8, SCR = kWave + 1;
-  static_assert(ROWS % NW == 0 && RPW % HALF == 0, "rows per wave");
+  constexpr int ROWS = kP2Rows, RPW = ROWS / NW, HALF = 8, SCR = kWave + 1;
+  static_assert(TI * TJ == ROWS && ROWS % NW == 0 && RPW % HALF == 0, "rows per wave");
   extern __shared__ __align__(16) float win[];  // W * H columns x SZ planes
   __shared__ int tab[SZ4 + 2];                  // per plane group: -(ox * H + oy) * SZ, in floats
   __shared__ int2 org[SZ4];
-  __shared__ float scr[NW][HALF][SCR];
+  __shared__ float scr[GEN ? ROWS : NW * HALF][SCR];  // pulled rows awaiting the conv
+  __shared__ unsigned char rowi[ROWS], rowj[ROWS];     // GEN: row -> (ri, rj)
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const P2Geom &G = P.G;
   // (each XCD walks one contiguous run of workgroups: neighbours share window columns in its L2)
   const int blk = xcd_chunked_block((int)blockIdx.x, (int)gridDim.x);
   const int bc = blk % G.nbc, bj = (blk / G.nbc) % G.nbj, bi = blk / (G.nbc * G.nbj);
-  const int i0 = bi * TI, j0 = bj * TJ;
+  const int i0 = GEN ? bi * G.oi * G.si : bi * TI, j0 = GEN ? bj * G.oj * G.sj : bj * TJ;
+  const int nrows = GEN ? G.pi * G.pj : ROWS;
   const int kk0 = bc * G.m, k0 = kk0 * G.sk;
   const int npts = min(kWave, G.gd.z - k0);  // grid points of this chunk along z
   const Dim3i sd = G.sd;
@@ -125,6 +134,10 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
     const int ox = rec[4 + 2 * tid], oy = rec[5 + 2 * tid];
     org[tid] = make_int2(ox, oy);
     tab[tid] = -(ox * H + oy) * SZ;
+  }
+  if (GEN && tid < ROWS) {
+    const int ri = tid / G.pj;
+    rowi[tid] = (unsigned char)ri, rowj[tid] = (unsigned char)(tid - ri * G.pj);
   }
   __syncthreads();
   // ---- stage the window: one 16-byte piece (4 planes of one column) per item; item n of the
@@ -196,7 +209,9 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
 #pragma unroll
     for (int r = 0; r < HALF; ++r) {
       const int row = wave * RPW + h0 + r;
-      const int i = min(i0 + row / TJ, G.gd.x - 1), j = min(j0 + row % TJ, G.gd.y - 1);
+      const int rr = GEN ? min(row, nrows - 1) : row;  // (rows past the layout replay the last one)
+      const int i = min(i0 + (GEN ? (int)rowi[rr] : row / TJ), G.gd.x - 1),
+                j = min(j0 + (GEN ? (int)rowj[rr] : row % TJ), G.gd.y - 1);
       const RowBase rb = affine_row(G.A, (float)i, (float)j);
       const float gx = fmaf(c0, kf, rb.x) + t0, gy = fmaf(c1, kf, rb.y) + t1, gz = fmaf(c2, kf, rb.z) + t2;
       const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
@@ -224,6 +239,11 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
       if (hv[0] + hv[HALF - 1] == 123.f) P.dst[0] = 1.f;
       continue;
     }
+    if (GEN) {  // keep the rows for the workgroup-wide separable conv below
+#pragma unroll
+      for (int r = 0; r < HALF; ++r) scr[wave * RPW + h0 + r][lane] = hv[r];
+      continue;
+    }
     if (plain) {  // no slice profile: the pulled rows are the output
 #pragma unroll
       for (int r = 0; r < HALF; ++r) {
@@ -236,13 +256,13 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private scratch: no barrier needed
 #pragma unroll
-    for (int r = 0; r < HALF; ++r) scr[wave][r][lane] = hv[r];
+    for (int r = 0; r < HALF; ++r) scr[wave * HALF + r][lane] = hv[r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int it = lane; it < HALF * G.m; it += kWave) {
       const int r = (int)(((float)it + 0.5f) * inv_m), win_i = it - r * G.m;  // exact: it < 2^20
       const int row = wave * RPW + h0 + r;
       const int i = i0 + row / TJ, j = j0 + row % TJ;
-      const float *h = &scr[wave][r][win_i * sk];
+      const float *h = &scr[wave * HALF + r][win_i * sk];
       float acc = 0.f;
       if (NK > 0) {
 #pragma unroll
@@ -253,6 +273,41 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
       const int kk = kk0 + win_i;
       acc *= (kk & 1) ? P.so : P.se;
       if (win_i < nout && i < G.gd.x && j < G.gd.y) P.dst[((size_t)i * xdy + j) * xdz + kk] = acc;
+    }
+  }
+  if (GEN) {
+    // ---- separable conv_down over the workgroup's rows: oi x oj x m x-space voxels ----
+    __syncthreads();
+    const int ojm = G.oj * G.m, nitem = G.oi * ojm;
+    const float inv_ojm = 1.f / (float)ojm;
+    const int ib = bi * G.oi, jb = bj * G.oj;
+    for (int it = tid; it < nitem; it += kBlock) {
+      const int a = (int)(((float)it + 0.5f) * inv_ojm), rem = it - a * ojm;
+      const int b = (int)(((float)rem + 0.5f) * inv_m), c = rem - b * G.m;
+      const int io = ib + a, jo = jb + b, ko = kk0 + c;
+      if (io >= P.xd.x || jo >= xdy || ko >= xdz) continue;
+      float acc = 0.f;
+      const int r0 = a * G.si * G.pj + b * G.sj;  // first row of the footprint
+      if (nk == 1 && G.nj == 1) {                 // profile along x only
+        const float *h = &scr[r0][c * sk];
+        for (int ta = 0; ta < G.ni; ++ta) acc += P.kx[ta] * h[ta * G.pj * SCR];
+      } else if (nk == 1 && G.ni == 1) {          // along y only
+        const float *h = &scr[r0][c * sk];
+        for (int tb = 0; tb < G.nj; ++tb) acc += P.ky[tb] * h[tb * SCR];
+      } else {
+        for (int ta = 0; ta < G.ni; ++ta) {
+          const float wa = P.kx[ta];
+          for (int tb = 0; tb < G.nj; ++tb) {
+            const float wab = wa * P.ky[tb];
+            const float *h = &scr[r0 + ta * G.pj + tb][c * sk];
+            float az = 0.f;
+            for (int tc = 0; tc < nk; ++tc) az += h[tc] * P.kz[tc];
+            acc += wab * az;
+          }
+        }
+      }
+      if (P.sdim >= 0) acc *= ((P.sdim == 0 ? io : (P.sdim == 1 ? jo : ko)) & 1) ? P.so : P.se;
+      P.dst[((size_t)io * xdy + jo) * xdz + ko] = acc;
     }
   }
 }
@@ -267,16 +322,16 @@ void pull2_free(PullPlan &Q) {
 // Geometry of the operator for this kernel; false: outside its domain.
 static bool p2_geometry(Dim3i sd, const Affine &A, const Taps &T, const Scaling &S, Dim3i xd, Dim3i gd,
                         P2Geom &G, int &W, int &H) {
-  // conv only along z (or none at all), scaling only along z
-  for (int d = 0; d < 2; ++d)
-    if (!(T.n[d] == 1 && T.s[d] == 1 && T.t[d][0] == 1.f)) return false;
-  if (S.dim >= 0 && S.dim != 2) return false;
-  if (T.n[2] > 32 || T.n[2] > kWave - 8 || T.s[2] > T.n[2]) return false;
-  if (gd.x != xd.x || gd.y != xd.y || gd.z != (xd.z - 1) * T.s[2] + T.n[2]) return false;
+  (void)S;
+  for (int d = 0; d < 3; ++d)
+    if (T.n[d] > 32 || T.s[d] > T.n[d] || T.n[d] < 1 || T.s[d] < 1) return false;
+  if (T.n[2] > kWave - 8) return false;
+  const int gdv[3] = {gd.x, gd.y, gd.z}, xdv[3] = {xd.x, xd.y, xd.z};
+  for (int d = 0; d < 3; ++d)
+    if (gdv[d] != (xdv[d] - 1) * T.s[d] + T.n[d]) return false;
   if (sd.numel() >= (1ull << 30) || !fits_fast_index(sd)) return false;
   const double a22 = A.m[10];
   if (!(fabs(a22) > 0.5)) return false;
-  constexpr int TI = kP2TI, TJ = kP2TJ;
   memset(&G, 0, sizeof(G));
   G.A = A, G.sd = sd, G.gd = gd;
   const double sxd = A.m[2] / a22, syd = A.m[6] / a22;
@@ -284,28 +339,51 @@ static bool p2_geometry(Dim3i sd, const Affine &A, const Taps &T, const Scaling 
   G.pyi = (float)(A.m[4] - syd * A.m[8]), G.pyj = (float)(A.m[5] - syd * A.m[9]);
   G.sx = (float)sxd, G.sy = (float)syd;
   G.cx = (float)(A.m[3] - sxd * A.m[11]), G.cy = (float)(A.m[7] - syd * A.m[11]);
-  // window extents: span of the rows over a plane group (z in [Zg - 1, Zg + 4)), + floor, + the
-  // upper corner, + rounding margin
-  const double ex = (TI - 1) * fabs(G.pxi) + (TJ - 1) * fabs(G.pxj) + 5.0 * fabs(sxd) + 0.05;
-  const double ey = (TI - 1) * fabs(G.pyi) + (TJ - 1) * fabs(G.pyj) + 5.0 * fabs(syd) + 0.05;
-  W = (int)floor(ex) + 3;
-  const int Hn = (int)floor(ey) + 3;
-  // z planes: span of gz over the workgroup + floor + upper corner + alignment of Z0 to 4
-  const double ez = (TI - 1) * fabs((double)A.m[8]) + (TJ - 1) * fabs((double)A.m[9]) + 63.0 * fabs(a22) + 0.05;
-  if ((int)floor(ez) + 2 + 3 + 1 > kP2SZ) return false;
-  if (W > 24 || Hn > 16) return false;
-  H = Hn <= 10 ? 10 : (Hn <= 12 ? 12 : 16);
-  if (W * H * kP2SZ4 > kP2Items * kBlock) return false;
-  if ((size_t)W * H * kP2SZ * sizeof(float) > 56 * 1024) return false;
+  G.si = T.s[0], G.sj = T.s[1], G.ni = T.n[0], G.nj = T.n[1];
   G.sk = T.s[2];
   G.m = (kWave - T.n[2]) / T.s[2] + 1;  // whole conv windows inside 64 grid points
-  G.nbj = (gd.y + TJ - 1) / TJ;
+  const bool zonly = T.n[0] == 1 && T.s[0] == 1 && T.n[1] == 1 && T.s[1] == 1;
+  // rows of a workgroup: the (oi, oj) with the most x-space rows per sampled grid row whose window
+  // fits; window extents = span of the rows over a plane group (z in [Zg - 1, Zg + 4)), + floor, +
+  // the upper corner, + rounding margin
+  auto extents = [&](int pi, int pj, int &w, int &hn) {
+    const double ex = (pi - 1) * fabs(G.pxi) + (pj - 1) * fabs(G.pxj) + 5.0 * fabs(sxd) + 0.05;
+    const double ey = (pi - 1) * fabs(G.pyi) + (pj - 1) * fabs(G.pyj) + 5.0 * fabs(syd) + 0.05;
+    w = (int)floor(ex) + 3, hn = (int)floor(ey) + 3;
+  };
+  auto fits = [&](int pi, int pj, int &w, int &h) {
+    int hn;
+    extents(pi, pj, w, hn);
+    // z planes: span of gz over the workgroup + floor + upper corner + alignment of Z0 to 4
+    const double ez = (pi - 1) * fabs((double)A.m[8]) + (pj - 1) * fabs((double)A.m[9]) + 63.0 * fabs(a22) + 0.05;
+    if ((int)floor(ez) + 2 + 3 + 1 > kP2SZ) return false;
+    if (w > 24 || hn > 16) return false;
+    h = hn <= 10 ? 10 : (hn <= 12 ? 12 : 16);
+    if (w * h * kP2SZ4 > kP2Items * kBlock) return false;
+    return (size_t)w * h * kP2SZ * sizeof(float) <= (zonly ? 56u : 40u) * 1024u;
+  };
+  if (zonly) {
+    G.pi = G.oi = kP2TI, G.pj = G.oj = kP2TJ;
+    if (!fits(G.pi, G.pj, W, H)) return false;
+  } else {
+    double best = 0.0;
+    for (int oi = 1; oi <= 16; ++oi)
+      for (int oj = 1; oj <= 16; ++oj) {
+        const int pi = (oi - 1) * T.s[0] + T.n[0], pj = (oj - 1) * T.s[1] + T.n[1];
+        int w, h;
+        if (pi > 16 || pj > 16 || pi * pj > kP2Rows || !fits(pi, pj, w, h)) continue;
+        const double score = (double)(oi * T.s[0]) * (oj * T.s[1]) / (pi * pj) + 1e-3 * (oi * oj);
+        if (score > best) best = score, G.oi = oi, G.oj = oj, G.pi = pi, G.pj = pj, W = w, H = h;
+      }
+    if (best == 0.0) return false;
+  }
+  G.nbj = (xd.y + G.oj - 1) / G.oj;
   G.nbc = (xd.z + G.m - 1) / G.m;
   return true;
 }
 
-static long long p2_blocks(const P2Geom &G) {
-  return (long long)((G.gd.x + kP2TI - 1) / kP2TI) * G.nbj * G.nbc;
+static long long p2_blocks(const P2Geom &G, Dim3i xd) {
+  return (long long)((xd.x + G.oi - 1) / G.oi) * G.nbj * G.nbc;
 }
 
 int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd, Dim3i gd) {
@@ -315,7 +393,7 @@ int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd,
   P2Geom G;
   int W, H;
   if (!p2_geometry(sd, A, T, Scaling{1.f, 1.f, -1}, xd, gd, G, W, H)) return 1;
-  const long long nblk = p2_blocks(G);
+  const long long nblk = p2_blocks(G, xd);
   if (nblk > 0x3fffffffll) return 1;
   if ((size_t)nblk > Q.cap) {
     if (Q.rec) (void)hipFree(Q.rec);
@@ -344,21 +422,30 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
   memcpy(&key, Q.key, sizeof(key));
   if (!same_geom(key, P.G)) return 1;  // the plan was built for another operator
   P.src = src, P.rec = Q.rec;
-  for (int i = 0; i < UNIRES_MAX_TAPS; ++i) P.kz[i] = i < T.n[2] ? T.t[2][i] : 0.f;
+  for (int i = 0; i < UNIRES_MAX_TAPS; ++i) {
+    P.kz[i] = i < T.n[2] ? T.t[2][i] : 0.f;
+    P.kx[i] = i < T.n[0] ? T.t[0][i] : 0.f;
+    P.ky[i] = i < T.n[1] ? T.t[1][i] : 0.f;
+  }
   P.nk = T.n[2];
-  P.se = S.dim == 2 ? S.e : 1.f, P.so = S.dim == 2 ? S.o : 1.f;
+  const bool gen = !(T.n[0] == 1 && T.s[0] == 1 && T.n[1] == 1 && T.s[1] == 1);
+  if (!gen && S.dim >= 0 && S.dim != 2) return 1;  // (the wave-private conv scales along z only)
+  P.sdim = S.dim;
+  P.se = S.dim >= 0 ? S.e : 1.f, P.so = S.dim >= 0 ? S.o : 1.f;
   P.dst = dst, P.xd = xd, P.tol = tol, P.W = W;
   static const int dbg = getenv("UNIRES_P2_DBG") ? atoi(getenv("UNIRES_P2_DBG")) : 0;
   P.dbg = dbg;
   const size_t lds = (size_t)W * H * kP2SZ * sizeof(float);
-  const dim3 grid((unsigned)p2_blocks(P.G)), block(kBlock);
+  const dim3 grid((unsigned)p2_blocks(P.G, xd)), block(kBlock);
   const bool k76 = T.n[2] == 7 && T.s[2] == 6;
-#define P2_LAUNCH(HH)                                                                     \
-  do {                                                                                    \
-    if (k76)                                                                              \
-      hipLaunchKernelGGL((k_pull_conv2<HH, 7, 6>), grid, block, lds, st, P, done);        \
-    else                                                                                  \
-      hipLaunchKernelGGL((k_pull_conv2<HH, 0, 0>), grid, block, lds, st, P, done);        \
+#define P2_LAUNCH(HH)                                                                        \
+  do {                                                                                       \
+    if (gen)                                                                                 \
+      hipLaunchKernelGGL((k_pull_conv2<HH, 0, 0, true>), grid, block, lds, st, P, done);     \
+    else if (k76)                                                                            \
+      hipLaunchKernelGGL((k_pull_conv2<HH, 7, 6, false>), grid, block, lds, st, P, done);    \
+    else                                                                                     \
+      hipLaunchKernelGGL((k_pull_conv2<HH, 0, 0, false>), grid, block, lds, st, P, done);    \
   } while (0)
   if (H == 10)
     P2_LAUNCH(10);
