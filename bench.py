@@ -136,7 +136,7 @@ def pmc_traffic(workload):
     """HBM bytes per matvec launch from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE in separate runs; gfx950 FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes).  None if no profile of this workload is committed."""
-    for name in ('r01_traffic.json', 'r01_traffic_aligned.json'):
+    for name in ('r02_traffic.json', 'r01_traffic_aligned.json'):
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if rec.get('workload') == workload:

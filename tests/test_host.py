@@ -177,3 +177,26 @@ def test_device_guard_finds_the_tensor_device_and_is_transparent_on_cpu():
     # the decorated entry points keep their names / docstrings
     assert _update._update_y.__name__ == '_update_y' and 'UPDATE: y' in _update._update_y.__doc__
     assert _plan.ChannelPlan.matvec.__name__ == 'matvec'
+
+
+def test_spatial_facade_recovers_the_affine_of_a_dense_grid():
+    """nitorch-style calls hand over a dense (1, X, Y, Z, 3) grid; the path only ever builds affine
+    grids (unires/_project.py:159), so the facade recovers the matrix and refuses anything else."""
+    import torch
+    from unires_amd import spatial
+    from tests.helpers import rigid_matrix
+    M = rigid_matrix([1.5, -2.0, 0.7], [0.03, -0.05, 0.08])
+    M[:3, :3] *= 1.3
+    shape = (7, 6, 5)
+    g = spatial.affine_grid(M, shape)
+    assert g.shape == shape + (3,) and g.dtype == torch.float32
+    mat, shp = spatial._affine_of_grid(g[None])
+    assert shp == shape and torch.allclose(mat, M, atol=1e-5)
+    bent = g.clone()
+    bent[3, 2, 2, 0] += 0.5
+    import pytest
+    with pytest.raises(NotImplementedError):
+        spatial._affine_of_grid(bent)
+    from unires_amd._util import _bids_name
+    assert _bids_name('/a/b/sub-01_T1w.nii') == '/a/b/sub-01_space-unires_T1w.nii'
+    assert _bids_name('img.nii.gz') == 'space-unires_img.nii.gz'
