@@ -80,8 +80,8 @@ def grid_pull(inp, grid, interpolation='linear', bound='zero', extrapolate=False
     extrapolate=False the result is multiplied by the mask
     ``g_d > -tol & g_d < n_d - 1 + tol`` (tol = 5e-2).
     """
-    if interpolation not in ('linear', 1) or bound != 'zero':
-        raise NotImplementedError('oracle restates linear/zero only')
+    if interpolation not in ('linear', 1, 0, 'nearest') or bound != 'zero':
+        raise NotImplementedError('oracle restates linear / nearest, zero bound only')
     B, C = inp.shape[:2]
     shape = inp.shape[2:]
     nx, ny, nz = shape
@@ -89,6 +89,17 @@ def grid_pull(inp, grid, interpolation='linear', bound='zero', extrapolate=False
     for b in range(B):
         g = grid[b if grid.shape[0] > 1 else 0]
         gx, gy, gz = g.unbind(-1)
+        if interpolation in (0, 'nearest'):
+            # order 0 (the call at unires/_update.py:592-598, always at integer coordinates D u):
+            # the voxel at round(g), zero outside the volume  [recalled]
+            ix, iy, iz = torch.round(gx).long(), torch.round(gy).long(), torch.round(gz).long()
+            ok = (ix >= 0) & (ix < nx) & (iy >= 0) & (iy < ny) & (iz >= 0) & (iz < nz)
+            idx = (ix.clamp(0, nx - 1) * ny + iy.clamp(0, ny - 1)) * nz + iz.clamp(0, nz - 1)
+            acc = inp[b].reshape(C, -1)[:, idx.reshape(-1)].reshape((C,) + gx.shape) * ok.to(inp.dtype)
+            if not extrapolate:
+                acc = acc * _fov_mask(g, shape, fov_tol).to(inp.dtype)
+            out.append(acc)
+            continue
         x0, x1, wx, okx0, okx1 = _corners(gx, nx)
         y0, y1, wy, oky0, oky1 = _corners(gy, ny)
         z0, z1, wz, okz0, okz1 = _corners(gz, nz)
@@ -111,8 +122,8 @@ def grid_grad(inp, grid, interpolation='linear', bound='zero', extrapolate=False
     """Spatial gradient of the trilinear sample w.r.t. the voxel coordinate  [recalled]:
     (B, C, X', Y', Z', 3).  Out-of-volume corners count as zeros; with extrapolate=False the
     in-FOV mask multiplies the result (call site unires/_update.py:508)."""
-    if interpolation not in ('linear', 1) or bound != 'zero':
-        raise NotImplementedError('oracle restates linear/zero only')
+    if interpolation not in ('linear', 1, 0, 'nearest') or bound != 'zero':
+        raise NotImplementedError('oracle restates linear / nearest, zero bound only')
     B, C = inp.shape[:2]
     shape = inp.shape[2:]
     nx, ny, nz = shape
@@ -120,6 +131,17 @@ def grid_grad(inp, grid, interpolation='linear', bound='zero', extrapolate=False
     for b in range(B):
         g = grid[b if grid.shape[0] > 1 else 0]
         gx, gy, gz = g.unbind(-1)
+        if interpolation in (0, 'nearest'):
+            # order 0 (the call at unires/_update.py:592-598, always at integer coordinates D u):
+            # the voxel at round(g), zero outside the volume  [recalled]
+            ix, iy, iz = torch.round(gx).long(), torch.round(gy).long(), torch.round(gz).long()
+            ok = (ix >= 0) & (ix < nx) & (iy >= 0) & (iy < ny) & (iz >= 0) & (iz < nz)
+            idx = (ix.clamp(0, nx - 1) * ny + iy.clamp(0, ny - 1)) * nz + iz.clamp(0, nz - 1)
+            acc = inp[b].reshape(C, -1)[:, idx.reshape(-1)].reshape((C,) + gx.shape) * ok.to(inp.dtype)
+            if not extrapolate:
+                acc = acc * _fov_mask(g, shape, fov_tol).to(inp.dtype)
+            out.append(acc)
+            continue
         x0, x1, wx, okx0, okx1 = _corners(gx, nx)
         y0, y1, wy, oky0, oky1 = _corners(gy, ny)
         z0, z1, wz, okz0, okz1 = _corners(gz, nz)

@@ -47,9 +47,10 @@ def apply_scaling(dat, scl, dim):
 # unires/_project.py:193-297
 # --------------------------------------------------------------------------
 def proj_info(dim_y, mat_y, dim_x, mat_x, rigid=None, prof_ip=0, prof_tp=0, gap=0.0,
-              scl=0.0, gauss_lim=None):
-    """Projection-operator descriptor (the ``samp>0`` branch, :245-264, is only
-    used by the rigid Gauss-Newton and is out of scope)."""
+              scl=0.0, gauss_lim=None, samp=0):
+    """Projection-operator descriptor; ``samp > 0``: the sub-sampling branch (:245-264) the rigid
+    Gauss-Newton uses (low-res side only: the high-res branch is dead code, :255 compares vx_x
+    with itself)."""
     dt = torch.float64
     po = SimpleNamespace()
     mat_y = torch.as_tensor(mat_y, dtype=dt)
@@ -66,6 +67,14 @@ def proj_info(dim_y, mat_y, dim_x, mat_x, rigid=None, prof_ip=0, prof_tp=0, gap=
     gap_cn[dim_thick] = gap                                    # :242
     profile[dim_thick] = prof_tp                               # :243
     po.dim_thick = dim_thick
+    po.D_x = None
+    if samp > 0:                                               # :245-253, :264
+        one = torch.ones(ndim, dtype=dt)
+        sk = torch.max(one, torch.floor(samp * one / po.vx_x + 0.5))
+        po.D_x = torch.diag(torch.cat((sk, one[0, None])))
+        mat_x = mat_x.mm(po.D_x)
+        dim_x_t = po.D_x.inverse()[:ndim, :ndim].mm(dim_x_t[..., None]).floor().squeeze()
+        po.mat_x, po.vx_x = mat_x, voxel_size(mat_x)
     ratio = torch.linalg.solve(mat_y, mat_x)                   # :266
     ratio = (ratio[:ndim, :ndim] ** 2).sum(0).sqrt()           # :267
     ratio = ratio.ceil().clamp(1)                              # :268
@@ -542,10 +551,13 @@ def rigid_match(dat_x, dat_y, po, tau, rigid, method, CtC=None, diff=False):
     return ll, gr, Hes
 
 
-def update_rigid_channel(xc, yc, method, basis, max_niter_gn=1, num_linesearch=4):
-    """_update_rigid_channel (:541-710) for D_x = I (samp / voxel size < 1.5: the
-    nearest-neighbour resample of the data is a copy, :589-601); xc[n].po is used where the
-    reference rebuilds an identical one (:575-578)."""
+def update_rigid_channel(xc, yc, method, basis, max_niter_gn=1, num_linesearch=4, samp=0,
+                         prof_ip=0, prof_tp=0, gap=0.0):
+    """_update_rigid_channel (:541-710).  ``samp = 0``: xc[n].po is used where the reference
+    rebuilds an identical one (:575-578).  ``samp > 0``: po is rebuilt with the sub-sampling branch
+    of _proj_info and the low-res data resampled onto the decimated lattice (:589-593: grid_pull
+    at the integer coordinates D_x u with interpolation 0 = a strided slice); the high-res side is
+    never resampled (D_y stays None, see proj_info)."""
     import torch.nn.functional as F
     from .nitorch_restated import affine_grid
     num_q = basis.shape[0]
@@ -558,6 +570,12 @@ def update_rigid_channel(xc, yc, method, basis, max_niter_gn=1, num_linesearch=4
         tau = xc[n_x].tau
         armijo = torch.tensor(1, dtype=q.dtype)
         po = xc[n_x].po
+        if samp > 0:                                                                 # :575-593
+            po0 = xc[n_x].po
+            po = proj_info(po0.dim_y, po0.mat_y, po0.dim_x, po0.mat_x, rigid=po0.rigid, prof_ip=prof_ip,
+                           prof_tp=prof_tp, gap=gap, scl=po0.scl, samp=samp)
+            sk = [int(v) for v in torch.diagonal(po.D_x)[:3].tolist()]
+            dat_x = dat_x[::sk[0], ::sk[1], ::sk[2]][:po.dim_x[0], :po.dim_x[1], :po.dim_x[2]]
         if method == 'super-resolution':
             dim, mat = tuple(po.dim_yx), po.mat_yx
         else:
@@ -617,12 +635,12 @@ def update_rigid_channel(xc, yc, method, basis, max_niter_gn=1, num_linesearch=4
     return xc, sll
 
 
-def update_rigid(x, y, method, basis, mean_correct=True, max_niter_gn=1, num_linesearch=4):
+def update_rigid(x, y, method, basis, mean_correct=True, max_niter_gn=1, num_linesearch=4, samp=0):
     """_update_rigid (:198-266)."""
     sll = torch.tensor(0, dtype=torch.float64)
     for c in range(len(x)):
         x[c], sllc = update_rigid_channel(x[c], y[c], method, basis, max_niter_gn=max_niter_gn,
-                                          num_linesearch=num_linesearch)
+                                          num_linesearch=num_linesearch, samp=samp)
         sll = sll + sllc
     if mean_correct:
         qs = [xn.rigid_q for xc in x for xn in xc]

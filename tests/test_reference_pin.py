@@ -18,7 +18,7 @@ from oracle import unires_restated as O
 from tests.helpers import rel_err
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = ['ref_sr_2ch', 'ref_sr_2rep', 'ref_dn_1ch', 'ref_id_2rep']
+CASES = ['ref_sr_2ch', 'ref_sr_2rep', 'ref_dn_1ch', 'ref_id_2rep', 'ref_sr_fine']
 TOL = 1e-6
 
 
@@ -96,7 +96,7 @@ def _after_admm(g, x, y, method, do_proj, tag='_a15'):
     return y
 
 
-@pytest.mark.parametrize('name', ['ref_sr_2ch', 'ref_sr_2rep'])
+@pytest.mark.parametrize('name', ['ref_sr_2ch', 'ref_sr_2rep', 'ref_sr_fine'])
 def test_update_scaling(name):
     """_update_scaling (:270-393): two Gauss-Newton iterations with line search."""
     g, method, do_proj, dim_y, x, y = load_case(name)
@@ -108,14 +108,15 @@ def test_update_scaling(name):
             np.testing.assert_allclose(float(xn.po.scl), float(g['scl1_%d_%d' % (c, n)]), rtol=1e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize('name', ['ref_sr_2ch', 'ref_sr_2rep', 'ref_dn_1ch'])
+@pytest.mark.parametrize('name', ['ref_sr_2ch', 'ref_sr_2rep', 'ref_dn_1ch', 'ref_sr_fine'])
 def test_update_rigid_channel(name):
     """_update_rigid_channel (:541-710), no sub-sampling, same se(3) basis as the fixture."""
     g, method, do_proj, dim_y, x, y = load_case(name)
     y = _after_admm(g, x, y, method, do_proj)
     basis = torch.from_numpy(g['basis'])
     for c in range(len(x)):
-        xc, sll = O.update_rigid_channel(x[c], y[c], method, basis, max_niter_gn=1, num_linesearch=4)
+        xc, sll = O.update_rigid_channel(x[c], y[c], method, basis, max_niter_gn=1, num_linesearch=4,
+                                         samp=int(g['rigid_samp']))
         np.testing.assert_allclose(float(sll), float(g['rig_sll_%d' % c]), rtol=1e-6)
         for n, xn in enumerate(xc):
             np.testing.assert_allclose(xn.rigid_q.numpy(), g['rig_q1_%d_%d' % (c, n)], rtol=1e-5, atol=1e-8)

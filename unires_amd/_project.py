@@ -45,15 +45,20 @@ def _proj_info(dim_y, mat_y, dim_x, mat_x, rigid=None, prof_ip=0, prof_tp=0, gap
         else torch.as_tensor(rigid).detach().to('cpu', _F64)
     po.D_x = po.D_y = None
     if samp > 0:
-        # sub-sampling for the rigid Gauss-Newton (unires/_project.py:245-264): the low-res
-        # image is decimated by sk = max(1, floor(samp / vx_x + 0.5)); the high-res branch is
-        # dead code in the reference (:255 compares vx_x with itself).  Built: sk = 1 (any
-        # voxel size >= 2/3 samp), where the decimation is the identity.
+        # sub-sampling for the rigid Gauss-Newton (unires/_project.py:245-264): the low-res image is
+        # decimated by sk = max(1, floor(samp / vx_x + 0.5)) voxels per axis: mat_x <- mat_x D_x,
+        # dim_x <- floor(dim_x / sk).  (The high-res branch is dead code in the reference - :255
+        # compares vx_x with itself - so D_y stays None.)  po.sk is the decimation the caller
+        # applies to the data: nearest-neighbour pull at the integer coordinates D_x u = a strided
+        # slice (unires/_update.py:589-593).
         sk = torch.clamp(torch.floor(float(samp) / po.vx_x + 0.5), min=1.0)
-        if bool((sk != 1).any()):
-            raise NotImplementedError('rigid Gauss-Newton on decimated data (samp / voxel size '
-                                      '>= 1.5) is not built')
-        po.D_x = torch.eye(4, dtype=_F64)
+        po.sk = tuple(int(v) for v in sk.tolist())
+        po.D_x = torch.diag(torch.cat((sk, torch.ones(1, dtype=_F64))))
+        mat_x = mat_x.mm(po.D_x)
+        dim_x = tuple(int(math.floor(d / k)) for d, k in zip(dim_x, po.sk))
+        if min(dim_x) < 1:
+            raise ValueError('sub-sampling leaves an empty image')
+        po.dim_x, po.mat_x, po.vx_x = dim_x, mat_x, voxel_size(mat_x)
     # thick-slice axis and per-axis profile / gap
     po.dim_thick = int(torch.max(po.vx_x, dim=0)[1])
     profile = [int(prof_ip)] * 3

@@ -165,7 +165,10 @@ def _update_rigid_channel(xc, yc, sett, max_niter_gn=1, num_linesearch=4, verbos
                         device=dev, scl=xn.po.scl, samp=samp)
         mat = po.mat_yx if method == 'super-resolution' else po.mat_x
         dim = tuple(po.dim_yx) if method == 'super-resolution' else tuple(po.dim_x)
-        dat_x = xn.dat.contiguous()       # D_x = I: the nearest-neighbour resample is a copy
+        # nearest-neighbour resample of the data onto the decimated lattice (unires/_update.py:589-593:
+        # grid_pull at the integer coordinates D_x u, interpolation 0) = a strided slice
+        sk = getattr(po, 'sk', (1, 1, 1))
+        dat_x = xn.dat[::sk[0], ::sk[1], ::sk[2]][:po.dim_x[0], :po.dim_x[1], :po.dim_x[2]].contiguous()
         dat_y = yc.dat
         CtC = _ctc(po, dim, dev) if method == 'super-resolution' else None
         ll = torch.zeros((), dtype=_F64, device=dev)
