@@ -167,14 +167,22 @@ class ChannelPlan:
         rigid / scaling / tau changes).  The reference recomputes it every ADMM iteration
         (unires/_update.py:125-128)."""
         xs = [_vol(t, 'x')[0] for t in x_dats]
-        key = tuple((t.data_ptr(), t._version) for t in xs)
+        # The cache is keyed on the caller's tensor OBJECTS (weak references) and their version
+        # counters - not on addresses: a new tensor can land on a freed tensor's address with version
+        # 0.  An observation that had to be copied to become contiguous is never cached.
+        import weakref
+        copied = any(v is not t and v.data_ptr() != t.data_ptr() for v, t in zip(xs, x_dats))
+        key = None if copied else tuple((id(t), t._version) for t in x_dats)
         cache = getattr(self, '_atx', None)
-        if cache is None or cache[0] != key:
+        alive = cache is not None and all(r() is t for r, t in zip(cache[2], x_dats)) \
+            and len(cache[2]) == len(x_dats)
+        if cache is None or key is None or not alive or cache[0] != key:
             atx = cache[1] if cache is not None else torch.empty(self.dim_y, dtype=torch.float32,
                                                                  device=xs[0].device)
             ptrs = (C.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
             check(self.lib.unires_atx_assemble(self._h, ptrs, _ptr(atx), _stream()))
-            self._atx = cache = (key, atx)
+            refs = [] if key is None else [weakref.ref(t) for t in x_dats]
+            self._atx = cache = (key, atx, refs)
         w_c, z_c = w_c.contiguous(), z_c.contiguous()
         check(self.lib.unires_rhs_from_atx(self._h, _ptr(cache[1]), _ptr(w_c), _ptr(z_c),
                                            float(rho), float(lam), _ptr(out), _stream()))

@@ -315,6 +315,15 @@ struct unires_plan {
   bool prec_ready = false;
 };
 
+// Drop the captured CG solve.  A launch of it may still be in flight (the ADMM loop never syncs):
+// wait for the device before destroying the executable graph.
+static void drop_cg_graph(unires_plan *pl) {
+  if (!pl->cg_exec) return;
+  (void)hipDeviceSynchronize();
+  (void)hipGraphExecDestroy(pl->cg_exec);
+  pl->cg_exec = nullptr;
+}
+
 static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat &out) {
   if (!in) return fail(UNIRES_ERR_NULL, "null repeat descriptor");
   if (!(in->tau > 0.f)) return fail(UNIRES_ERR_ARG, "tau must be positive");
@@ -588,10 +597,7 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
     return fail(UNIRES_ERR_DIM, "new repeat exceeds the plan's workspace");
   if (plan->regime == UNIRES_REGIME_SUPERRES && tmp.sep && !plan->gbuf2)
     return fail(UNIRES_ERR_DIM, "new repeat needs the separable-conv scratch the plan was built without");
-  if (plan->cg_exec) {  // the captured solve has the old operator baked in
-    (void)hipGraphExecDestroy(plan->cg_exec);
-    plan->cg_exec = nullptr;
-  }
+  drop_cg_graph(plan);  // the captured solve has the old operator baked in
   plan->prec_ready = false;  // a preconditioner built for the old operator is stale
   if (tmp.dim_gf.z != plan->reps[n].dim_gf.z) free_ztabs(plan->reps[n]);
   tmp.ztab_dev[0] = plan->reps[n].ztab_dev[0];
@@ -834,14 +840,17 @@ extern "C" int unires_ata_matvec(unires_plan_t *plan, float rho, float lam, cons
 extern "C" int unires_precond_build(unires_plan_t *plan, int32_t precond_mode, float rho,
                                     float lam, float *m_out, void *stream) {
   if (!plan) return fail(UNIRES_ERR_NULL, "null plan");
-  if (plan->cg_exec) {
-    (void)hipGraphExecDestroy(plan->cg_exec);
-    plan->cg_exec = nullptr;
-  }
+  // The ADMM loop asks for the preconditioner every iteration: nothing to do while the mode,
+  // rho, lam and the operator (set_repeat clears prec_ready) are what it was built for.  The
+  // captured CG solve survives a rebuild too: it reads the diagonal at run time and its key
+  // holds the mode, rho and lam.
   if (precond_mode == UNIRES_PRECOND_IDENTITY) {
     plan->prec_ready = false;
     return UNIRES_OK;
   }
+  if (plan->prec_ready && plan->prec_mode == precond_mode && plan->prec_rho == rho && plan->prec_lam == lam &&
+      !m_out)
+    return UNIRES_OK;
   if (precond_mode != UNIRES_PRECOND_JACOBI && precond_mode != UNIRES_PRECOND_FFT)
     return fail(UNIRES_ERR_UNSUPPORTED, "preconditioner modes: identity (0), Jacobi (1), FFT (2)");
   hipStream_t st = (hipStream_t)stream;
@@ -1039,8 +1048,7 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
     bool capturing = false;
     if (graphable) {
       if (pl->cg_exec) {
-        (void)hipGraphExecDestroy(pl->cg_exec);
-        pl->cg_exec = nullptr;
+        drop_cg_graph(pl);
       }
       capturing = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
       if (!capturing) (void)hipGetLastError();
