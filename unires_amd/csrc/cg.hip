@@ -205,6 +205,11 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ---- scalar kernels: <<<1, kBlock>>> -------------------------------------
+// (Tried and dropped, r2: folding k_sc_alpha / k_sc_beta into the kernels that write their
+// partials - every workgroup takes a ticket, the last one sums all partials in a fixed order.  The
+// ticket needs an agent-scope release so that the partials of workgroups on other XCDs are visible,
+// and on gfx950 that is an L2 write-back per workgroup: config 3 fell from 4 200 to 1 550 CG
+// iterations/s, the aligned variant from 6 400 to 1 800.  Two 5 us launches per iteration it is.)
 __device__ __forceinline__ double sum_partials(const double *part, int g) {
   // loads batched eight deep (the additions keep their order): this one-block kernel is pure
   // latency, and sixteen dependent load->add steps per thread were most of its 6 us

@@ -437,6 +437,21 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
     return 1;
   }
   S.ntiles = nt;
+  {
+    // contiguous runs of tiles per XCD with equal cost.  Cost of a tile = its instructions + the
+    // epilogue (~5 us against ~0.45 us per instruction in tools/s2_timeline.py); with equal tile
+    // COUNTS the XCD that holds the volume's first x slabs had a third less to do than the others.
+    constexpr double kEpilogueCost = 11.0;
+    const double total = (double)ri + kEpilogueCost * nt;
+    int x = 1;
+    S.xcd_lo[0] = 0;
+    for (int i = 0; i < nt && x < 8; ++i) {
+      const double cum = (double)h[i + 1].y + kEpilogueCost * (i + 1);
+      while (x < 8 && cum >= total * x / 8.0) S.xcd_lo[x++] = i + 1;
+    }
+    for (; x <= 8; ++x) S.xcd_lo[x] = nt;
+    S.xcd_lo[8] = nt;
+  }
   S.axis = axis;
   S.fill = hs[1] ? (double)hs[0] / (64.0 * (double)hs[1]) : 0.0;
   S.valid = true;
@@ -496,6 +511,8 @@ struct S2Args {
   double *partials;
   const float *objb;
   int dbg;  // UNIRES_S2_DBG ablation bits (read only by -DUNIRES_ABLATE builds)
+  int xlo[9];  // tile range [xlo[x], xlo[x + 1]) of partition x (an XCD when the grid has >= 8 workgroups)
+  unsigned long long *prof;  // -DUNIRES_S2_PROF builds: per-wave timeline (100 MHz ticks)
 };
 
 template <int AXIS>
@@ -528,23 +545,25 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
     __syncthreads();
   }
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(P.src, P.src_bytes);
-  const int ntiles = P.ntiles;
   // XCD-aware persistent schedule: workgroup b sits on XCD b % 8; each XCD walks one contiguous
   // run of tiles so that neighbouring tiles (shared stencil halos, schedule lines) share an L2.
   // (Tried and dropped: a contiguous, cost-balanced range of tiles per wave - 103 us instead of
   // 95 us: waves that sweep the run together share cache lines, waves far apart do not.)
   const int nxcd = min(8, (int)gridDim.x);
-  const int per_xcd = (ntiles + nxcd - 1) / nxcd;
   const int xcd = blockIdx.x % nxcd;
+  const int t_lo = P.xlo[xcd], t_hi = P.xlo[xcd + 1];
   const int slot = (blockIdx.x / nxcd) * kS2Waves + wave;
   const int slots = ((gridDim.x + nxcd - 1 - xcd) / nxcd) * kS2Waves;
   const float c0 = P.A.m[2], c1 = P.A.m[6], c2 = P.A.m[10];
   const float t0 = P.A.m[3], t1 = P.A.m[7], t2 = P.A.m[11];
   const int lane_m64 = lane - 64;
   double dot = 0.0;
-  for (int tl = slot; tl < per_xcd; tl += slots) {
-    const int t = xcd * per_xcd + tl;
-    if (t >= ntiles) break;
+#ifdef UNIRES_S2_PROF
+  unsigned long long *pw = P.prof ? P.prof + (size_t)(blockIdx.x * kS2Waves + wave) * 32 : nullptr;
+  int ptile = 0;
+  if (pw && lane == 0) pw[0] = wall_clock64();
+#endif
+  for (int t = t_lo + slot; t < t_hi; t += slots) {
     const S2TileGeom g = s2_tile(t, dd);
     const int x0 = g.x0, y0 = g.y0, z0 = g.z0, ex = g.ex, ey = g.ey, ez = g.ez;
     const uint2 off0 = P.tile_off[t], off1 = P.tile_off[t + 1];
@@ -694,6 +713,13 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
       }
     };
     if (ninstr > 0 && !S2_ABL(1)) {
+      // (Measured, r2: the branches around the fetches make the compiler's wait-count pass put
+      // s_waitcnt vmcnt(0) in front of every splat, so a batch also waits for the source loads of
+      // the next one.  A branch-free body - fetch / splat / fetch / splat with slots past the end
+      // switched off - gets vmcnt(4..7) there and is no faster, 92 vs 90 us: the stream is not bound
+      // by that latency but by VALU issue (~58 % of a SIMD) and LDS (~57 % of a CU) together, see
+      // tools/s2_timeline.py.  Same outcome for a dynamic tile queue, a staggered start of half the
+      // waves and a prefetch of the next tile's schedule: 90 - 92 us each.)
       Batch ba, bb;
       fetch(ba, 0);
       for (int p0 = 0; p0 < ninstr; p0 += 2 * kU) {
@@ -707,12 +733,17 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
       }
     }
     S2_FENCE();
+#ifdef UNIRES_S2_PROF
+    if (pw && lane == 0 && ptile < 9) pw[3 + 3 * ptile] = wall_clock64(), pw[5 + 3 * ptile] = (unsigned long long)ninstr;
+#endif
     // ---- epilogue: q = [q +] acc + a0 p + c DtD p ; dot += p*q  (one row per lane group) ----
     if (S2_ABL(2)) continue;
-    const bool fast_xy = pin != nullptr && !P.accumulate && x0 > 0 && y0 > 0 &&
-                         x0 + TX < dd.x && y0 + TY < dd.y && dd.numel() < (1ull << 29);
+    const bool fast_xy = pin != nullptr && !P.accumulate && ex == TX && y0 > 0 && y0 + TY < dd.y &&
+                         dd.numel() < (1ull << 29);
     if (fast_xy) {
-      // Interior tiles (all x / y stencil neighbours inside the volume).  Lane gl of a group holds
+      // Tiles whose y stencil neighbours are all inside the volume (x neighbours outside it read
+      // as zeros through an out-of-range buffer offset: the volume's first and last x slabs are a
+      // quarter of the tiles of the XCDs that own them).  Lane gl of a group holds
       // z plane z0 - 1 + gl of the aproned tile; group g owns x slabs 4g .. 4g + 3.  Every row of p
       // the group's stencils touch is loaded ONCE (32 loads per tile instead of 7 per output row);
       // the z neighbours come from the adjacent lanes (DPP wave shifts), the x / y neighbours from
@@ -722,7 +753,12 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
       const int kz = z0 - 1 + gl;
       const bool out_z = gl >= 1 && gl <= ez, lz_ok = kz > 0, hz_ok = kz + 1 < dd.z;
       const unsigned sxb = 4u * (unsigned)(dd.y * dd.z), syb = 4u * (unsigned)dd.z;
-      const unsigned e0 = 4u * (unsigned)(((x0 + 4 * grp - 1) * dd.y + y0 - 1) * dd.z + kz);
+      // byte offset of (first owned slab, row y0 - 1, plane kz); the slab below / above the group's
+      // four gets its own offset so that it can point out of range
+      constexpr unsigned kOob = 0x80000000u;
+      const int xg = x0 + 4 * grp;
+      const unsigned e1 = 4u * (unsigned)((xg * dd.y + y0 - 1) * dd.z + kz);
+      const unsigned elo = xg > 0 ? e1 - sxb : kOob, ehi = xg + 4 < dd.x ? e1 : kOob;
       const __amdgpu_buffer_rsrc_t rp = make_rsrc(pin, dd.numel() * 4),
                                    rd = make_rsrc(dst, dd.numel() * 4),
                                    rb = make_rsrc(P.objb ? P.objb : pin, dd.numel() * 4);
@@ -733,7 +769,10 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
 #pragma unroll
         for (int la = 0; la < 6; ++la) {
           const bool halo_x = sa == 0 || sa == 5, halo_y = la == 0 || la == 5;
-          pv[sa][la] = (halo_x && halo_y) ? 0.f : buf_load(rp, e0, (unsigned)sa * sxb + (unsigned)la * syb);
+          pv[sa][la] = (halo_x && halo_y) ? 0.f
+                       : sa == 0 ? buf_load(rp, elo, (unsigned)la * syb)
+                       : sa == 5 ? buf_load(rp, ehi, 4u * sxb + (unsigned)la * syb)
+                                 : buf_load(rp, e1, (unsigned)(sa - 1) * sxb + (unsigned)la * syb);
         }
       auto rows = [&](auto obj_tag) {
         constexpr bool OBJ = decltype(obj_tag)::value;
@@ -742,7 +781,7 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
           float ob[4];
           if (OBJ) {
 #pragma unroll
-            for (int la = 1; la <= 4; ++la) ob[la - 1] = buf_load(rb, e0, (unsigned)sa * sxb + (unsigned)la * syb);
+            for (int la = 1; la <= 4; ++la) ob[la - 1] = buf_load(rb, e1, (unsigned)(sa - 1) * sxb + (unsigned)la * syb);
           }
 #pragma unroll
           for (int la = 1; la <= 4; ++la) {
@@ -750,7 +789,9 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
             const float vzm = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), 0x138, 0xf, 0xf, false));
             const float vzp = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), 0x130, 0xf, 0xf, false));
             float q = arow[((sa - 1) * SY + (la - 1)) * SZ];
-            const float xf = pv[sa + 1][la] - c, xbk = c - pv[sa - 1][la];
+            // (forward differences with a zero bound: the backward term of the volume's first
+            // slab is absent, the forward term of its last slab sees a zero neighbour)
+            const float xf = pv[sa + 1][la] - c, xbk = (sa == 1 && xg == 0) ? 0.f : c - pv[sa - 1][la];
             const float yf = pv[sa][la + 1] - c, ybk = c - pv[sa][la - 1];
             const float zf = (hz_ok ? vzp : 0.f) - c, zbk = lz_ok ? c - vzm : 0.f;
             const float st = P.cx * (xbk - xf) + P.cy * (ybk - yf) + P.cz * (zbk - zf);
@@ -759,7 +800,7 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
               if (OBJ) {
                 dot += (double)obj_term(q, ob[la - 1], c);
               } else {
-                buf_store(q, rd, e0, (unsigned)sa * sxb + (unsigned)la * syb);
+                buf_store(q, rd, e1, (unsigned)(sa - 1) * sxb + (unsigned)la * syb);
                 dot += (double)__fmul_rn(c, q);
               }
             }
@@ -787,7 +828,15 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
         matvec_emit(dst, idx, q, pc, P.objb, P.partials != nullptr, dot);
       }
     }
+#ifdef UNIRES_S2_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (pw && lane == 0 && ptile < 9) pw[4 + 3 * ptile] = wall_clock64();
+    ++ptile;
+#endif
   }
+#ifdef UNIRES_S2_PROF
+  if (pw && lane == 0) pw[1] = wall_clock64(), pw[2] = (unsigned long long)ptile;
+#endif
   if (P.partials) {
     const double tot = wave_sum(dot);
     if (lane == 0) P.partials[blockIdx.x * kS2Waves + wave] = tot;
@@ -818,6 +867,19 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
   static const int dbg = getenv("UNIRES_S2_DBG") ? atoi(getenv("UNIRES_S2_DBG")) : 0;
   P.dbg = dbg;
   const dim3 grid(s2_grid(dd)), block(kWave * kS2Waves);
+  if (grid.x >= 8) {
+    for (int x = 0; x <= 8; ++x) P.xlo[x] = S.xcd_lo[x];
+  } else {  // fewer workgroups than XCDs: one equal share per workgroup
+    for (int x = 0; x <= 8; ++x) P.xlo[x] = (int)std::min<long long>(S.ntiles, ((long long)S.ntiles * x + grid.x - 1) / grid.x);
+  }
+  P.prof = nullptr;
+#ifdef UNIRES_S2_PROF
+  static unsigned long long *prof_dev = nullptr;
+  const size_t nprof = (size_t)grid.x * kS2Waves * 32;
+  if (!prof_dev) (void)hipMalloc((void **)&prof_dev, 4096 * 4 * 32 * sizeof(unsigned long long));
+  (void)hipMemsetAsync(prof_dev, 0, nprof * sizeof(unsigned long long), st);
+  P.prof = prof_dev;
+#endif
   const size_t lds = S.axis >= 0 ? (size_t)P.tabn * sizeof(float4) : 0;
   if (lds > 24 * 1024) return 1;
   switch (S.axis) {
@@ -827,6 +889,22 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
     case 3: hipLaunchKernelGGL((k_splat2<3>), grid, block, lds, st, P, done); break;
     default: hipLaunchKernelGGL((k_splat2<-1>), grid, block, lds, st, P, done); break;
   }
+#ifdef UNIRES_S2_PROF
+  {
+    static int shots = 0;
+    if (++shots == 12 && getenv("UNIRES_S2_PROF_OUT")) {  // one warmed-up launch
+      std::vector<unsigned long long> h(nprof);
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h.data(), prof_dev, nprof * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      FILE *f = fopen(getenv("UNIRES_S2_PROF_OUT"), "w");
+      for (size_t w = 0; w < nprof / 32; ++w) {
+        for (int i = 0; i < 32; ++i) fprintf(f, "%llu ", h[w * 32 + i]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+#endif
   return 0;
 }
 

@@ -39,6 +39,7 @@ struct SplatSched {
   unsigned long long *scratch = nullptr; // device: {error flag, points, instructions} of a build
   size_t cap_entries = 0, cap_instr = 0, cap_tiles = 0;
   int ntiles = 0;
+  int xcd_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // tile range of each XCD: contiguous, equal COST (instructions + epilogue)
   bool valid = false;
   int axis = -1;      // -1 direct source; 0..2 conv_up along that axis; 3 along all three
   double fill = 0.0;  // active lanes / issued lanes (diagnostic)
