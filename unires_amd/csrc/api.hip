@@ -264,6 +264,12 @@ struct Repeat {
   Taps Tf;
   SplatSafety safe;  // of Af (the linear part is the same for A)
   bool sep = false;  // many-tap profile: convolutions run as separable 1-D passes
+  // profile along x and / or y AND z with a z fan-in <= 2 (isotropic down-sampling, BASELINE config
+  // 4): the x / y part runs as 1-D passes through a (gf.x, gf.y, xd.z) intermediate, the z part
+  // stays fused in the pull / splat kernels, which then cost what they cost for a z-only profile
+  bool hyb = false;
+  Taps Tz, Txy;
+  Dim3i dim_h;
   // device tables for the on-the-fly conv_up of k_gather2: [0] no scaling (AtA), [1] S(scl) (At)
   float *ztab_dev[2] = {nullptr, nullptr};
   // schedule-driven splat (splat2.hip): per-tile segment lists of this operator + conv_up tables
@@ -363,6 +369,23 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
   out.sep = (long long)out.Tf.n[0] * out.Tf.n[1] * out.Tf.n[2] > 64;
   for (int d = 0; d < 3; ++d)
     if ((out.Tf.n[d] + out.Tf.s[d] - 1) / out.Tf.s[d] > 2) out.sep = true;
+  out.hyb = false;
+  if (pl->regime == UNIRES_REGIME_SUPERRES) {
+    static const bool no_hyb = getenv("UNIRES_NO_HYBRID") != nullptr;
+    auto dirac = [&](int d) { return out.Tf.n[d] == 1 && out.Tf.s[d] == 1 && out.Tf.t[d][0] == 1.f; };
+    const bool xy = !dirac(0) || !dirac(1);
+    const bool z_ok = (out.Tf.n[2] + out.Tf.s[2] - 1) / out.Tf.s[2] <= 2 && out.dim_x.z >= 2;
+    int nconv = 0;
+    for (int d = 0; d < 3; ++d) nconv += !dirac(d);
+    if (!no_hyb && xy && nconv > 1 && z_ok) {
+      out.hyb = true;
+      out.sep = false;
+      out.Tz = out.Tf, out.Txy = out.Tf;
+      for (int d = 0; d < 2; ++d) out.Tz.n[d] = out.Tz.s[d] = 1, out.Tz.t[d][0] = 1.f;
+      out.Txy.n[2] = out.Txy.s[2] = 1, out.Txy.t[2][0] = 1.f;
+      out.dim_h = Dim3i{out.dim_gf.x, out.dim_gf.y, out.dim_x.z};
+    }
+  }
   if (!invert_affine(out.Af, out.Afinv)) return fail(UNIRES_ERR_ARG, "singular affine");
   splat_safety(out.Af, out.safe.row_sep, out.safe.use_atomics);
   return UNIRES_OK;
@@ -412,7 +435,9 @@ static int build_sched(unires_plan *pl, Repeat &R) {
     }
     const int xdv[3] = {R.dim_x.x, R.dim_x.y, R.dim_x.z}, gdv[3] = {R.dim_gf.x, R.dim_gf.y, R.dim_gf.z};
     if (R.dim_x.numel() >= (1ull << 30)) return UNIRES_OK;
-    if (nconv > 1) {
+    if (R.hyb) {
+      axis = 2;
+    } else if (nconv > 1) {
       // conv_up along several axes (isotropic down-sampling, BASELINE config 4): x / y parts per
       // segment in the schedule, z part per lane
       for (int d = 0; d < 3; ++d)
@@ -422,11 +447,11 @@ static int build_sched(unires_plan *pl, Repeat &R) {
     } else {
       if (axis < 0) axis = 2;  // all dirac: conv_up is the identity, any axis works
       if ((R.Tf.n[axis] + R.Tf.s[axis] - 1) / R.Tf.s[axis] > 2 || xdv[axis] < 2) return UNIRES_OK;
-      if (R.scl != 0.f && R.dim_thick != axis) return UNIRES_OK;
+      if (R.scl != 0.f && R.dim_thick != axis && !R.hyb) return UNIRES_OK;  // (hybrid: x / y scaling rides with the 1-D passes)
     }
     const unsigned xyz = (unsigned)R.dim_x.y * (unsigned)R.dim_x.z, xz = (unsigned)R.dim_x.z;
     const int taxis = axis == 3 ? 2 : axis;  // axis of the run-time (per-lane) table
-    if (axis == 2) rows_y = R.dim_x.y, R.src_stride = xz, R.ctab_step = 1;
+    if (axis == 2) rows_y = R.hyb ? R.dim_h.y : R.dim_x.y, R.src_stride = xz, R.ctab_step = 1;
     if (axis == 1) R.src_stride = xyz, R.ctab_step = xz;  // source offset ui * xyz + koff(uj) * xz + k
     if (axis == 0) R.src_stride = xz, R.ctab_step = xyz;  // source offset uj * xz + koff(ui) * xyz + k
     if (axis == 3) R.src_stride = xz, R.ctab_step = xyz;  // (x-space row / slab strides)
@@ -476,6 +501,8 @@ static void build_pull(unires_plan *pl, Repeat &R) {
   R.pplan.valid = false;
   if (pl->regime == UNIRES_REGIME_DENOISE)
     (void)pull2_build(R.pplan, pl->dy, R.A, R.T, R.dim_g, R.dim_g);
+  else if (pl->regime == UNIRES_REGIME_SUPERRES && R.hyb)
+    (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tz, R.dim_h, R.dim_gf);
   else if (pl->regime == UNIRES_REGIME_SUPERRES && !R.sep)
     (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tf, R.dim_x, R.dim_gf);
   (void)hipGetLastError();
@@ -521,7 +548,7 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
       pl->cap_g = std::max(pl->cap_g, pl->reps[n].dim_g.numel());
       pl->cap_x = std::max(pl->cap_x, pl->reps[n].dim_x.numel());
     }
-    need_sep = need_sep || (regime == UNIRES_REGIME_SUPERRES && pl->reps[n].sep);
+    need_sep = need_sep || (regime == UNIRES_REGIME_SUPERRES && (pl->reps[n].sep || pl->reps[n].hyb));
   }
   const size_t ny = pl->dy.numel();
   size_t off = 0;
@@ -595,7 +622,7 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   if (plan->regime != UNIRES_REGIME_IDENTITY &&
       (tmp.dim_g.numel() > plan->cap_g || tmp.dim_x.numel() > plan->cap_x))
     return fail(UNIRES_ERR_DIM, "new repeat exceeds the plan's workspace");
-  if (plan->regime == UNIRES_REGIME_SUPERRES && tmp.sep && !plan->gbuf2)
+  if (plan->regime == UNIRES_REGIME_SUPERRES && (tmp.sep || tmp.hyb) && !plan->gbuf2)
     return fail(UNIRES_ERR_DIM, "new repeat needs the separable-conv scratch the plan was built without");
   drop_cg_graph(plan);  // the captured solve has the old operator baked in
   plan->prec_ready = false;  // a preconditioner built for the old operator is stale
@@ -634,6 +661,22 @@ static PushSrc push_src(const Repeat &R, const float *data, bool convup, float s
   return src;
 }
 
+// scaling split for the hybrid path: the part along z goes with the fused kernels, the rest with
+// the 1-D passes
+static Scaling scaling_z(const Scaling &S) { return S.dim == 2 ? S : Scaling{1.f, 1.f, -1}; }
+static Scaling scaling_xy(const Scaling &S) { return S.dim == 2 ? Scaling{1.f, 1.f, -1} : S; }
+
+// hybrid forward: out = S conv_down_xy (conv_down_z pull(in));  false: not available for this repeat
+static bool hybrid_forward(unires_plan *pl, const Repeat &R, const float *in, const Scaling &S, float *out,
+                           const int *done, hipStream_t st) {
+  if (!R.hyb || !pl->gbuf2 || !R.pplan.valid) return false;
+  if (launch_pull_conv2(R.pplan, in, pl->dy, R.Af, R.Tz, scaling_z(S), pl->gbuf, R.dim_h, R.dim_gf,
+                        pl->fov_tol, done, st))
+    return false;
+  launch_conv_down_sep(pl->gbuf, R.dim_h, R.Txy, scaling_xy(S), out, R.dim_x, pl->gbuf, pl->gbuf2, done, st);
+  return true;
+}
+
 // x-space intermediate of AtA: xbuf = S(2 scl) conv_down pull(in)  (regime 2) or
 // gbuf = pull(in) (regime 1); returns the push source that finishes the operator.
 static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, const int *done,
@@ -646,6 +689,7 @@ static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, co
   }
   // S(2 scl) once between conv and conv^T  (unires/_project.py:175-177)
   const Scaling S2 = make_scaling(2.f * R.scl, R.dim_thick);
+  if (hybrid_forward(pl, R, in, S2, pl->xbuf, done, st)) return push_src(R, pl->xbuf, true, 0.f);
   if (R.sep && pl->gbuf2) {
     launch_pull(in, pl->dy, R.Af, pl->gbuf, R.dim_gf, pl->fov_tol, done, st);
     launch_conv_down_sep(pl->gbuf, R.dim_gf, R.Tf, S2, pl->xbuf, R.dim_x, pl->gbuf, pl->gbuf2, done, st);
@@ -687,7 +731,15 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
     if (!launch_gather2(src, zt, A, R.Afinv, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
       return ep.partials ? gather2_blocks(pl->dy) : 0;
   }
-  if (!use_tile && mode == nullptr && R.sched.valid && (src.convup != 0) == (R.sched.axis >= 0)) {
+  if (!use_tile && mode == nullptr && R.hyb && src.convup && R.sched.valid && R.sched.axis == 2 && pl->gbuf2) {
+    // conv_up along x / y as 1-D passes, then the z-profile splat with the intermediate as its source
+    const float *h = launch_conv_up_sep(src.data, src.xd, R.Txy, scaling_xy(src.S), R.dim_h, pl->gbuf, pl->gbuf2, st);
+    const float4 *tab = (const float4 *)R.ctab_dev[src.S.dim == 2 ? 1 : 0];
+    if (!launch_splat2(R.sched, h, R.dim_h.numel(), tab, R.ctab_n, R.src_stride, R.ctab_step, R.src_stride,
+                       R.ctab_step, A, alpha, ep, out, pl->dy, done, st))
+      return ep.partials ? splat2_blocks(pl->dy) : 0;
+  }
+  if (!use_tile && mode == nullptr && !R.hyb && R.sched.valid && (src.convup != 0) == (R.sched.axis >= 0)) {
     const float4 *tab = src.convup ? (const float4 *)R.ctab_dev[src.S.dim >= 0 ? 1 : 0] : nullptr;
     const size_t numel = src.convup ? src.xd.numel() : src.gd.numel();
     if (!launch_splat2(R.sched, src.data, numel, tab, R.ctab_n, R.src_stride, R.ctab_step, R.src_stride,
@@ -754,7 +806,8 @@ extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, con
                             plan->fov_tol, nullptr, st))
         launch_pull(in, plan->dy, R.A, out, R.dim_g, plan->fov_tol, nullptr, st);
     } else {
-      if (R.sep && plan->gbuf2) {
+      if (hybrid_forward(plan, R, in, make_scaling(R.scl, R.dim_thick), out, nullptr, st)) {
+      } else if (R.sep && plan->gbuf2) {
         launch_pull(in, plan->dy, R.Af, plan->gbuf, R.dim_gf, plan->fov_tol, nullptr, st);
         launch_conv_down_sep(plan->gbuf, R.dim_gf, R.Tf, make_scaling(R.scl, R.dim_thick), out,
                              R.dim_x, plan->gbuf, plan->gbuf2, nullptr, st);

@@ -197,9 +197,9 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   //    issued together (sched_barrier between the phases; row by row the compiler serialises two
   //    dependent LDS round trips per row): 65 us - 148 VGPRs, one workgroup fewer per CU, and capped
   //    at 128 it spills;
-  //  * (kept) the row part of the coordinates computed by lane r for row r and broadcast with
-  //    v_readlane instead of 8 vector instructions per row on wave-uniform operands: 60 -> 44 VGPRs,
-  //    ~10 % fewer VALU instructions, the same 55 us - the kernel is not bound by VALU issue alone.
+  //  * the row part of the coordinates computed by lane r for row r and broadcast with v_readlane:
+  //    the same 55 us, and SQ_INSTS_VALU went UP 7 % (the compiler already shares the products of a
+  //    row's i with the 8 rows that have it).
   const float kf = (float)(k0 + min(lane, npts - 1));
   const float c0 = G.A.m[2], c1 = G.A.m[6], c2 = G.A.m[10];
   const float t0 = G.A.m[3], t1 = G.A.m[7], t2 = G.A.m[11];
@@ -213,23 +213,13 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
 #pragma unroll 1
   for (int h0 = 0; h0 < RPW; h0 += HALF) {
     float hv[HALF];
-    // row part of the coordinates: lane r computes it for row r of this half, the loop broadcasts it
-    // (the same affine_row, so the values are the splat's bit for bit; computed per row on wave-uniform
-    // operands it was 8 vector instructions a row)
-    RowBase rbl;
-    {
-      const int row = wave * RPW + h0 + (lane & (HALF - 1));
+#pragma unroll
+    for (int r = 0; r < HALF; ++r) {
+      const int row = wave * RPW + h0 + r;
       const int rr = GEN ? min(row, nrows - 1) : row;  // (rows past the layout replay the last one)
       const int i = min(i0 + (GEN ? (int)rowi[rr] : row / TJ), G.gd.x - 1),
                 j = min(j0 + (GEN ? (int)rowj[rr] : row % TJ), G.gd.y - 1);
-      rbl = affine_row(G.A, (float)i, (float)j);
-    }
-#pragma unroll
-    for (int r = 0; r < HALF; ++r) {
-      RowBase rb;
-      rb.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbl.x), r));
-      rb.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbl.y), r));
-      rb.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbl.z), r));
+      const RowBase rb = affine_row(G.A, (float)i, (float)j);
       const float gx = fmaf(c0, kf, rb.x) + t0, gy = fmaf(c1, kf, rb.y) + t1, gz = fmaf(c2, kf, rb.z) + t2;
       const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
       const float wx = gx - fx, wy = gy - fy, wz = gz - fz;
