@@ -79,7 +79,7 @@ def make_problem(dim_y=(16, 14, 12), n_channels=1, thick=3, seed=0, scl=0.0, reg
                     sc_ = [1.0, 1.0, 1.0]
                     sc_[ax_] = float(thick)
                     if iso:
-                        sc_ = [float(thick)] * 3
+                        sc_ = [float(v) for v in iso] if isinstance(iso, (tuple, list)) else [float(thick)] * 3
                     mx_ = mat_y @ torch.diag(torch.tensor(sc_ + [1.0], dtype=torch.float64))
                     dx_ = tuple(int(math.floor(d / s_)) for d, s_ in zip(dim_y, sc_))
                     po_ = O.proj_info(dim_y, mat_y, dx_, mx_, rigid=rigid, prof_ip=prof_ip,
@@ -94,8 +94,8 @@ def make_problem(dim_y=(16, 14, 12), n_channels=1, thick=3, seed=0, scl=0.0, reg
                 ax = (thick_axes[c] if thick_axes is not None else (2 - c - n) % 3)
                 scale = [1.0, 1.0, 1.0]
                 scale[ax] = float(thick)
-                if iso:  # BASELINE config 4: every axis coarser (ratio thick, thick, thick)
-                    scale = [float(thick)] * 3
+                if iso:  # BASELINE config 4: every axis coarser (ratio thick, thick, thick, or as given)
+                    scale = [float(v) for v in iso] if isinstance(iso, (tuple, list)) else [float(thick)] * 3
                 D = torch.diag(torch.tensor(scale + [1.0], dtype=torch.float64))
                 mat_x = mat_y @ D
                 dim_x = tuple(int(math.floor(d / s)) for d, s in zip(dim_y, scale))

@@ -22,6 +22,11 @@ CASES = {
     'sr_iso2_gauss': dict(dim_y=(16, 14, 12), n_channels=2, thick=2, regime='sr', iso=True, prof_ip=2,
                           prof_tp=0, vx_y=0.5),
     'sr_iso3_rect': dict(dim_y=(15, 15, 12), n_channels=1, thick=3, regime='sr', iso=True, rot=0.02),
+    # profiles along all three axes with even / odd slice scaling: along x (rides with the 1-D x / y
+    # passes of the hybrid path) and along z (rides with the fused z profile)
+    'sr_iso2_scl_x': dict(dim_y=(16, 14, 12), n_channels=1, thick=2, regime='sr', iso=True, scl=0.1),
+    'sr_223_scl_z': dict(dim_y=(14, 12, 18), n_channels=2, thick=3, regime='sr', iso=(2, 2, 3), scl=0.1,
+                         n_repeats=2),
     'sr_aligned': dict(dim_y=(16, 14, 24), n_channels=2, thick=3, regime='sr', thick_axes=[2, 2], rot=0.0,
                        trans=0.0, scl=0.1),
     'dn_2ch': dict(dim_y=(15, 13, 11), n_channels=2, regime='dn', rot=0.1, trans=1.5),
