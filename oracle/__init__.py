@@ -19,5 +19,10 @@ algorithm from its documented behaviour; it is pinned only by
   * the few known answers the reference's demo notebooks print
     (``get_gain`` trace, ``_proj_info`` dimension arithmetic).
 ``unires_restated`` restates the reference's own files line by line and cites
-them.
+them - and IS pinned: ``tests/golden/make_golden_from_reference.py`` imports the
+reference's ``unires/_project.py`` and ``_update.py`` as they lie (with ``nitorch``
+bound to ``nitorch_restated``), runs them on five small seeded problems and writes
+their inputs and outputs to ``tests/golden/ref_*.npz``;
+``tests/test_reference_pin.py`` requires ``unires_restated`` to reproduce every one
+of them to 1e-6.  What remains unpinned is ``nitorch_restated`` alone.
 """

@@ -2,9 +2,11 @@
 reference composes it (dense affine grid rebuilt per call, unfused pull / conv /
 push, stacked gradient, unpreconditioned CG) - deliberately slow.
 
-ORACLE - test infrastructure only (see oracle/__init__.py); PARITY UNPINNED at
-the nitorch boundary (oracle/nitorch_restated.py).  Each function cites the
-reference lines it follows.
+ORACLE - test infrastructure only (see oracle/__init__.py).  This half is pinned
+against the reference's own Python (tests/test_reference_pin.py, fixtures written
+by tests/golden/make_golden_from_reference.py); PARITY UNPINNED at the nitorch
+boundary (oracle/nitorch_restated.py).  Each function cites the reference lines
+it follows.
 """
 import math
 from types import SimpleNamespace
