@@ -16,4 +16,5 @@ for c in 0 1 2; do CH=$c WL=cfg3_256c3_thick6z bash tools/traffic2.sh ch$c -- py
 for c in 0 1 2; do echo "== channel $c"; CH=$c WL=cfg3_256c3_thick6z bash tools/pmc2.sh tools/pmc5.py; done > $OUT/r02_sq_counters.txt 2>&1
 bash tools/r2_configs.sh > $OUT/configs.txt 2>&1; cp gpurun_out/r2/configs.jsonl $OUT/r02_configs.jsonl
 bash tools/r2_timeline.sh > $OUT/r02_splat2_timeline.txt 2>&1
+bash tools/r2_timeline_pull.sh > $OUT/r02_pull2_timeline.txt 2>&1
 ls -la $OUT

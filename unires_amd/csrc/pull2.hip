@@ -26,6 +26,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "pull2.hpp"
 
 namespace unires {
@@ -99,6 +101,7 @@ struct P2Args {
   Dim3i xd;
   float tol;
   int W;             // window extent along x (cells); along y it is the template parameter H
+  unsigned long long *prof;  // -DUNIRES_P2_PROF builds: per-workgroup timeline (100 MHz ticks)
   int dbg;           // UNIRES_P2_DBG ablation bits (measurement only): 1 no staging, 2 no sampling, 4 no conv / store
 };
 
@@ -108,6 +111,10 @@ struct P2Args {
 template <int H, int NK, int SK, bool GEN>
 __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__restrict__ done) {
   if (done && *done) return;
+#ifdef UNIRES_P2_PROF
+  unsigned long long *pw = P.prof ? P.prof + (size_t)blockIdx.x * 8 : nullptr;
+  if (pw && threadIdx.x == 0) pw[0] = wall_clock64(), pw[4] = __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4);
+#endif
   constexpr int SZ = kP2SZ, SZ4 = kP2SZ4, NW = kBlock / kWave, TI = kP2TI, TJ = kP2TJ;
   constexpr int ROWS = kP2Rows, RPW = ROWS / NW, HALF = 8, SCR = kWave + 1;
   static_assert(TI * TJ == ROWS && ROWS % NW == 0 && RPW % HALF == 0, "rows per wave");
@@ -182,6 +189,9 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
     }
   }
   __syncthreads();
+#ifdef UNIRES_P2_PROF
+  if (pw && threadIdx.x == 0) pw[1] = wall_clock64();
+#endif
   // ---- pull: one grid row per wave pass, lanes along grid z; conv_down every 8 rows ----
   // Measured alternatives that did NOT pay on config 3 (this form: 55 us):
   //  * a 96-word column stride (bank = z plane, LDS bank conflicts 48 % -> 4 % of the LDS cycles):
@@ -228,11 +238,14 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
       const int a0 = xy + zl + tab[zl >> 2], a1 = xy + zl + 1 + tab[(zl + 1) >> 2];
       float v = 0.f;
       if (!(P.dbg & 2)) {
-        const float p000 = win[a0], p010 = win[a0 + SZ], p100 = win[a0 + H * SZ], p110 = win[a0 + (H + 1) * SZ];
-        const float p001 = win[a1], p011 = win[a1 + SZ], p101 = win[a1 + H * SZ], p111 = win[a1 + (H + 1) * SZ];
-        const float q00 = fmaf(wz, p001 - p000, p000), q01 = fmaf(wz, p011 - p010, p010);
-        const float q10 = fmaf(wz, p101 - p100, p100), q11 = fmaf(wz, p111 - p110, p110);
-        const float q0 = fmaf(wy, q01 - q00, q00), q1 = fmaf(wy, q11 - q10, q10);
+        // the four ds_read2_b32 return (y, y + 1) pairs: the z interpolation runs on the pairs as they
+        // come (v_pk_add_f32 / v_pk_fma_f32, no register shuffles), y and x on scalars
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f P0 = {win[a0], win[a0 + SZ]}, R0 = {win[a0 + H * SZ], win[a0 + (H + 1) * SZ]};
+        const v2f P1 = {win[a1], win[a1 + SZ]}, R1 = {win[a1 + H * SZ], win[a1 + (H + 1) * SZ]};
+        const v2f wz2 = {wz, wz};
+        const v2f Q0 = __builtin_elementwise_fma(wz2, P1 - P0, P0), Q1 = __builtin_elementwise_fma(wz2, R1 - R0, R0);
+        const float q0 = fmaf(wy, Q0.y - Q0.x, Q0.x), q1 = fmaf(wy, Q1.y - Q1.x, Q1.x);
         v = fmaf(wx, q1 - q0, q0);
       }
       if (!inside) {  // zero bound comes from the zero-filled window; the in-FOV mask is explicit
@@ -282,6 +295,9 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
       if (win_i < nout && i < G.gd.x && j < G.gd.y) P.dst[((size_t)i * xdy + j) * xdz + kk] = acc;
     }
   }
+#ifdef UNIRES_P2_PROF
+  if (pw && threadIdx.x == 0) pw[2] = wall_clock64();
+#endif
   if (GEN) {
     // ---- separable conv_down over the workgroup's rows: oi x oj x m x-space voxels ----
     __syncthreads();
@@ -444,6 +460,16 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
   P.dbg = dbg;
   const size_t lds = (size_t)W * H * kP2SZ * sizeof(float);
   const dim3 grid((unsigned)p2_blocks(P.G, xd)), block(kBlock);
+  P.prof = nullptr;
+#ifdef UNIRES_P2_PROF
+  static unsigned long long *prof_dev = nullptr;
+  const size_t nprof = (size_t)grid.x * 8;
+  if (!prof_dev) (void)hipMalloc((void **)&prof_dev, (size_t)(1 << 20) * 8 * sizeof(unsigned long long));
+  if (grid.x <= (1u << 20)) {
+    (void)hipMemsetAsync(prof_dev, 0, nprof * sizeof(unsigned long long), st);
+    P.prof = prof_dev;
+  }
+#endif
   const bool k76 = T.n[2] == 7 && T.s[2] == 6;
 #define P2_LAUNCH(HH)                                                                        \
   do {                                                                                       \
@@ -461,6 +487,23 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
   else
     P2_LAUNCH(16);
 #undef P2_LAUNCH
+#ifdef UNIRES_P2_PROF
+  {
+    static int shots = 0;
+    if (P.prof && ++shots == 12 && getenv("UNIRES_P2_PROF_OUT")) {  // one warmed-up launch
+      std::vector<unsigned long long> h(nprof);
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h.data(), prof_dev, nprof * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      FILE *f = fopen(getenv("UNIRES_P2_PROF_OUT"), "w");
+      fprintf(f, "# lds_bytes %zu\n", lds);
+      for (size_t w = 0; w < nprof / 8; ++w) {
+        for (int i = 0; i < 8; ++i) fprintf(f, "%llu ", h[w * 8 + i]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+#endif
   return 0;
 }
 
