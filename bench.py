@@ -202,20 +202,25 @@ def host_cpu_model():
     return 'unknown'
 
 
-def oracle_channel(wl, dim_y, seed=0):
-    """One channel of workload ``wl`` at size ``dim_y`` as oracle structs (+ the raw pieces)."""
+def oracle_channel(wl, dim_y, seed=0, channel=None):
+    """One channel of workload ``wl`` at size ``dim_y`` as oracle structs (+ the raw pieces).
+    ``channel`` picks that channel's thick axis (default: z, the headline configuration's)."""
     from oracle import unires_restated as O
     thick = wl['thick']
     gen = torch.Generator().manual_seed(seed)
     mat_y = torch.eye(4, dtype=torch.float64)
-    scale = [1.0, 1.0, float(thick)] if wl['axes'] is not None else [float(thick)] * 3
+    scale = [1.0, 1.0, 1.0]
+    if wl['axes'] is None:
+        scale = [float(thick)] * 3
+    else:
+        scale[2 if channel is None else wl['axes'][channel]] = float(thick)
     if wl['axes'] is None:
         mat_y = torch.diag(torch.tensor([0.5, 0.5, 0.5, 1.0], dtype=torch.float64))
     mat_x = mat_y @ torch.diag(torch.tensor(scale + [1.0], dtype=torch.float64))
     dim_x = tuple(int(math.floor(d / s)) for d, s in zip(dim_y, scale))
     u = torch.rand(6, generator=gen) * 2 - 1
     rigid = rigid_matrix((u[:3] * 5.0).tolist(), (u[3:] * 0.1).tolist())
-    po = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid)
+    po = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=wl.get('prof_ip', 0), prof_tp=0)
     dat_x = torch.rand(dim_x, generator=gen) * 400
     tau, lam = 1 / 75.0 ** 2, 4.0 * math.sqrt(1 / 3.0) / 400.0
     xc = [O.make_input(dat_x, mat_x, torch.tensor(tau), po)]
@@ -269,8 +274,8 @@ def matvec_parity(wl, P, q_cpu, device, rho=0.9):
     regime = wl.get('regime', 'sr')
     method = 'super-resolution' if regime == 'sr' else 'denoising'
     dim_y = tuple(P['b'].shape)
-    po_g = U._proj_info(dim_y, P['mat_y'], P['dim_x'], P['mat_x'], rigid=P['rigid'], prof_ip=0, prof_tp=0,
-                        device=device)
+    po_g = U._proj_info(dim_y, P['mat_y'], P['dim_x'], P['mat_x'], rigid=P['rigid'],
+                        prof_ip=wl.get('prof_ip', 0), prof_tp=0, device=device)
     xg = [U._input(P['dat_x'].to(device), P['mat_x'], P['tau'], po_g)]
     yg = U._output(torch.zeros(dim_y, device=device), P['mat_y'], P['lam'])
     plan = _channel_plan(xg, yg, method, regime != 'id')

@@ -25,11 +25,11 @@ pytestmark = pytest.mark.gpu
 GATE = 1e-4
 
 
-def _check(dev, wlname, dim_y, seed, rhs=True):
+def _check(dev, wlname, dim_y, seed, rhs=True, channel=None):
     from unires_amd._project import _channel_plan
     import unires_amd as U
     wl = dict(bench.WORKLOADS[wlname])
-    P = bench.oracle_channel(wl, dim_y, seed=seed)
+    P = bench.oracle_channel(wl, dim_y, seed=seed, channel=channel)
     q_cpu = bench.oracle_lhs(wl, P)(P['b'])
     par = bench.matvec_parity(wl, P, q_cpu, dev)
     assert par['rel_err_away_from_fov_ties'] < GATE, par
@@ -66,6 +66,49 @@ def _check(dev, wlname, dim_y, seed, rhs=True):
 ])
 def test_midsize_matvec_and_rhs_match_oracle(dev, wlname, dim_y):
     _check(dev, wlname, dim_y, seed=3)
+
+
+@pytest.mark.parametrize('wlname,dim_y,channel', [
+    ('cfg3_256c3_thick6xyz', (96, 90, 102), 0),      # thick slices along x: profile along x, window pull with a workgroup-wide conv
+    ('cfg3_256c3_thick6xyz', (96, 90, 102), 1),      # ... along y
+    ('demo_181c3_thick4xyz', (91, 109, 91), 0),      # the demo's 4 mm slices along x on half its 181 x 217 x 181
+    ('cfg4_384c4_iso2_gauss', (72, 66, 80), None),   # rect x Gaussian x Gaussian profile: 1-D passes through grid space
+])
+def test_midsize_other_profiles_match_oracle(dev, wlname, dim_y, channel):
+    _check(dev, wlname, dim_y, seed=4, rhs=False, channel=channel)
+
+
+def test_full_size_config4_properties(dev):
+    """BASELINE configs[3] at full size (384^3 from 192^3, ratio 2,2,2: profile along all three
+    axes).  No oracle at this size (a dense 387^3 x 3 grid per application): the size-independent
+    properties instead - the reference's own adjoint check, symmetry and positivity of the matvec,
+    and AtA = At(A)."""
+    import unires_amd as U
+    from unires_amd._project import _channel_plan
+    from tests.helpers import rigid_matrix
+    dim_y, dim_x = (384, 384, 384), (192, 192, 192)
+    mat_y = torch.diag(torch.tensor([0.5, 0.5, 0.5, 1.0], dtype=torch.float64))
+    mat_x = torch.eye(4, dtype=torch.float64)
+    po = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid_matrix([1.5, -2.0, 1.0], [0.04, -0.06, 0.03]),
+                      device=dev)
+    assert tuple(po.ratio) == (2, 2, 2)
+    val = U._check_adjoint(po, 'super-resolution')
+    assert abs(val) < 1e-5 * 192 ** 3
+    g = torch.Generator().manual_seed(0)
+    x = [U._input(torch.rand(dim_x, generator=g).to(dev), mat_x, 1.8e-4, po)]
+    y = U._output(torch.zeros(dim_y, device=dev), mat_y, 0.006)
+    plan = _channel_plan(x, y, 'super-resolution', True)
+    p = torch.rand(dim_y, generator=g).to(dev)
+    q = torch.rand(dim_y, generator=g).to(dev)
+    Ap, Aq = plan.matvec(p, 0.9, 0.006), plan.matvec(q, 0.9, 0.006)
+    s1 = torch.sum(Ap * q, dtype=torch.float64).item()
+    s2 = torch.sum(p * Aq, dtype=torch.float64).item()
+    assert abs(s1 - s2) < 1e-5 * abs(s1)
+    assert torch.sum(Ap * p, dtype=torch.float64).item() > 0
+    # the fused AtA against its two halves (rho = 0: no stencil term)
+    AtAp = plan.matvec(p, 0.0, 0.006)
+    two = float(x[0].tau) * plan.proj_apply(0, 'At', plan.proj_apply(0, 'A', p))
+    assert rel_err(AtAp.cpu(), two.cpu()) < 1e-5
 
 
 def test_full_size_config3_matvec_matches_oracle(dev):
