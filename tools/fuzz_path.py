@@ -8,7 +8,7 @@ dev = 'cuda:0'
 g = torch.Generator().manual_seed(int(os.environ.get('SEED', '0')))
 worst = 0.0
 for it in range(int(os.environ.get('N', '12'))):
-    dims = tuple(int(v) for v in torch.randint(10, 40, (3,), generator=g))
+    dims = tuple(int(v) for v in torch.randint(10, int(os.environ.get('DMAX', '40')), (3,), generator=g))
     regime = ['sr', 'sr', 'dn'][int(torch.randint(0, 3, (1,), generator=g))]
     kw = dict(dim_y=dims, n_channels=int(torch.randint(1, 3, (1,), generator=g)), regime=regime,
               rot=float(torch.rand(1, generator=g)) * 0.25, trans=float(torch.rand(1, generator=g)) * 4,
@@ -16,6 +16,8 @@ for it in range(int(os.environ.get('N', '12'))):
     if regime == 'sr':
         kw.update(thick=int(torch.randint(2, 6, (1,), generator=g)), scl=float(torch.rand(1, generator=g)) * 0.2,
                   n_repeats=int(torch.randint(1, 3, (1,), generator=g)))
+        if int(torch.randint(0, 3, (1,), generator=g)) == 0:  # profile along several axes (per-axis ratios 1..3)
+            kw['iso'] = tuple(int(v) for v in torch.randint(1, 4, (3,), generator=g))
     try:
         prob = make_problem(**kw)
     except Exception as e:  # degenerate draw (e.g. a thick axis longer than the volume)
