@@ -107,16 +107,17 @@ __device__ __forceinline__ unsigned s2_rowcode(const S2BuildArgs &B, int ui, int
 // the exclusive prefix sums and the entries / masks are written.
 template <bool FILL>
 __global__ void __launch_bounds__(kWave)
-    k_splat2_build(S2BuildArgs B, uint2 *__restrict__ counts, S2Entry *__restrict__ entries,
-                   S2Ext *__restrict__ ext, ulonglong2 *__restrict__ masks, int *__restrict__ err,
-                   unsigned long long *__restrict__ stats) {
+    k_splat2_build(S2BuildArgs B, uint2 *__restrict__ counts, const int *__restrict__ geom,
+                   S2Entry *__restrict__ entries, S2Ext *__restrict__ ext, ulonglong2 *__restrict__ masks,
+                   int *__restrict__ err, unsigned long long *__restrict__ stats) {
   using T = S2Tile;
   constexpr int L = T::L, kSegs = 384;
   __shared__ S2Seg segs[kSegs];
   __shared__ unsigned short member[kWave][kS2MaxSeg];
   const int lane = threadIdx.x;
   const Dim3i dd = B.dd;
-  const int t = blockIdx.x;
+  const int slot = blockIdx.x;                  // where this tile's counts / offsets live
+  const int t = geom ? geom[slot] : slot;       // the output tile (FILL: processing order -> tile)
   const S2TileGeom g = s2_tile(t, dd);
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const float flx = (float)(g.x0 - 1), fly = (float)(g.y0 - 1), flz = (float)(g.z0 - 1);
@@ -291,10 +292,10 @@ __global__ void __launch_bounds__(kWave)
   }
   const int total_ent = __shfl(incl, kWave - 1, kWave);
   if (!FILL) {
-    if (lane == 0) counts[t] = make_uint2((unsigned)total_ent, (unsigned)nbins);
+    if (lane == 0) counts[slot] = make_uint2((unsigned)total_ent, (unsigned)nbins);
     return;
   }
-  const uint2 base = counts[t];
+  const uint2 base = counts[slot];
   unsigned long long pts = 0;
   if (lane < nbins) {
     S2Entry *out = entries + base.x + (incl - nent);
@@ -352,6 +353,7 @@ void splat2_free(SplatSched &S) {
   if (S.ext) (void)hipFree(S.ext);
   if (S.masks) (void)hipFree(S.masks);
   if (S.tile_off) (void)hipFree(S.tile_off);
+  if (S.tile_geom) (void)hipFree(S.tile_geom);
   if (S.scratch) (void)hipFree(S.scratch);
   S = SplatSched();
 }
@@ -378,6 +380,9 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
     if (S.tile_off) (void)hipFree(S.tile_off);
     S.tile_off = nullptr;
     if (hipMalloc((void **)&S.tile_off, ((size_t)nt + 1) * sizeof(uint2)) != hipSuccess) return 1;
+    if (S.tile_geom) (void)hipFree(S.tile_geom);
+    S.tile_geom = nullptr;
+    if (hipMalloc((void **)&S.tile_geom, ((size_t)nt + 1) * sizeof(int)) != hipSuccess) return 1;
     S.cap_tiles = (size_t)nt + 1;
   }
   if (!S.scratch && hipMalloc((void **)&S.scratch, 4 * sizeof(unsigned long long)) != hipSuccess) return 1;
@@ -388,16 +393,53 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
   B.A = A, B.Ainv = Ainv, B.gd = gd, B.dd = dd, B.tol = tol, B.row_sep = safe.row_sep;
   B.axis = axis, B.rows_y = rows_y;
   B.xtab = xtab, B.ytab = ytab, B.xd = xd;
-  hipLaunchKernelGGL(k_splat2_build<false>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off,
+  hipLaunchKernelGGL(k_splat2_build<false>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off, (const int *)nullptr,
                      (S2Entry *)nullptr, (S2Ext *)nullptr, (ulonglong2 *)nullptr, err_dev,
                      (unsigned long long *)nullptr);
-  std::vector<uint2> h((size_t)nt + 1);
-  if (hipMemcpy(h.data(), S.tile_off, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess)
+  std::vector<uint2> cnt((size_t)nt), h((size_t)nt + 1);
+  if (hipMemcpy(cnt.data(), S.tile_off, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess)
     return 1;
+  // Processing order.  (1) Contiguous runs of tiles per XCD with equal cost: a tile costs its
+  // instructions + 11 for the epilogue (~5 us against ~0.45 us per instruction, tools/s2_timeline.py);
+  // with equal tile COUNTS the XCD that holds the volume's first x slabs had a third less to do.
+  // (2) Inside a run, the tiles with (next to) no instructions - the part of the volume the
+  // observation does not see, 14 % of config 3 - go LAST, emptiest at the very end: a wave gets 4.5
+  // tiles, so the last round is half empty and as long as its longest tile; made of 5 us tiles
+  // instead of 16 us ones the kernel's tail shrinks by two thirds.  The other tiles keep their index
+  // order (neighbours share halos and schedule lines in the XCD's L2).
+  constexpr double kEpilogueCost = 11.0;
+  std::vector<int> geom((size_t)nt + 1);
+  {
+    double total = 0.0;
+    unsigned imax = 0;
+    for (int i = 0; i < nt; ++i) total += (double)cnt[i].y + kEpilogueCost, imax = std::max(imax, cnt[i].y);
+    int x = 1;
+    double cum = 0.0;
+    S.xcd_lo[0] = 0;
+    for (int i = 0; i < nt && x < 8; ++i) {
+      cum += (double)cnt[i].y + kEpilogueCost;
+      while (x < 8 && cum >= total * x / 8.0) S.xcd_lo[x++] = i + 1;
+    }
+    for (; x <= 8; ++x) S.xcd_lo[x] = nt;
+    static const bool keep_order = getenv("UNIRES_SPLAT2_INDEX_ORDER") != nullptr;
+    const unsigned cheap = keep_order ? 0u : imax / 2u;
+    for (int xc = 0; xc < 8; ++xc) {
+      const int lo = S.xcd_lo[xc], hi = S.xcd_lo[xc + 1];
+      int u = lo;
+      for (int g = lo; g < hi; ++g)
+        if (keep_order || cnt[g].y > cheap) geom[u++] = g;
+      const int first_cheap = u;
+      for (int g = lo; g < hi; ++g)
+        if (!keep_order && cnt[g].y <= cheap) geom[u++] = g;
+      std::stable_sort(geom.begin() + first_cheap, geom.begin() + hi,
+                       [&](int a, int b) { return cnt[a].y > cnt[b].y; });
+    }
+    geom[nt] = 0;
+  }
   unsigned re = 0, ri = 0;
-  for (int i = 0; i < nt; ++i) {
-    const uint2 c = h[i];
-    h[i] = make_uint2(re, ri);
+  for (int u = 0; u < nt; ++u) {
+    const uint2 c = cnt[geom[u]];
+    h[u] = make_uint2(re, ri);
     re += c.x, ri += c.y;
   }
   h[nt] = make_uint2(re, ri);
@@ -424,10 +466,12 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
   }
   if (hipMemcpy(S.tile_off, h.data(), ((size_t)nt + 1) * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess)
     return 1;
+  if (hipMemcpy(S.tile_geom, geom.data(), ((size_t)nt + 1) * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+    return 1;
   (void)hipMemset(S.entries + re, 0xff, kPad * sizeof(S2Entry));
   (void)hipMemset(S.masks + ri, 0, 8 * sizeof(ulonglong2));
-  hipLaunchKernelGGL(k_splat2_build<true>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off, S.entries,
-                     S.ext, S.masks, err_dev, stats_dev);
+  hipLaunchKernelGGL(k_splat2_build<true>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off, (const int *)S.tile_geom,
+                     S.entries, S.ext, S.masks, err_dev, stats_dev);
   int herr = 0;
   unsigned long long hs[2] = {0, 0};
   if (hipMemcpy(&herr, err_dev, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 1;
@@ -437,21 +481,6 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
     return 1;
   }
   S.ntiles = nt;
-  {
-    // contiguous runs of tiles per XCD with equal cost.  Cost of a tile = its instructions + the
-    // epilogue (~5 us against ~0.45 us per instruction in tools/s2_timeline.py); with equal tile
-    // COUNTS the XCD that holds the volume's first x slabs had a third less to do than the others.
-    constexpr double kEpilogueCost = 11.0;
-    const double total = (double)ri + kEpilogueCost * nt;
-    int x = 1;
-    S.xcd_lo[0] = 0;
-    for (int i = 0; i < nt && x < 8; ++i) {
-      const double cum = (double)h[i + 1].y + kEpilogueCost * (i + 1);
-      while (x < 8 && cum >= total * x / 8.0) S.xcd_lo[x++] = i + 1;
-    }
-    for (; x <= 8; ++x) S.xcd_lo[x] = nt;
-    S.xcd_lo[8] = nt;
-  }
   S.axis = axis;
   S.fill = hs[1] ? (double)hs[0] / (64.0 * (double)hs[1]) : 0.0;
   S.valid = true;
@@ -500,6 +529,7 @@ struct S2Args {
   unsigned xs_sy4, xs_sx4;  // AXIS 3: bytes between x-space rows / slabs
   const ulonglong2 *masks;  // per instruction: {segment starts, active lanes}
   const uint2 *tile_off;
+  const int *tile_geom;  // output tile of processing slot u
   int ntiles;
   Affine A;
   float alpha;
@@ -564,7 +594,7 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
   if (pw && lane == 0) pw[0] = wall_clock64();
 #endif
   for (int t = t_lo + slot; t < t_hi; t += slots) {
-    const S2TileGeom g = s2_tile(t, dd);
+    const S2TileGeom g = s2_tile(P.tile_geom[t], dd);
     const int x0 = g.x0, y0 = g.y0, z0 = g.z0, ex = g.ex, ey = g.ey, ez = g.ez;
     const uint2 off0 = P.tile_off[t], off1 = P.tile_off[t + 1];
     const int ninstr = (int)(off1.y - off0.y);
@@ -738,12 +768,12 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
 #endif
     // ---- epilogue: q = [q +] acc + a0 p + c DtD p ; dot += p*q  (one row per lane group) ----
     if (S2_ABL(2)) continue;
-    const bool fast_xy = pin != nullptr && !P.accumulate && ex == TX && y0 > 0 && y0 + TY < dd.y &&
-                         dd.numel() < (1ull << 29);
+    const bool fast_xy = pin != nullptr && !P.accumulate && ex == TX && ey == TY && dd.numel() < (1ull << 29);
     if (fast_xy) {
-      // Tiles whose y stencil neighbours are all inside the volume (x neighbours outside it read
-      // as zeros through an out-of-range buffer offset: the volume's first and last x slabs are a
-      // quarter of the tiles of the XCDs that own them).  Lane gl of a group holds
+      // Whole tiles, wherever they lie: x / y stencil neighbours outside the volume read as zeros
+      // through an out-of-range buffer offset (the volume's first and last x slabs are a quarter of
+      // the tiles of the XCDs that own them, and a wave whose stride lands it on the first or last
+      // y row of tiles got four 12 us generic epilogues in a row).  Lane gl of a group holds
       // z plane z0 - 1 + gl of the aproned tile; group g owns x slabs 4g .. 4g + 3.  Every row of p
       // the group's stencils touch is loaded ONCE (32 loads per tile instead of 7 per output row);
       // the z neighbours come from the adjacent lanes (DPP wave shifts), the x / y neighbours from
@@ -753,12 +783,13 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
       const int kz = z0 - 1 + gl;
       const bool out_z = gl >= 1 && gl <= ez, lz_ok = kz > 0, hz_ok = kz + 1 < dd.z;
       const unsigned sxb = 4u * (unsigned)(dd.y * dd.z), syb = 4u * (unsigned)dd.z;
-      // byte offset of (first owned slab, row y0 - 1, plane kz); the slab below / above the group's
-      // four gets its own offset so that it can point out of range
+      // byte offset of (first owned slab, first owned row, plane kz); the slab / row below and above
+      // the owned 4 x 4 get their own offsets so that they can point out of range
       constexpr unsigned kOob = 0x80000000u;
       const int xg = x0 + 4 * grp;
-      const unsigned e1 = 4u * (unsigned)((xg * dd.y + y0 - 1) * dd.z + kz);
+      const unsigned e1 = 4u * (unsigned)((xg * dd.y + y0) * dd.z + kz);
       const unsigned elo = xg > 0 ? e1 - sxb : kOob, ehi = xg + 4 < dd.x ? e1 : kOob;
+      const unsigned eyl = y0 > 0 ? e1 - syb : kOob, eyh = y0 + TY < dd.y ? e1 : kOob;
       const __amdgpu_buffer_rsrc_t rp = make_rsrc(pin, dd.numel() * 4),
                                    rd = make_rsrc(dst, dd.numel() * 4),
                                    rb = make_rsrc(P.objb ? P.objb : pin, dd.numel() * 4);
@@ -770,9 +801,11 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
         for (int la = 0; la < 6; ++la) {
           const bool halo_x = sa == 0 || sa == 5, halo_y = la == 0 || la == 5;
           pv[sa][la] = (halo_x && halo_y) ? 0.f
-                       : sa == 0 ? buf_load(rp, elo, (unsigned)la * syb)
-                       : sa == 5 ? buf_load(rp, ehi, 4u * sxb + (unsigned)la * syb)
-                                 : buf_load(rp, e1, (unsigned)(sa - 1) * sxb + (unsigned)la * syb);
+                       : sa == 0 ? buf_load(rp, elo, (unsigned)(la - 1) * syb)
+                       : sa == 5 ? buf_load(rp, ehi, 4u * sxb + (unsigned)(la - 1) * syb)
+                       : la == 0 ? buf_load(rp, eyl, (unsigned)(sa - 1) * sxb)
+                       : la == 5 ? buf_load(rp, eyh, (unsigned)(sa - 1) * sxb + 4u * syb)
+                                 : buf_load(rp, e1, (unsigned)(sa - 1) * sxb + (unsigned)(la - 1) * syb);
         }
       auto rows = [&](auto obj_tag) {
         constexpr bool OBJ = decltype(obj_tag)::value;
@@ -781,7 +814,7 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
           float ob[4];
           if (OBJ) {
 #pragma unroll
-            for (int la = 1; la <= 4; ++la) ob[la - 1] = buf_load(rb, e1, (unsigned)(sa - 1) * sxb + (unsigned)la * syb);
+            for (int la = 1; la <= 4; ++la) ob[la - 1] = buf_load(rb, e1, (unsigned)(sa - 1) * sxb + (unsigned)(la - 1) * syb);
           }
 #pragma unroll
           for (int la = 1; la <= 4; ++la) {
@@ -792,7 +825,7 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
             // (forward differences with a zero bound: the backward term of the volume's first
             // slab is absent, the forward term of its last slab sees a zero neighbour)
             const float xf = pv[sa + 1][la] - c, xbk = (sa == 1 && xg == 0) ? 0.f : c - pv[sa - 1][la];
-            const float yf = pv[sa][la + 1] - c, ybk = c - pv[sa][la - 1];
+            const float yf = pv[sa][la + 1] - c, ybk = (la == 1 && y0 == 0) ? 0.f : c - pv[sa][la - 1];
             const float zf = (hz_ok ? vzp : 0.f) - c, zbk = lz_ok ? c - vzm : 0.f;
             const float st = P.cx * (xbk - xf) + P.cy * (ybk - yf) + P.cz * (zbk - zf);
             q += P.a0 * c + st;
@@ -800,7 +833,7 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
               if (OBJ) {
                 dot += (double)obj_term(q, ob[la - 1], c);
               } else {
-                buf_store(q, rd, e1, (unsigned)(sa - 1) * sxb + (unsigned)la * syb);
+                buf_store(q, rd, e1, (unsigned)(sa - 1) * sxb + (unsigned)(la - 1) * syb);
                 dot += (double)__fmul_rn(c, q);
               }
             }
@@ -860,7 +893,7 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
   P.tab = tab_dev, P.gn = gn;
   P.tabn = S.axis >= 0 ? gn + 2 * kWave : 0;
   P.row_stride4 = 4u * row_stride, P.tab_step4 = 4u * tab_step;
-  P.entries = S.entries, P.ext = S.ext, P.xs_sy4 = 4u * xs_sy, P.xs_sx4 = 4u * xs_sx, P.masks = S.masks, P.tile_off = S.tile_off, P.ntiles = S.ntiles;
+  P.entries = S.entries, P.ext = S.ext, P.xs_sy4 = 4u * xs_sy, P.xs_sx4 = 4u * xs_sx, P.masks = S.masks, P.tile_off = S.tile_off, P.tile_geom = S.tile_geom, P.ntiles = S.ntiles;
   P.A = A, P.alpha = alpha;
   P.p = ep.p, P.a0 = ep.a0, P.cx = ep.cx, P.cy = ep.cy, P.cz = ep.cz;
   P.dst = dst, P.dd = dd, P.accumulate = ep.accumulate, P.partials = ep.partials, P.objb = ep.objb;

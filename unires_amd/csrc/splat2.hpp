@@ -35,7 +35,8 @@ struct SplatSched {
   S2Entry *entries = nullptr;            // device
   S2Ext *ext = nullptr;                  // device, axis 3 only (same indexing as entries)
   ulonglong2 *masks = nullptr;           // device, per instruction: {bit l-1 set <=> a segment starts at lane l, active lanes}
-  uint2 *tile_off = nullptr;             // device, ntiles + 1 {entry offset, instruction offset}
+  uint2 *tile_off = nullptr;             // device, ntiles + 1 {entry offset, instruction offset}, in PROCESSING order
+  int *tile_geom = nullptr;              // device, ntiles: the output tile of processing slot u (cheap tiles last, see splat2_build)
   unsigned long long *scratch = nullptr; // device: {error flag, points, instructions} of a build
   size_t cap_entries = 0, cap_instr = 0, cap_tiles = 0;
   int ntiles = 0;
