@@ -748,8 +748,9 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
       // the next one.  A branch-free body - fetch / splat / fetch / splat with slots past the end
       // switched off - gets vmcnt(4..7) there and is no faster, 92 vs 90 us: the stream is not bound
       // by that latency but by VALU issue (~58 % of a SIMD) and LDS (~57 % of a CU) together, see
-      // tools/s2_timeline.py.  Same outcome for a dynamic tile queue, a staggered start of half the
-      // waves and a prefetch of the next tile's schedule: 90 - 92 us each.)
+      // tools/s2_timeline.py.  Same outcome for a dynamic tile queue (also on top of the cheap-tiles-last
+      // order: ends bunch up, 64 .. 80 us, but the ticket in front of the epilogue's loads costs each
+      // epilogue 1 us), a staggered start of half the waves and a prefetch of the next tile's schedule.)
       Batch ba, bb;
       fetch(ba, 0);
       for (int p0 = 0; p0 < ninstr; p0 += 2 * kU) {
