@@ -500,11 +500,11 @@ static int build_sched(unires_plan *pl, Repeat &R) {
 static void build_pull(unires_plan *pl, Repeat &R) {
   R.pplan.valid = false;
   if (pl->regime == UNIRES_REGIME_DENOISE)
-    (void)pull2_build(R.pplan, pl->dy, R.A, R.T, R.dim_g, R.dim_g);
+    (void)pull2_build(R.pplan, pl->dy, R.A, R.T, R.dim_g, R.dim_g, pl->fov_tol);
   else if (pl->regime == UNIRES_REGIME_SUPERRES && R.hyb)
-    (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tz, R.dim_h, R.dim_gf);
+    (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tz, R.dim_h, R.dim_gf, pl->fov_tol);
   else if (pl->regime == UNIRES_REGIME_SUPERRES && !R.sep)
-    (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tf, R.dim_x, R.dim_gf);
+    (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tf, R.dim_x, R.dim_gf, pl->fov_tol);
   (void)hipGetLastError();
 }
 

@@ -49,10 +49,10 @@ struct P2Geom {
   float pxi, pxj, sx, cx, pyi, pyj, sy, cy;
 };
 
-// per-workgroup record: {Z0, plane groups in use, all-inside flag, -} then the 18 window origins
+// per-workgroup record: {Z0, plane groups in use, all-inside flag, all-outside flag} then the 18 window origins
 constexpr int kP2Rec = 4 + 2 * kP2SZ4;
 
-__global__ void k_pull2_plan(P2Geom G, int nblk, int *__restrict__ rec) {
+__global__ void k_pull2_plan(P2Geom G, int nblk, float tol, int *__restrict__ rec) {
   const int blk = blockIdx.x * blockDim.x + threadIdx.x;
   if (blk >= nblk) return;
   constexpr int SZ4 = kP2SZ4;
@@ -64,6 +64,11 @@ __global__ void k_pull2_plan(P2Geom G, int nblk, int *__restrict__ rec) {
   // z extent of the workgroup's samples: 8 vertices of the (i, j, k) box
   float zmin = 1e30f, zmax = -1e30f;
   bool inside = true;  // every sample has all 8 corners inside the volume (no FOV mask needed)
+  // ... or every sample is outside the field of view: the 8 vertices of the box of grid points lie
+  // beyond one face of the volume (an affine image of a box is convex), with a margin well above the
+  // rounding of the coordinates
+  int below[3] = {0, 0, 0}, above[3] = {0, 0, 0};
+  const float lim[3] = {(float)(G.sd.x - 1), (float)(G.sd.y - 1), (float)(G.sd.z - 1)};
   for (int c = 0; c < 8; ++c) {
     float gx, gy, gz;
     affine_point(G.A, (float)((c & 4) ? i1 : i0), (float)((c & 2) ? j1 : j0),
@@ -71,11 +76,15 @@ __global__ void k_pull2_plan(P2Geom G, int nblk, int *__restrict__ rec) {
     zmin = fminf(zmin, gz), zmax = fmaxf(zmax, gz);
     inside = inside && gx >= 0.01f && gx <= (float)(G.sd.x - 1) - 0.01f && gy >= 0.01f &&
              gy <= (float)(G.sd.y - 1) - 0.01f && gz >= 0.01f && gz <= (float)(G.sd.z - 1) - 0.01f;
+    const float gv[3] = {gx, gy, gz};
+    for (int d = 0; d < 3; ++d) below[d] += gv[d] < -tol - 0.01f, above[d] += gv[d] > lim[d] + tol + 0.01f;
   }
+  bool empty = false;
+  for (int d = 0; d < 3; ++d) empty = empty || below[d] == 8 || above[d] == 8;
   const int Z0 = 4 * (int)floorf(floorf(zmin - 0.01f) * 0.25f);
   const int ngrp = min(SZ4, ((int)floorf(zmax + 0.01f) + 1 - Z0) / 4 + 1);
   int *r = rec + (size_t)blk * kP2Rec;
-  r[0] = Z0, r[1] = ngrp, r[2] = inside ? 1 : 0, r[3] = 0;
+  r[0] = Z0, r[1] = ngrp, r[2] = inside ? 1 : 0, r[3] = empty ? 1 : 0;
   const float fi0 = (float)i0, fi1 = (float)i1, fj0 = (float)j0, fj1 = (float)j1;
   for (int g = 0; g < SZ4; ++g) {
     // samples whose lower or upper corner plane falls in this group: gz in [Zg - 1, Zg + 4)
@@ -137,6 +146,31 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   const int *rec = P.rec + (size_t)blk * kP2Rec;
   const int Z0 = rec[0], ngrp = rec[1];
   const bool inside = rec[2] != 0;
+  if (rec[3] != 0) {
+    // every sample of this workgroup lies outside the field of view (the part of the observation's
+    // grid that sticks out of the volume: ~10 % of config 3's workgroups): its outputs are zeros
+    const int xdy = P.xd.y, xdz = P.xd.z;
+    if (GEN) {
+      const int ojm = G.oj * G.m, nitem = G.oi * ojm;
+      for (int it = tid; it < nitem; it += kBlock) {
+        const int a = it / ojm, rem = it - a * ojm, b = rem / G.m, c = rem - b * G.m;
+        const int io = bi * G.oi + a, jo = bj * G.oj + b, ko = kk0 + c;
+        if (io < P.xd.x && jo < xdy && ko < xdz) P.dst[((size_t)io * xdy + jo) * xdz + ko] = 0.f;
+      }
+    } else {
+      const bool plain0 = (NK > 0 ? NK : P.nk) == 1 && (SK > 0 ? SK : G.sk) == 1;
+      const int per_row = plain0 ? npts : min(G.m, xdz - kk0), first = plain0 ? k0 : kk0;
+      for (int it = tid; it < ROWS * per_row; it += kBlock) {
+        const int row = it / per_row, c = it - row * per_row;
+        const int i = i0 + row / TJ, j = j0 + row % TJ;
+        if (i < G.gd.x && j < G.gd.y) P.dst[((size_t)i * xdy + j) * xdz + first + c] = 0.f;
+      }
+    }
+#ifdef UNIRES_P2_PROF
+    if (pw && threadIdx.x == 0) pw[1] = pw[2] = wall_clock64();
+#endif
+    return;
+  }
   if (tid < SZ4) {
     const int ox = rec[4 + 2 * tid], oy = rec[5 + 2 * tid];
     org[tid] = make_int2(ox, oy);
@@ -409,7 +443,7 @@ static long long p2_blocks(const P2Geom &G, Dim3i xd) {
   return (long long)((xd.x + G.oi - 1) / G.oi) * G.nbj * G.nbc;
 }
 
-int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd, Dim3i gd) {
+int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd, Dim3i gd, float tol) {
   Q.valid = false;
   static const bool off = getenv("UNIRES_NO_PULL2") != nullptr;
   if (off) return 1;
@@ -424,7 +458,8 @@ int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd,
     if (hipMalloc((void **)&Q.rec, (size_t)nblk * kP2Rec * sizeof(int)) != hipSuccess) return 1;
     Q.cap = (size_t)nblk;
   }
-  hipLaunchKernelGGL(k_pull2_plan, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, G, (int)nblk, Q.rec);
+  hipLaunchKernelGGL(k_pull2_plan, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, G, (int)nblk, tol, Q.rec);
+  Q.tol = tol;
   if (hipDeviceSynchronize() != hipSuccess) return 1;
   static_assert(sizeof(P2Geom) <= sizeof(Q.key), "PullPlan key too small");
   memset(Q.key, 0, sizeof(Q.key));
@@ -443,7 +478,7 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
   if (!p2_geometry(sd, A, T, S, xd, gd, P.G, W, H)) return 1;
   P2Geom key;
   memcpy(&key, Q.key, sizeof(key));
-  if (!same_geom(key, P.G)) return 1;  // the plan was built for another operator
+  if (!same_geom(key, P.G) || tol != Q.tol) return 1;  // the plan was built for another operator / mask tolerance
   P.src = src, P.rec = Q.rec;
   for (int i = 0; i < UNIRES_MAX_TAPS; ++i) {
     P.kz[i] = i < T.n[2] ? T.t[2][i] : 0.f;

@@ -11,12 +11,13 @@ struct PullPlan {
   int *rec = nullptr;  // device
   size_t cap = 0;      // workgroup records allocated
   bool valid = false;
+  float tol = 0.f;               // in-FOV tolerance the all-outside flags were computed for
   unsigned char key[192] = {0};  // the geometry it was built for
 };
 
 // Builds (or rebuilds) the table; synchronises the device (plan time only).  Non-zero: the
 // operator is outside the kernel's domain (plan left invalid; callers use the general kernels).
-int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd, Dim3i gd);
+int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd, Dim3i gd, float tol);
 void pull2_free(PullPlan &Q);
 
 // xs = S conv_down_z pull_A(src)  (dst is the grid-space volume when T has no taps).
