@@ -541,6 +541,7 @@ struct S2Args {
   double *partials;
   const float *objb;
   int dbg;  // UNIRES_S2_DBG ablation bits (read only by -DUNIRES_ABLATE builds)
+  int prio_rot;  // rotate the waves' issue priority per tile (UNIRES_S2_PRIO=0 switches it off)
   int xlo[9];  // tile range [xlo[x], xlo[x + 1]) of partition x (an XCD when the grid has >= 8 workgroups)
   unsigned long long *prof;  // -DUNIRES_S2_PROF builds: per-wave timeline (100 MHz ticks)
 };
@@ -593,7 +594,24 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
   int ptile = 0;
   if (pw && lane == 0) pw[0] = wall_clock64();
 #endif
-  for (int t = t_lo + slot; t < t_hi; t += slots) {
+  // The SIMD's arbiter issues from its OLDEST wave first: of the four waves that share a SIMD the
+  // first to arrive ran its instruction stream at 0.43 us per instruction, the last at 0.62 us - same
+  // work, and the youngest waves set the kernel time.  User priority beats age, so every wave walks
+  // through the four priorities, one per tile, starting from its slot on the SIMD: over a wave's 4.5
+  // tiles the four of a SIMD are each first, second, third and last once: 81.8 -> 76.8 us.  (Rotating
+  // every 8 instructions instead: 80.7 us - strict priorities are the efficient way to run, it is
+  // the fixed ranking that unbalances.)
+  const int hw_slot = (int)(__builtin_amdgcn_s_getreg(6148) & 3u);  // HW_ID.wave_id
+  int round = 0;
+  for (int t = t_lo + slot; t < t_hi; t += slots, ++round) {
+    if (P.prio_rot) {
+      switch ((hw_slot + round) & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+      }
+    }
     const S2TileGeom g = s2_tile(P.tile_geom[t], dd);
     const int x0 = g.x0, y0 = g.y0, z0 = g.z0, ex = g.ex, ey = g.ey, ez = g.ez;
     const uint2 off0 = P.tile_off[t], off1 = P.tile_off[t + 1];
@@ -906,6 +924,8 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
   } else {  // fewer workgroups than XCDs: one equal share per workgroup
     for (int x = 0; x <= 8; ++x) P.xlo[x] = (int)std::min<long long>(S.ntiles, ((long long)S.ntiles * x + grid.x - 1) / grid.x);
   }
+  static const int prio_rot = getenv("UNIRES_S2_PRIO") ? atoi(getenv("UNIRES_S2_PRIO")) : 1;
+  P.prio_rot = prio_rot;
   P.prof = nullptr;
 #ifdef UNIRES_S2_PROF
   static unsigned long long *prof_dev = nullptr;
