@@ -241,6 +241,10 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   //    issued together (sched_barrier between the phases; row by row the compiler serialises two
   //    dependent LDS round trips per row): 65 us - 148 VGPRs, one workgroup fewer per CU, and capped
   //    at 128 it spills;
+  //  * the workgroup's geometry (z range, flags, window origins) computed at its head, lane-parallel,
+  //    instead of read from the plan's table: 53 / 57 / 60 us for the three channels against 52.5 /
+  //    55 / 56 with the table - the table read costs less than ~45 vector instructions and three
+  //    cross-lane reductions in front of the first barrier;
   //  * the row part of the coordinates computed by lane r for row r and broadcast with v_readlane:
   //    the same 55 us, and SQ_INSTS_VALU went UP 7 % (the compiler already shares the products of a
   //    row's i with the 8 rows that have it).
