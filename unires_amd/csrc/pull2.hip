@@ -23,6 +23,8 @@
 // The coordinate arithmetic is affine_row / affine_along, bit for bit the splat's, so the pair
 // stays an exact adjoint.
 #include <math.h>
+
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -130,7 +132,6 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   extern __shared__ __align__(16) float win[];  // W * H columns x SZ planes
   __shared__ int tab[SZ4 + 2];                  // per plane group: -(ox * H + oy) * SZ, in floats
   __shared__ int2 org[SZ4];
-  __shared__ float scr[GEN ? ROWS : NW * HALF][SCR];  // pulled rows awaiting the conv
   __shared__ unsigned char rowi[ROWS], rowj[ROWS];     // GEN: row -> (ri, rj)
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -258,7 +259,12 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   const bool plain = nk == 1 && sk == 1;
   const int nout = min(G.m, xdz - kk0);
   const float inv_m = 1.f / (float)G.m;
-#pragma unroll 1
+  // A wave first pulls all of its rows (one value per lane and row stays in a register), then the
+  // workgroup meets once and the rows go through the conv in a scratch that ALIASES the window -
+  // dead by then: no LDS of its own for the scratch (it was 8.3 KB, 16.6 KB with profiles along x / y),
+  // so a fifth workgroup fits a CU where the window is <= 32 KB.
+  float hvall[RPW];
+#pragma unroll
   for (int h0 = 0; h0 < RPW; h0 += HALF) {
     float hv[HALF];
 #pragma unroll
@@ -293,34 +299,34 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
       }
       hv[r] = lane < npts ? v : 0.f;
     }
-    if (P.dbg & 4) {
-      if (hv[0] + hv[HALF - 1] == 123.f) P.dst[0] = 1.f;
-      continue;
-    }
-    if (GEN) {  // keep the rows for the workgroup-wide separable conv below
 #pragma unroll
-      for (int r = 0; r < HALF; ++r) scr[wave * RPW + h0 + r][lane] = hv[r];
-      continue;
-    }
-    if (plain) {  // no slice profile: the pulled rows are the output
+    for (int r = 0; r < HALF; ++r) hvall[h0 + r] = hv[r];
+  }
+  float (*scr)[SCR] = reinterpret_cast<float (*)[SCR]>(win);
+  if (P.dbg & 4) {
+    if (hvall[0] + hvall[RPW - 1] == 123.f) P.dst[0] = 1.f;
+  } else if (GEN) {  // keep the rows for the workgroup-wide separable conv below
+    __syncthreads();  // every wave is done with the window
 #pragma unroll
-      for (int r = 0; r < HALF; ++r) {
-        const int row = wave * RPW + h0 + r;
-        const int i = i0 + row / TJ, j = j0 + row % TJ;
-        if (i < G.gd.x && j < G.gd.y && lane < npts)
-          P.dst[((size_t)i * xdy + j) * xdz + k0 + lane] = hv[r] * P.se;
-      }
-      continue;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private scratch: no barrier needed
+    for (int r = 0; r < RPW; ++r) scr[wave * RPW + r][lane] = hvall[r];
+  } else if (plain) {  // no slice profile: the pulled rows are the output
 #pragma unroll
-    for (int r = 0; r < HALF; ++r) scr[wave * HALF + r][lane] = hv[r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int it = lane; it < HALF * G.m; it += kWave) {
-      const int r = (int)(((float)it + 0.5f) * inv_m), win_i = it - r * G.m;  // exact: it < 2^20
-      const int row = wave * RPW + h0 + r;
+    for (int r = 0; r < RPW; ++r) {
+      const int row = wave * RPW + r;
       const int i = i0 + row / TJ, j = j0 + row % TJ;
-      const float *h = &scr[wave * HALF + r][win_i * sk];
+      if (i < G.gd.x && j < G.gd.y && lane < npts)
+        P.dst[((size_t)i * xdy + j) * xdz + k0 + lane] = hvall[r] * P.se;
+    }
+  } else {
+    __syncthreads();  // every wave is done with the window; the scratch rows below are wave-private
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) scr[wave * RPW + r][lane] = hvall[r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int it = lane; it < RPW * G.m; it += kWave) {
+      const int r = (int)(((float)it + 0.5f) * inv_m), win_i = it - r * G.m;  // exact: it < 2^20
+      const int row = wave * RPW + r;
+      const int i = i0 + row / TJ, j = j0 + row % TJ;
+      const float *h = &scr[row][win_i * sk];
       float acc = 0.f;
       if (NK > 0) {
 #pragma unroll
@@ -497,7 +503,8 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
   P.dst = dst, P.xd = xd, P.tol = tol, P.W = W;
   static const int dbg = getenv("UNIRES_P2_DBG") ? atoi(getenv("UNIRES_P2_DBG")) : 0;
   P.dbg = dbg;
-  const size_t lds = (size_t)W * H * kP2SZ * sizeof(float);
+  // the window, or the conv scratch that aliases it (64 rows x 65 floats) if that is larger
+  const size_t lds = std::max((size_t)W * H * kP2SZ, (size_t)kP2Rows * (kWave + 1)) * sizeof(float);
   const dim3 grid((unsigned)p2_blocks(P.G, xd)), block(kBlock);
   P.prof = nullptr;
 #ifdef UNIRES_P2_PROF
