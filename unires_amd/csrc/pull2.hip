@@ -36,7 +36,13 @@ namespace unires {
 
 constexpr int kP2SZ = 72, kP2SZ4 = kP2SZ / 4;  // z planes of a window (64 + drift + 2 + alignment)
 constexpr int kP2Items = 10;                    // 16-byte window pieces staged per thread (at most)
-constexpr int kP2TI = 8, kP2TJ = 8;             // grid rows per workgroup (profile along z only)
+#ifndef UNIRES_P2_TI
+#define UNIRES_P2_TI 4
+#endif
+#ifndef UNIRES_P2_TJ
+#define UNIRES_P2_TJ 8
+#endif
+constexpr int kP2TI = UNIRES_P2_TI, kP2TJ = UNIRES_P2_TJ;  // grid rows per workgroup (profile along z only)
 constexpr int kP2Rows = 64;                     // ... and at most, in any layout
 
 struct P2Geom {
@@ -127,12 +133,13 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   if (pw && threadIdx.x == 0) pw[0] = wall_clock64(), pw[4] = __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4);
 #endif
   constexpr int SZ = kP2SZ, SZ4 = kP2SZ4, NW = kBlock / kWave, TI = kP2TI, TJ = kP2TJ;
-  constexpr int ROWS = kP2Rows, RPW = ROWS / NW, HALF = 8, SCR = kWave + 1;
-  static_assert(TI * TJ == ROWS && ROWS % NW == 0 && RPW % HALF == 0, "rows per wave");
+  constexpr int ROWS = GEN ? kP2Rows : TI * TJ, RPW = ROWS / NW, SCR = kWave + 1;
+  constexpr int HALF = RPW % 8 == 0 ? 8 : (RPW % 6 == 0 ? 6 : 4);
+  static_assert(TI * TJ <= kP2Rows && ROWS % NW == 0 && RPW % HALF == 0, "rows per wave");
   extern __shared__ __align__(16) float win[];  // W * H columns x SZ planes
   __shared__ int tab[SZ4 + 2];                  // per plane group: -(ox * H + oy) * SZ, in floats
   __shared__ int2 org[SZ4];
-  __shared__ unsigned char rowi[ROWS], rowj[ROWS];     // GEN: row -> (ri, rj)
+  __shared__ unsigned char rowi[kP2Rows], rowj[kP2Rows];  // GEN: row -> (ri, rj)
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const P2Geom &G = P.G;
@@ -236,8 +243,10 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   //    instead of interleaving them;
   //  * persistent workgroups looping over work items (1024 - 2560 of them): 61 - 70 us - the
   //    hardware dispatcher balances 10 240 short workgroups better than a static loop does;
-  //  * 4 x 8 instead of 8 x 8 rows per workgroup: the same 55 us (more workgroups per CU, more
-  //    window overlap);
+  //  * (r2, with the conv scratch still in LDS of its own) 4 x 8 instead of 8 x 8 rows per workgroup:
+  //    the same 55 us.  Once the scratch aliases the window, LDS is the window alone and 4 x 8 rows
+  //    (7 x 10 columns = 20 KB, eight workgroups = every wave slot of a CU) beat 8 x 8 (29 KB, five):
+  //    config 3 47.6 vs 49.4 us, config 2 22 / 24 vs 26 / 31 us, config 4 155 vs 167 us;
   //  * the rows of a half in groups of 2 / 4 / 8 with their table reads, then their window reads
   //    issued together (sched_barrier between the phases; row by row the compiler serialises two
   //    dependent LDS round trips per row): 65 us - 148 VGPRs, one workgroup fewer per CU, and capped
