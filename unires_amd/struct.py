@@ -91,6 +91,8 @@ class settings:
         # 'fft': build-side FFT-diagonal preconditioner (circulant a I + rho lam^2 DtD)
         self.cgs_precond = 'none'
         # build-side knob: enqueue the (independent) channels of the y-update on separate HIP streams
+        # (round 2, streams vs one channel after the other: config 3 within +-4 % either way - its
+        # kernels fill the chip alone; config 2 +20 %, config 4 +15 %, the demo's shape +25 %)
         self.channel_streams = True
         # build-side knob: keep sum_n tau_n At x_n across ADMM iterations (recomputed on change)
         self.cache_atx = True
