@@ -108,6 +108,30 @@ def test_proj_info_matches_oracle(scale, dim_x, lib):
         assert da == tuple(db) and torch.allclose(ma, mb, atol=1e-12)
 
 
+@pytest.mark.parametrize('vx_x,samp', [((0.4, 0.4, 1.0), 1), ((0.5, 0.5, 0.8), 1), ((1.0, 1.0, 3.0), 3),
+                                       ((0.5, 0.5, 0.5), 1), ((0.3, 0.9, 0.6), 1)])
+def test_proj_info_subsampled_matches_oracle(vx_x, samp, lib):
+    """Sub-sampling branch (unires/_project.py:245-264) with the reference's default profiles
+    (profile_ip = 2, profile_tp = 0, struct.py:95-96): the thick axis, the profile and the gap come
+    from the ORIGINAL voxel size (:239-243 sit above the samp block), so decimation that moves the
+    argmax of vx_x - (0.5, 0.5, 0.8) -> (1, 1, 0.8) - or creates a tie must not move dim_thick."""
+    import unires_amd as U
+    dim_y, dim_x = (40, 44, 36), (32, 30, 18)
+    mat_y = torch.diag(torch.tensor([0.4, 0.4, 0.4, 1.0], dtype=torch.float64))
+    mat_x = torch.diag(torch.tensor(list(vx_x) + [1.0], dtype=torch.float64))
+    mat_x[:3, 3] = torch.tensor([0.3, -0.2, 0.5], dtype=torch.float64)
+    rigid = rigid_matrix([0.4, -0.3, 0.2], [0.01, -0.02, 0.015])
+    a = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=2, prof_tp=0, scl=0.07, gap=0.1,
+                     device='cpu', samp=samp)
+    b = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=2, prof_tp=0, scl=0.07, gap=0.1,
+                    samp=samp)
+    assert a.dim_thick == b.dim_thick
+    assert a.dim_x == b.dim_x and a.dim_yx == b.dim_yx and a.ratio == b.ratio
+    assert torch.allclose(a.mat_x, b.mat_x, atol=1e-12) and torch.allclose(a.mat_yx, b.mat_yx, atol=1e-12)
+    assert a.smo_ker.shape == b.smo_ker.shape
+    assert torch.allclose(a.smo_ker.cpu(), b.smo_ker, atol=1e-7)
+
+
 def test_step_size_matches_oracle(lib):
     import unires_amd as U
     x = [[U._input(None, None, 4.2e-4)], [U._input(None, None, 2.5e-4), U._input(None, None, 1.6e-4)]]

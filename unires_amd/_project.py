@@ -44,6 +44,15 @@ def _proj_info(dim_y, mat_y, dim_x, mat_x, rigid=None, prof_ip=0, prof_tp=0, gap
     po.rigid = torch.eye(4, dtype=_F64) if rigid is None \
         else torch.as_tensor(rigid).detach().to('cpu', _F64)
     po.D_x = po.D_y = None
+    # thick-slice axis and per-axis profile / gap: from the ORIGINAL voxel size, before any
+    # sub-sampling (unires/_project.py:239-243 sit above the samp block :245-264; decimation can move
+    # the argmax: vx_x = (0.4, 0.4, 1), samp = 1 decimates to (0.8, 0.8, 1) - still z - but
+    # vx_x = (0.5, 0.5, 0.8) becomes (1, 1, 0.8))
+    po.dim_thick = int(torch.max(po.vx_x, dim=0)[1])
+    profile = [int(prof_ip)] * 3
+    gaps = [0.0] * 3
+    profile[po.dim_thick] = int(prof_tp)
+    gaps[po.dim_thick] = float(gap)
     if samp > 0:
         # sub-sampling for the rigid Gauss-Newton (unires/_project.py:245-264): the low-res image is
         # decimated by sk = max(1, floor(samp / vx_x + 0.5)) voxels per axis: mat_x <- mat_x D_x,
@@ -59,12 +68,6 @@ def _proj_info(dim_y, mat_y, dim_x, mat_x, rigid=None, prof_ip=0, prof_tp=0, gap
         if min(dim_x) < 1:
             raise ValueError('sub-sampling leaves an empty image')
         po.dim_x, po.mat_x, po.vx_x = dim_x, mat_x, voxel_size(mat_x)
-    # thick-slice axis and per-axis profile / gap
-    po.dim_thick = int(torch.max(po.vx_x, dim=0)[1])
-    profile = [int(prof_ip)] * 3
-    gaps = [0.0] * 3
-    profile[po.dim_thick] = int(prof_tp)
-    gaps[po.dim_thick] = float(gap)
     # low-res / high-res voxel ratio, rounded up, at least one
     lin = torch.linalg.solve(mat_y, mat_x)[:3, :3]
     ratio = (lin ** 2).sum(0).sqrt().ceil().clamp(1)

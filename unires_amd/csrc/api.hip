@@ -20,6 +20,7 @@
 #include "ops.hpp"
 #include "pull2.hpp"
 #include "splat2.hpp"
+#include "stencil.hpp"
 
 using namespace unires;
 
@@ -624,6 +625,10 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
     return fail(UNIRES_ERR_DIM, "new repeat exceeds the plan's workspace");
   if (plan->regime == UNIRES_REGIME_SUPERRES && (tmp.sep || tmp.hyb) && !plan->gbuf2)
     return fail(UNIRES_ERR_DIM, "new repeat needs the separable-conv scratch the plan was built without");
+  // The tables rebuilt below (pull records, splat schedule, conv tables) are rewritten by kernels on
+  // the NULL stream and synchronous copies; work queued on the caller's - possibly non-blocking -
+  // streams may still be reading them: wait for the device first.
+  (void)hipDeviceSynchronize();
   drop_cg_graph(plan);  // the captured solve has the old operator baked in
   plan->prec_ready = false;  // a preconditioner built for the old operator is stale
   if (tmp.dim_gf.z != plan->reps[n].dim_gf.z) free_ztabs(plan->reps[n]);
@@ -841,6 +846,12 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
     float a0 = 0.f;
     for (const Repeat &R : pl->reps) a0 += R.tau;
     static const bool no_lines = getenv("UNIRES_NO_ALIGNED") != nullptr;
+    static const bool no_flat = getenv("UNIRES_NO_FLAT") != nullptr;
+    const float ivx = 1.f / (pl->vx[0] * pl->vx[0]), ivy = 1.f / (pl->vx[1] * pl->vx[1]),
+                ivz = 1.f / (pl->vx[2] * pl->vx[2]);
+    // one flat streaming pass (stencil.hip); the line kernel and the generic one are its fallbacks
+    if (!no_flat && !launch_dtd_flat(p, q, pl->dy, a0, c * ivx, c * ivy, c * ivz, part, objb, done, st))
+      return part ? dtd_flat_blocks(pl->dy) : 0;
     if (!no_lines &&
         !launch_dtd_lines(p, q, pl->dy, a0, c / (pl->vx[0] * pl->vx[0]), c / (pl->vx[1] * pl->vx[1]),
                           c / (pl->vx[2] * pl->vx[2]), part, objb, done, st))
@@ -1042,23 +1053,33 @@ static int cg_enqueue(unires_plan *pl, float rho, float lam, const float *b, flo
   }
   launch_sc_init(S, pl->part0, pl->part1, gv, stop_mode, check ? 1 : 0, st);
 
+  // UNIRES_CG_FOLD=0: alpha / beta in one-block kernels of their own (the r1 / r2 form)
+  static const bool fold_on = !(getenv("UNIRES_CG_FOLD") && getenv("UNIRES_CG_FOLD")[0] == '0');
+  const int gf = vec_num_blocks_fold(ny);
   for (int k = 1; k <= max_iter; ++k) {
     const int g = matvec(pl, rho, lam, pl->p, pl->ap, pl->part0, done, st);
-    launch_sc_alpha(S, pl->part0, g, st);
     const bool recur = check && stop_mode == UNIRES_STOP_MAXGAIN_RECURRED;
     int obj_kind = 0;
     if (check && stop_mode == UNIRES_STOP_RESIDUAL) obj_kind = 1;
     if (recur) obj_kind = 2;
     // "x += alpha p" rides with the p update unless sc_beta can stop the solve in between
     const bool lazy_x = obj_kind == 0;
-    launch_update_xr(S, pl->p, pl->ap, lazy_x ? nullptr : x, pl->r, b, ny, pl->part0,
-                     recur ? pl->part1 : nullptr, M, st);
-    if (fft) {  // (the transforms also run after convergence: hipFFT has no device-side skip)
-      if (fftpre_apply(pl->fft, pl->r, pl->fft.z, st)) return fail(UNIRES_ERR_HIP, "hipFFT execution failed");
-      launch_dot(pl->r, pl->fft.z, ny, pl->part0, done, st);
+    if (fold_on && lazy_x && !fft) {
+      // no scalar kernels: alpha in the prologue of the r update (its r.z partials go to part1 -
+      // part0 is being read by every workgroup), beta in the prologue of the x / p update
+      launch_update_r_fold(S, pl->part0, g, k, pl->ap, pl->r, ny, pl->part1, M, st);
+      launch_update_px_fold(S, pl->part1, gf, k, pl->r, pl->p, x, ny, M, st);
+    } else {
+      launch_sc_alpha(S, pl->part0, g, st);
+      launch_update_xr(S, pl->p, pl->ap, lazy_x ? nullptr : x, pl->r, b, ny, pl->part0,
+                       recur ? pl->part1 : nullptr, M, st);
+      if (fft) {  // (the transforms also run after convergence: hipFFT has no device-side skip)
+        if (fftpre_apply(pl->fft, pl->r, pl->fft.z, st)) return fail(UNIRES_ERR_HIP, "hipFFT execution failed");
+        launch_dot(pl->r, pl->fft.z, ny, pl->part0, done, st);
+      }
+      launch_sc_beta(S, pl->part0, pl->part1, gv, k, obj_kind, tol, st);
+      launch_update_p(S, fft ? pl->fft.z : pl->r, pl->p, ny, M, lazy_x ? x : nullptr, st);
     }
-    launch_sc_beta(S, pl->part0, pl->part1, gv, k, obj_kind, tol, st);
-    launch_update_p(S, fft ? pl->fft.z : pl->r, pl->p, ny, M, lazy_x ? x : nullptr, st);
     if (check && stop_mode == UNIRES_STOP_MAXGAIN) {
       // objective sum x (Ax - 2b) folded into the matvec epilogue: A(x) is never stored
       const int go = matvec(pl, rho, lam, x, pl->ax, pl->part1, done, st, b);

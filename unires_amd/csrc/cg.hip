@@ -204,6 +204,111 @@ __global__ void __launch_bounds__(kBlock)
     y[i] = fmaf(a, x[i], y[i]);
 }
 
+// ---- folded forms: the scalar steps ride in the prologues of the vector kernels ------------
+// (r2 tried the opposite fold - the LAST workgroup of the producer sums the partials - which needs
+// an agent-scope release per workgroup, an L2 write-back each: 4 200 -> 1 550 iterations/s.  Here
+// nothing crosses workgroups inside a launch: every consumer workgroup reads the producer's <= 8192
+// partials (L2 hits, 64 KB at most) after the kernel boundary and sums them in the same fixed
+// order.  The vector kernels run as 1024 persistent workgroups so that the prologue is paid once
+// per workgroup and all of them are resident together.)
+__device__ __forceinline__ double reduce_all(const double *__restrict__ part, int g) {
+  __shared__ double s_tot[kBlock / kWave];
+  double v = 0.0;
+  int i = threadIdx.x;
+  for (; i + 7 * kBlock < g; i += 8 * kBlock) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = part[i + u * kBlock];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; i < g; i += kBlock) v += part[i];
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) s_tot[threadIdx.x / kWave] = v;
+  __syncthreads();
+  double tot = 0.0;
+#pragma unroll
+  for (int w = 0; w < kBlock / kWave; ++w) tot += s_tot[w];
+  return tot;  // the same value, bit for bit, in every thread of every workgroup
+}
+
+static inline int vec_blocks_fold(size_t n) {
+  size_t b = (n / 4 + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  return (int)(b < 1024 ? b : 1024);
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_update_r_fold(CgState *__restrict__ st, const double *__restrict__ part_pap, int g, int k,
+                    const float *__restrict__ ap, float *__restrict__ r, size_t n,
+                    double *__restrict__ part_rr, const float *__restrict__ M) {
+  if (st->done) return;
+  const double pap = reduce_all(part_pap, g);
+  const double alpha_d = st->rzpp[(k - 1) & 1] / pap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->pAp = pap, st->alpha = alpha_d;
+  const float alpha = (float)alpha_d;
+  GRID_STRIDE_VEC4(n);
+  double rr = 0.0;
+  for (size_t i = tid0; i < n4; i += stride) {
+    const float4 va = ld4(ap, i);
+    float4 vr = ld4(r, i);
+    vr.x = __fsub_rn(vr.x, __fmul_rn(alpha, va.x));
+    vr.y = __fsub_rn(vr.y, __fmul_rn(alpha, va.y));
+    vr.z = __fsub_rn(vr.z, __fmul_rn(alpha, va.z));
+    vr.w = __fsub_rn(vr.w, __fmul_rn(alpha, va.w));
+    st4(r, i, vr);
+    const float4 vz = zval4(vr, M, i);
+    rr += (double)__fmul_rn(vr.x, vz.x) + (double)__fmul_rn(vr.y, vz.y) +
+          (double)__fmul_rn(vr.z, vz.z) + (double)__fmul_rn(vr.w, vz.w);
+  }
+  for (size_t i = n4 * 4 + tid0; i < n; i += stride) {
+    const float vr = __fsub_rn(r[i], __fmul_rn(alpha, ap[i]));
+    r[i] = vr;
+    rr += (double)__fmul_rn(vr, zval1(vr, M, i));
+  }
+  const double t = block_sum(rr);
+  if (threadIdx.x == 0) part_rr[blockIdx.x] = t;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_update_px_fold(CgState *__restrict__ st, const double *__restrict__ part_rr, int g, int k,
+                     const float *__restrict__ r, float *__restrict__ p, float *__restrict__ x, size_t n,
+                     const float *__restrict__ M) {
+  if (st->done) return;
+  const double rr = reduce_all(part_rr, g);
+  const double rz0 = st->rzpp[(k - 1) & 1];
+  const double beta_d = rr / rz0;
+  const float beta = (float)beta_d, alpha = (float)st->alpha;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->rzpp[k & 1] = rr;
+    st->rz = rr;
+    st->beta = beta_d;
+    st->iters = k;
+  }
+  GRID_STRIDE_VEC4(n);
+  for (size_t i = tid0; i < n4; i += stride) {
+    const float4 vr = zval4(ld4(r, i), M, i);
+    float4 vp = ld4(p, i);
+    float4 vx = ld4(x, i);
+    vx.x = __fadd_rn(vx.x, __fmul_rn(alpha, vp.x));
+    vx.y = __fadd_rn(vx.y, __fmul_rn(alpha, vp.y));
+    vx.z = __fadd_rn(vx.z, __fmul_rn(alpha, vp.z));
+    vx.w = __fadd_rn(vx.w, __fmul_rn(alpha, vp.w));
+    st4(x, i, vx);
+    vp.x = __fadd_rn(__fmul_rn(beta, vp.x), vr.x);
+    vp.y = __fadd_rn(__fmul_rn(beta, vp.y), vr.y);
+    vp.z = __fadd_rn(__fmul_rn(beta, vp.z), vr.z);
+    vp.w = __fadd_rn(__fmul_rn(beta, vp.w), vr.w);
+    st4(p, i, vp);
+  }
+  for (size_t i = n4 * 4 + tid0; i < n; i += stride) {
+    const float vp = p[i];
+    x[i] = __fadd_rn(x[i], __fmul_rn(alpha, vp));
+    p[i] = __fadd_rn(__fmul_rn(beta, vp), zval1(r[i], M, i));
+  }
+}
+
 // ---- scalar kernels: <<<1, kBlock>>> -------------------------------------
 // (Tried and dropped, r2: folding k_sc_alpha / k_sc_beta into the kernels that write their
 // partials - every workgroup takes a ticket, the last one sums all partials in a fixed order.  The
@@ -248,6 +353,8 @@ __global__ void __launch_bounds__(kBlock)
   if (check && mode != UNIRES_STOP_RESIDUAL) ob = sum_partials(part_obj, g);
   if (threadIdx.x == 0) {
     st->rz = rr;
+    st->rzpp[0] = rr;
+    st->rzpp[1] = rr;
     st->done = 0;
     st->iters = 0;
     st->alpha = 0.0;
@@ -276,6 +383,7 @@ __global__ void __launch_bounds__(kBlock)
   if (threadIdx.x == 0) {
     const double rz0 = st->rz;
     st->rz = rr;
+    st->rzpp[k & 1] = rr;
     st->beta = rr / rz0;
     st->iters = k;
     if (obj_kind == 1) record_obj(st, k, sqrt(rr), tol);
@@ -297,6 +405,17 @@ __global__ void __launch_bounds__(kBlock) k_sum_to(const double *part, int g, do
 
 // ---- launchers -------------------------------------------------------------
 int vec_num_blocks(size_t n) { return vec_blocks(n); }
+int vec_num_blocks_fold(size_t n) { return vec_blocks_fold(n); }
+void launch_update_r_fold(CgState *s, const double *part_pap, int g, int k, const float *ap, float *r,
+                          size_t n, double *part_rr, const float *M, hipStream_t st) {
+  hipLaunchKernelGGL(k_update_r_fold, dim3(vec_blocks_fold(n)), dim3(kBlock), 0, st, s, part_pap, g, k, ap, r,
+                     n, part_rr, M);
+}
+void launch_update_px_fold(CgState *s, const double *part_rr, int g, int k, const float *r, float *p,
+                           float *x, size_t n, const float *M, hipStream_t st) {
+  hipLaunchKernelGGL(k_update_px_fold, dim3(vec_blocks_fold(n)), dim3(kBlock), 0, st, s, part_rr, g, k, r, p,
+                     x, n, M);
+}
 
 void launch_residual_init(const float *b, const float *ax, const float *x, float *r, float *p,
                           size_t n, double *part_rr, double *part_obj, const float *M,

@@ -9,6 +9,8 @@ constexpr int kMaxCgIter = 4096;
 struct CgState {  // lives in device memory, owned by the plan
   double rz, pAp, alpha, beta, obj_max, obj_min;
   int done, iters;
+  double rzpp[2];  // r.z of iterations k (slot k & 1) and k - 1: the folded kernels read one slot while
+                   // workgroup 0 of the same launch writes the other
   double obj[kMaxCgIter + 1];
 };
 
@@ -37,5 +39,17 @@ void launch_sc_beta(CgState *s, const double *part_rr, const double *part_obj, i
                     int obj_kind, double tol, hipStream_t st);
 void launch_sc_obj(CgState *s, const double *part, int g, int k, double tol, hipStream_t st);
 void launch_sum_to(const double *part, int g, double *out, hipStream_t st);
+// Folded forms (no scalar kernels between the matvec and the vector updates): EVERY workgroup
+// re-reduces the producer's partial sums in a fixed order in its prologue - visibility comes from
+// the kernel boundary, the order is the same everywhere, so all workgroups hold the same alpha /
+// beta bit for bit; workgroup 0 records them in the state.
+int vec_num_blocks_fold(size_t n);
+// r -= alpha Ap with alpha = rz / sum(part_pap[0..g)); part_rr (vec_num_blocks_fold(n) doubles, NOT the
+// buffer part_pap lives in) gets sum r*z
+void launch_update_r_fold(CgState *s, const double *part_pap, int g, int k, const float *ap, float *r,
+                          size_t n, double *part_rr, const float *M, hipStream_t st);
+// x += alpha p; p = z + beta p with beta = sum(part_rr[0..g)) / rz; records rz, beta, iters = k
+void launch_update_px_fold(CgState *s, const double *part_rr, int g, int k, const float *r, float *p,
+                           float *x, size_t n, const float *M, hipStream_t st);
 
 }  // namespace unires

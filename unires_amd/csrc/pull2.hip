@@ -17,6 +17,13 @@
 //               three scalar loads instead of a page of uniform float arithmetic.
 //   staging   = buffer_load_dwordx4 ... lds (LDS-DMA): the window is laid out so that item n of
 //               the load order is 16 bytes n of the LDS window - no VGPR round trip, no ds_write.
+//               The byte offset of an item is  boff[plane group] + coff[item]:  boff (window origin of
+//               the group, per workgroup) comes with the plan's record, coff and the item -> group map
+//               from a per-operator table (r3: the in-kernel form - two divisions by constants, a
+//               64-bit multiply-add and four range tests per item, five quarter-rate integer
+//               multiplies among them - was a quarter of the kernel's VALU time).  Plane groups that
+//               lie outside the volume along z carry an out-of-range origin, so every workgroup takes
+//               the LDS-DMA path (the volume's last, partial group is zero-filled after the barrier).
 //   conv_down = the slice profile runs on the pulled values of 8 rows at a time through a small
 //               padded LDS scratch; chunks are cut at multiples of the stride so every x-space
 //               voxel is produced by exactly one workgroup.
@@ -57,10 +64,14 @@ struct P2Geom {
   float pxi, pxj, sx, cx, pyi, pyj, sy, cy;
 };
 
-// per-workgroup record: {Z0, plane groups in use, all-inside flag, all-outside flag} then the 18 window origins
-constexpr int kP2Rec = 4 + 2 * kP2SZ4;
+// per-workgroup record: {Z0, plane groups in use, all-inside flag, flags} then the 18 window origins,
+// then the 18 byte offsets of the origins (kP2OobBase: the group is not staged)
+//   flags: 1 all samples outside the field of view, 2 every staged column inside the volume in x / y,
+//          4 the volume's last plane group is partial (planes >= sd.z to be zero-filled)
+constexpr int kP2Rec = 4 + 3 * kP2SZ4 + 2;
+constexpr unsigned kP2OobBase = 0x80000000u;  // + any in-window offset (< 2^31) stays out of range
 
-__global__ void k_pull2_plan(P2Geom G, int nblk, float tol, int *__restrict__ rec) {
+__global__ void k_pull2_plan(P2Geom G, int nblk, float tol, int W, int H, int *__restrict__ rec) {
   const int blk = blockIdx.x * blockDim.x + threadIdx.x;
   if (blk >= nblk) return;
   constexpr int SZ4 = kP2SZ4;
@@ -92,8 +103,8 @@ __global__ void k_pull2_plan(P2Geom G, int nblk, float tol, int *__restrict__ re
   const int Z0 = 4 * (int)floorf(floorf(zmin - 0.01f) * 0.25f);
   const int ngrp = min(SZ4, ((int)floorf(zmax + 0.01f) + 1 - Z0) / 4 + 1);
   int *r = rec + (size_t)blk * kP2Rec;
-  r[0] = Z0, r[1] = ngrp, r[2] = inside ? 1 : 0, r[3] = empty ? 1 : 0;
   const float fi0 = (float)i0, fi1 = (float)i1, fj0 = (float)j0, fj1 = (float)j1;
+  bool xyin = true, partial = false;
   for (int g = 0; g < SZ4; ++g) {
     // samples whose lower or upper corner plane falls in this group: gz in [Zg - 1, Zg + 4)
     const float za = (float)(Z0 + 4 * g - 1), zb = (float)(Z0 + 4 * g + 4);
@@ -101,14 +112,34 @@ __global__ void k_pull2_plan(P2Geom G, int nblk, float tol, int *__restrict__ re
                       fminf(G.sx * za, G.sx * zb);
     const float ylo = G.cy + fminf(G.pyi * fi0, G.pyi * fi1) + fminf(G.pyj * fj0, G.pyj * fj1) +
                       fminf(G.sy * za, G.sy * zb);
-    r[4 + 2 * g] = (int)floorf(xlo - 0.02f);
-    r[5 + 2 * g] = (int)floorf(ylo - 0.02f);
+    const int ox = (int)floorf(xlo - 0.02f), oy = (int)floorf(ylo - 0.02f);
+    r[4 + 2 * g] = ox;
+    r[5 + 2 * g] = oy;
+    // byte offset of the group's origin column (wraps for negative origins: the sum with an in-volume
+    // column's offset is exact mod 2^32); groups beyond ngrp or wholly outside the volume along z are
+    // not staged (Z0 is a multiple of 4: a group below z = 0 is wholly below)
+    const int z = Z0 + 4 * g;
+    const bool staged = g < ngrp && z >= 0 && z < G.sd.z;
+    unsigned boff = kP2OobBase;
+    if (staged) {
+      boff = 4u * (unsigned)((ox * G.sd.y + oy) * G.sd.z + z);
+      xyin = xyin && ox >= 0 && ox + W <= G.sd.x && oy >= 0 && oy + H <= G.sd.y;
+      partial = partial || z + 3 >= G.sd.z;
+    }
+    r[4 + 2 * SZ4 + g] = (int)boff;
   }
+  r[0] = Z0, r[1] = ngrp, r[2] = inside ? 1 : 0;
+  r[3] = (empty ? 1 : 0) | (xyin ? 2 : 0) | (partial ? 4 : 0);
+  r[4 + 3 * SZ4] = (int)kP2OobBase;  // slot the padding items of the table point at
+  r[5 + 3 * SZ4] = 0;
 }
 
 struct P2Args {
   const float *src;
   const int *rec;
+  const int2 *itab;  // per staging item: {4 * plane group, byte offset inside the window} ...
+  const int *itab2;  // ... and cxl | cyl << 16 (column inside the window; read by workgroups at the volume's x / y faces)
+  float inv_m;       // 1 / G.m
   P2Geom G;
   float kz[UNIRES_MAX_TAPS], kx[UNIRES_MAX_TAPS], ky[UNIRES_MAX_TAPS];
   int nk;            // taps along grid z (1 with sk 1: no conv)
@@ -139,6 +170,7 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   extern __shared__ __align__(16) float win[];  // W * H columns x SZ planes
   __shared__ int tab[SZ4 + 2];                  // per plane group: -(ox * H + oy) * SZ, in floats
   __shared__ int2 org[SZ4];
+  __shared__ unsigned boff[SZ4 + 1];            // per plane group: byte offset of the window origin; [SZ4]: out of range
   __shared__ unsigned char rowi[kP2Rows], rowj[kP2Rows];  // GEN: row -> (ri, rj)
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -152,9 +184,21 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   const int npts = min(kWave, G.gd.z - k0);  // grid points of this chunk along z
   const Dim3i sd = G.sd;
   const int *rec = P.rec + (size_t)blk * kP2Rec;
-  const int Z0 = rec[0], ngrp = rec[1];
+  const int Z0 = rec[0];
   const bool inside = rec[2] != 0;
-  if (rec[3] != 0) {
+  const int flags = rec[3];
+  // this thread's staging items: issued now, they travel while the record is read and the
+  // workgroup meets (the table is padded to whole waves; padding items point at the record's
+  // out-of-range slot)
+  const int nitem = P.W * H * SZ4;
+  int2 ie[kP2Items];
+#pragma unroll
+  for (int n = 0; n < kP2Items; ++n) {
+    const int base = n * kBlock + wave * kWave;
+    ie[n] = make_int2(4 * SZ4, 0);
+    if (base < nitem) ie[n] = P.itab[base + lane];
+  }
+  if (flags & 1) {
     // every sample of this workgroup lies outside the field of view (the part of the observation's
     // grid that sticks out of the volume: ~10 % of config 3's workgroups): its outputs are zeros
     const int xdy = P.xd.y, xdz = P.xd.z;
@@ -184,6 +228,7 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
     org[tid] = make_int2(ox, oy);
     tab[tid] = -(ox * H + oy) * SZ;
   }
+  if (tid >= kWave && tid < kWave + SZ4 + 1) boff[tid - kWave] = (unsigned)rec[4 + 2 * SZ4 + tid - kWave];
   if (GEN && tid < ROWS) {
     const int ri = tid / G.pj;
     rowi[tid] = (unsigned char)ri, rowj[tid] = (unsigned char)(tid - ri * G.pj);
@@ -193,41 +238,38 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   // load order lands on bytes 16 n of the window.  Pieces outside the volume come from an
   // out-of-range buffer offset (zeros, no branch). ----
   if (!(P.dbg & 1)) {
-    const int nitem = P.W * H * SZ4;
-    const bool zsafe = Z0 >= 0 && Z0 + 4 * ngrp <= sd.z;  // every piece inside the volume along z
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(P.src, sd.numel() * sizeof(float));
-    constexpr unsigned kOob = 0xfffffff0u;
-    if (zsafe) {
+    // (all origin reads first, then the loads: one LDS round trip per wave instead of one per item)
+    unsigned offs[kP2Items];
+#pragma unroll
+    for (int n = 0; n < kP2Items; ++n)
+      offs[n] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(boff) + ie[n].x) + (unsigned)ie[n].y;
+    if (!(flags & 2)) {  // the window sticks out of the volume in x / y: range test on every item's column
 #pragma unroll
       for (int n = 0; n < kP2Items; ++n) {
-        const int base = n * kBlock + wave * kWave;  // wave-uniform: LDS-DMA writes base + lane
+        const int base = n * kBlock + wave * kWave;
         if (base >= nitem) break;
-        const int it = base + lane;
-        const int zg = it % SZ4, slot = it / SZ4;  // (compile-time divisors)
-        const int cxl = slot / H, cyl = slot - cxl * H;
-        const int2 o = org[zg];
-        const int x = o.x + cxl, y = o.y + cyl, z = Z0 + 4 * zg;
-        const bool ok = zg < ngrp && x >= 0 && x < sd.x && y >= 0 && y < sd.y;
-        const unsigned off = 4u * (unsigned)((x * sd.y + y) * sd.z + z);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rs, (__attribute__((address_space(3))) void *)(win + 4 * base), 16, ok ? off : kOob, 0, 0, 0);
+        const int cc = P.itab2[base + lane];
+        const int2 o = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(org) + 2 * min(ie[n].x, 4 * (SZ4 - 1)));
+        const unsigned x = (unsigned)(o.x + (cc & 0xffff)), y = (unsigned)(o.y + (cc >> 16));
+        offs[n] = (x < (unsigned)sd.x && y < (unsigned)sd.y) ? offs[n] : kP2OobBase;
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      for (int it = tid; it < nitem; it += kBlock) {
-        const int zg = it % SZ4, slot = it / SZ4;
-        const int cxl = slot / H, cyl = slot - cxl * H;
-        const int2 o = org[zg];
-        const int x = o.x + cxl, y = o.y + cyl, z = Z0 + 4 * zg;
-        const bool ok = zg < ngrp && x >= 0 && x < sd.x && y >= 0 && y < sd.y;
-        const unsigned off = 4u * (unsigned)((x * sd.y + y) * sd.z + z);
-        float4 v;
-        v.x = buf_load(rs, ok && z >= 0 && z < sd.z ? off : kOob, 0);
-        v.y = buf_load(rs, ok && z + 1 >= 0 && z + 1 < sd.z ? off + 4u : kOob, 0);
-        v.z = buf_load(rs, ok && z + 2 >= 0 && z + 2 < sd.z ? off + 8u : kOob, 0);
-        v.w = buf_load(rs, ok && z + 3 >= 0 && z + 3 < sd.z ? off + 12u : kOob, 0);
-        *reinterpret_cast<float4 *>(win + 4 * it) = v;
-      }
+    }
+#pragma unroll
+    for (int n = 0; n < kP2Items; ++n) {
+      const int base = n * kBlock + wave * kWave;  // wave-uniform: LDS-DMA writes base + lane
+      if (base >= nitem) break;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs, (__attribute__((address_space(3))) void *)(win + 4 * base), 16, offs[n], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (flags & 4) {
+      // the volume's last plane group is partial (sd.z not a multiple of 4): its 16-byte pieces run
+      // into the next column - zero bound wants zeros there.  After every wave's pieces have landed.
+      __syncthreads();
+      const int gl = (sd.z - 1 - Z0) >> 2, first = sd.z - (Z0 + 4 * gl);  // planes first .. 3 of group gl
+      for (int c = tid; c < P.W * H; c += kBlock)
+        for (int q = first; q < 4; ++q) win[c * SZ + 4 * gl + q] = 0.f;
     }
   }
   __syncthreads();
@@ -267,7 +309,7 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   const int nk = NK > 0 ? NK : P.nk, sk = SK > 0 ? SK : G.sk;
   const bool plain = nk == 1 && sk == 1;
   const int nout = min(G.m, xdz - kk0);
-  const float inv_m = 1.f / (float)G.m;
+  const float inv_m = P.inv_m;
   // A wave first pulls all of its rows (one value per lane and row stays in a register), then the
   // workgroup meets once and the rows go through the conv in a scratch that ALIASES the window -
   // dead by then: no LDS of its own for the scratch (it was 8.3 KB, 16.6 KB with profiles along x / y),
@@ -332,10 +374,10 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
     for (int r = 0; r < RPW; ++r) scr[wave * RPW + r][lane] = hvall[r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int it = lane; it < RPW * G.m; it += kWave) {
-      const int r = (int)(((float)it + 0.5f) * inv_m), win_i = it - r * G.m;  // exact: it < 2^20
+      const int r = (int)(((float)it + 0.5f) * inv_m), win_i = it - __mul24(r, G.m);  // exact: it < 2^20
       const int row = wave * RPW + r;
       const int i = i0 + row / TJ, j = j0 + row % TJ;
-      const float *h = &scr[row][win_i * sk];
+      const float *h = &scr[0][0] + __mul24(row, SCR) + __mul24(win_i, sk);
       float acc = 0.f;
       if (NK > 0) {
 #pragma unroll
@@ -345,7 +387,9 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
       }
       const int kk = kk0 + win_i;
       acc *= (kk & 1) ? P.so : P.se;
-      if (win_i < nout && i < G.gd.x && j < G.gd.y) P.dst[((size_t)i * xdy + j) * xdz + kk] = acc;
+      // (x-space indices fit 24-bit multiplies: p2_geometry checks fits_fast_index(xd))
+      if (win_i < nout && i < G.gd.x && j < G.gd.y)
+        P.dst[__umul24(__umul24((unsigned)i, (unsigned)xdy) + (unsigned)j, (unsigned)xdz) + (unsigned)kk] = acc;
     }
   }
 #ifdef UNIRES_P2_PROF
@@ -392,6 +436,7 @@ static bool same_geom(const P2Geom &a, const P2Geom &b) { return memcmp(&a, &b, 
 
 void pull2_free(PullPlan &Q) {
   if (Q.rec) (void)hipFree(Q.rec);
+  if (Q.itab) (void)hipFree(Q.itab);
   Q = PullPlan();
 }
 
@@ -405,7 +450,7 @@ static bool p2_geometry(Dim3i sd, const Affine &A, const Taps &T, const Scaling 
   const int gdv[3] = {gd.x, gd.y, gd.z}, xdv[3] = {xd.x, xd.y, xd.z};
   for (int d = 0; d < 3; ++d)
     if (gdv[d] != (xdv[d] - 1) * T.s[d] + T.n[d]) return false;
-  if (sd.numel() >= (1ull << 30) || !fits_fast_index(sd)) return false;
+  if (sd.numel() >= (1ull << 29) || !fits_fast_index(sd) || !fits_fast_index(xd)) return false;  // (byte offsets + kP2OobBase stay below 2^32)
   const double a22 = A.m[10];
   if (!(fabs(a22) > 0.5)) return false;
   memset(&G, 0, sizeof(G));
@@ -477,7 +522,28 @@ int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd,
     if (hipMalloc((void **)&Q.rec, (size_t)nblk * kP2Rec * sizeof(int)) != hipSuccess) return 1;
     Q.cap = (size_t)nblk;
   }
-  hipLaunchKernelGGL(k_pull2_plan, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, G, (int)nblk, tol, Q.rec);
+  // staging items of a window (the same for every workgroup of the operator), padded to whole waves
+  const int nitem = W * H * kP2SZ4, npad = (nitem + kWave - 1) / kWave * kWave;
+  if ((size_t)npad > Q.itab_cap) {
+    if (Q.itab) (void)hipFree(Q.itab);
+    Q.itab = nullptr;
+    if (hipMalloc((void **)&Q.itab, (size_t)npad * 3 * sizeof(int)) != hipSuccess) return 1;
+    Q.itab_cap = (size_t)npad;
+  }
+  {
+    std::vector<int> host((size_t)Q.itab_cap * 3, 0);
+    int *fast = host.data(), *col = host.data() + 2 * Q.itab_cap;
+    for (int it = 0; it < npad; ++it) {
+      const int zg = it % kP2SZ4, slot = it / kP2SZ4, cxl = slot / H, cyl = slot - cxl * H;
+      const bool real = it < nitem;
+      fast[2 * it] = real ? 4 * zg : 4 * kP2SZ4;
+      fast[2 * it + 1] = real ? (int)(4u * (unsigned)((cxl * sd.y + cyl) * sd.z)) : 0;
+      col[it] = real ? (cxl | (cyl << 16)) : 0;
+    }
+    if (hipMemcpy(Q.itab, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return 1;
+  }
+  hipLaunchKernelGGL(k_pull2_plan, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, G, (int)nblk, tol, W, H,
+                     Q.rec);
   Q.tol = tol;
   if (hipDeviceSynchronize() != hipSuccess) return 1;
   static_assert(sizeof(P2Geom) <= sizeof(Q.key), "PullPlan key too small");
@@ -499,6 +565,8 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
   memcpy(&key, Q.key, sizeof(key));
   if (!same_geom(key, P.G) || tol != Q.tol) return 1;  // the plan was built for another operator / mask tolerance
   P.src = src, P.rec = Q.rec;
+  P.itab = reinterpret_cast<const int2 *>(Q.itab), P.itab2 = Q.itab + 2 * Q.itab_cap;
+  P.inv_m = 1.f / (float)P.G.m;
   for (int i = 0; i < UNIRES_MAX_TAPS; ++i) {
     P.kz[i] = i < T.n[2] ? T.t[2][i] : 0.f;
     P.kx[i] = i < T.n[0] ? T.t[0][i] : 0.f;
