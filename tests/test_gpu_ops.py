@@ -210,3 +210,36 @@ def test_abi_status_codes(dev, lib):
     assert b'Undefined operator' in lib.unires_last_error()
     assert lib.unires_cg_solve(h, 1.0, 1.0, p, p, 5, 0.0, 1, 0, None, None, None) == 3
     assert lib.unires_plan_destroy(h) == 0
+
+
+@pytest.mark.parametrize('dim', [(5, 7, 9), (6, 5, 4), (3, 4, 13), (9, 8, 70), (33, 29, 31), (40, 37, 64),
+                                 (24, 50, 181)])
+@pytest.mark.parametrize('shift', [0, 1, 3])
+def test_identity_regime_stencil_any_shape_and_alignment(dev, dim, shift):
+    """Regime A = I (unires/_project.py:76-77 + _DtD :300-317) through the flat 16-byte kernel:
+    line lengths that are not multiples of 4, volumes of one chunk and of several, and p / q that
+    start 4 or 12 bytes off a 16-byte boundary (the kernel aligns its vectors to q).  Also the fused
+    dot product and the never-stored objective form."""
+    import ctypes as C
+    from unires_amd._plan import ChannelPlan
+    from unires_amd._ops import _ptr, _stream
+    from unires_amd._lib import check
+    torch.manual_seed(sum(dim) + shift)
+    n = dim[0] * dim[1] * dim[2]
+    vx = (1.0, 0.8, 1.3)
+    tau, rho, lam = 0.7, 1.3, 0.9
+    p_cpu = torch.rand(dim)
+    plan = ChannelPlan(dim, vx, [(None, tau)], 'denoising', False, device=dev)
+    pbuf = torch.zeros(n + 8, device=dev)
+    qbuf = torch.full((n + 8,), 7.0, device=dev)
+    p = pbuf[shift:shift + n].view(dim)
+    q = qbuf[(shift + 2) % 4:(shift + 2) % 4 + n].view(dim)
+    p.copy_(p_cpu.to(dev))
+    dot = torch.zeros((), dtype=torch.float64, device=dev)
+    check(plan.lib.unires_ata_matvec(plan._h, rho, lam, _ptr(p), _ptr(q), _ptr(dot), _stream()))
+    ref = tau * p_cpu + rho * lam * lam * O.DtD(p_cpu, torch.tensor(vx))
+    assert rel_err(q.cpu(), ref) < 2e-6
+    assert abs(float(dot) - float((p_cpu.double() * ref.double()).sum())) < 1e-5 * float(ref.abs().sum())
+    # nothing written outside q
+    off = (shift + 2) % 4
+    assert bool((qbuf[:off] == 7.0).all()) and bool((qbuf[off + n:] == 7.0).all())

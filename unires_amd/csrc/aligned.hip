@@ -218,6 +218,185 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- 16-byte form (r3): nz a multiple of 4, one z pass of 256 voxels per wave -------------------
+// The dword form above spends 5 x NP global loads per 64 outputs and reaches the z neighbours
+// through LDS.  Here a lane owns FOUR consecutive voxels of the line: the line and its four x / y
+// neighbour lines are one 16-byte load each (five vector-memory instructions per 256 outputs
+// instead of twenty), the z neighbours are the lane's own values or the adjacent lane's (DPP wave
+// shift), q leaves as one 16-byte store.  LDS only serves the slice-profile part: the line is
+// written once (ds_write_b128), 42 lanes build the x-space line, every lane reads its four
+// (xs[k], xs[k + 1]) pairs back.
+typedef float af4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float a4_lower(float v) {  // lane l gets lane l - 1's value (lane 0: 0)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float a4_upper(float v) {  // lane l gets lane l + 1's value (lane 63: 0)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+template <int NP4, bool DOT, bool OBJ>
+__global__ void __launch_bounds__(kBlock)
+    k_ata_aligned4(AlignedArgs A, const int *__restrict__ done) {
+  if (done && *done) return;
+  extern __shared__ __align__(16) float smem[];
+  const unsigned lane = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const Dim3i dd = A.dd;
+  const int nz = dd.z;
+  constexpr int ZP = NP4 * 4 * kWave;  // z positions a wave covers
+  float4 *ztab = reinterpret_cast<float4 *>(smem);  // per output z: {x-space offset, w0, w1, -}
+  float *kzs = smem + 4 * ZP;
+  float *buf = kzs + kAlignedMaxTaps + w * A.wave_floats;  // (wave_floats, padl: multiples of 4)
+  float *pl = buf + A.padl;
+  float *xs = pl + nz + A.padr;
+  if (w == 0 && lane < kAlignedMaxTaps) kzs[lane] = A.kz[lane];
+  for (int i = lane; i < A.wave_floats; i += kWave) buf[i] = 0.f;  // aprons stay zero
+  __syncthreads();
+  for (int z = w * kWave + (int)lane; z < ZP; z += kBlock) {
+    const int uz = z - A.oz;
+    float w0 = 0.f, w1 = 0.f;
+    int koff = 0;
+    if (uz >= 0 && uz < A.gz && z < nz) {
+      int klo, khi;
+      up_range(uz, A.nk, A.s, A.xdz, klo, khi);
+      const int n = khi - klo + 1;
+      if (n >= 1) w0 = kzs[uz - A.s * klo], koff = klo;  // (koff + 1 <= xdz: xs[xdz] is a zero pad)
+      if (n >= 2) w1 = kzs[uz - A.s * (klo + 1)];
+    }
+    ztab[z] = make_float4(__int_as_float(koff), w0, w1, 0.f);
+  }
+  __syncthreads();
+  // ---- lane constants (independent of the line): the conv_up pair of each of the lane's voxels ----
+  float ew0[NP4][4], ew1[NP4][4];
+  int exo[NP4][4];
+#pragma unroll
+  for (int u = 0; u < NP4; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float4 tb = ztab[u * 4 * kWave + 4 * lane + e];
+      ew0[u][e] = tb.y, ew1[u][e] = tb.z, exo[u][e] = __float_as_int(tb.x);
+    }
+  const float *__restrict__ p = A.p;
+  float *__restrict__ q = A.q;
+  const int nlines = dd.x * dd.y;
+  const size_t sx = (size_t)dd.y * nz, sy = nz;
+  double dot = 0.0;
+  const int lb = xcd_chunked_block(blockIdx.x, gridDim.x);  // x/y halo lines stay in one L2
+  const int line_step = gridDim.x * kLinesPerBlock;
+  for (int line = lb * kLinesPerBlock + w; line < nlines; line += line_step) {
+    const int vx = line / dd.y, vy = line - vx * dd.y;
+    const size_t base = (size_t)line * nz;
+    const bool hx = vx + 1 < dd.x, lx = vx > 0, hy = vy + 1 < dd.y, ly = vy > 0;
+    const float *pc = p + base;
+    const float *pxp = hx ? pc + sx : pc, *pxm = lx ? pc - sx : pc;
+    const float *pyp = hy ? pc + sy : pc, *pym = ly ? pc - sy : pc;
+    const float *ob = OBJ ? A.objb + base : pc;
+    af4 rc[NP4], rxp[NP4], rxm[NP4], ryp[NP4], rym[NP4], rb[NP4];
+#pragma unroll
+    for (int u = 0; u < NP4; ++u) {
+      const int z = u * 4 * kWave + 4 * (int)lane;
+      const bool in = z < nz;  // nz % 4 == 0: a vector is inside or outside as a whole
+      const int zc = in ? z : 0;
+      const af4 zero = {0.f, 0.f, 0.f, 0.f};
+      rc[u] = *reinterpret_cast<const af4 *>(pc + zc), rxp[u] = *reinterpret_cast<const af4 *>(pxp + zc);
+      rxm[u] = *reinterpret_cast<const af4 *>(pxm + zc), ryp[u] = *reinterpret_cast<const af4 *>(pyp + zc);
+      rym[u] = *reinterpret_cast<const af4 *>(pym + zc);
+      if (OBJ) rb[u] = *reinterpret_cast<const af4 *>(ob + zc);
+      if (!in) rc[u] = zero;  // (the z + 1 neighbour of the line's last voxel reads this zero)
+    }
+    const int ux = vx - A.ox, uy = vy - A.oy;
+    const bool has = ux >= 0 && ux < A.gx && uy >= 0 && uy < A.gy;  // wave-uniform
+    if (has) {
+#pragma unroll
+      for (int u = 0; u < NP4; ++u)
+        if (u * 4 * kWave + 4 * (int)lane < nz) *reinterpret_cast<af4 *>(pl + u * 4 * kWave + 4 * lane) = rc[u];
+      asm volatile("" ::: "memory");  // single wave: LDS ops execute in order
+      for (int k0 = 0; k0 < A.xdz; k0 += kWave) {
+        const int k = k0 + (int)lane;
+        if (k < A.xdz) {
+          const float *in = pl + (k * A.s + A.oz);  // apron: no bounds checks on the taps
+          float acc = 0.f;
+          for (int t = 0; t < A.nk; ++t) acc = fmaf(kzs[t], in[t], acc);  // taps: LDS broadcast
+          xs[k] = acc * ((k & 1) ? A.so2 : A.se2);
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+    af4 out[NP4];
+    auto compute = [&](auto edge_tag, auto has_tag) {
+      constexpr bool EDGE = decltype(edge_tag)::value, HAS = decltype(has_tag)::value;
+#pragma unroll
+      for (int u = 0; u < NP4; ++u) {
+        // z neighbours across lanes: the lane below holds z - 1 in its .w, the lane above z + 4 in its .x;
+        // across passes through readlane; the line's first voxel has no backward term (zlo := c)
+        float zlo = a4_lower(rc[u].w), zhi = a4_upper(rc[u].x);
+        if (u > 0) {
+          const float prev = __builtin_amdgcn_readlane(rc[u > 0 ? u - 1 : 0].w, kWave - 1);
+          zlo = lane == 0 ? prev : zlo;
+        } else {
+          zlo = lane == 0 ? rc[0].x : zlo;
+        }
+        if (u + 1 < NP4) {
+          const float next = __builtin_amdgcn_readlane(rc[u + 1 < NP4 ? u + 1 : 0].x, 0);
+          zhi = lane == kWave - 1 ? next : zhi;
+        }
+        const float c4[4] = {rc[u].x, rc[u].y, rc[u].z, rc[u].w};
+        const float zm4[4] = {zlo, rc[u].x, rc[u].y, rc[u].z}, zp4[4] = {rc[u].y, rc[u].z, rc[u].w, zhi};
+        const float xp4[4] = {rxp[u].x, rxp[u].y, rxp[u].z, rxp[u].w}, xm4[4] = {rxm[u].x, rxm[u].y, rxm[u].z, rxm[u].w};
+        const float yp4[4] = {ryp[u].x, ryp[u].y, ryp[u].z, ryp[u].w}, ym4[4] = {rym[u].x, rym[u].y, rym[u].z, rym[u].w};
+        float o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float c = c4[e];
+          float h = 0.f;
+          if (HAS) h = ew0[u][e] * xs[exo[u][e]] + ew1[u][e] * xs[exo[u][e] + 1];
+          float xf, xb, yf, yb;
+          if (EDGE) {
+            xf = (hx ? xp4[e] : 0.f) - c, xb = lx ? c - xm4[e] : 0.f;
+            yf = (hy ? yp4[e] : 0.f) - c, yb = ly ? c - ym4[e] : 0.f;
+          } else {
+            xf = xp4[e] - c, xb = c - xm4[e], yf = yp4[e] - c, yb = c - ym4[e];
+          }
+          const float zf = zp4[e] - c, zb = c - zm4[e];
+          o4[e] = A.tau * h + A.a0 * c + (A.cx * (xb - xf) + A.cy * (yb - yf) + A.cz * (zb - zf));
+        }
+        out[u] = af4{o4[0], o4[1], o4[2], o4[3]};
+      }
+    };
+    const bool edge = !(hx && lx && hy && ly);
+    if (!edge && has)
+      compute(std::false_type{}, std::true_type{});
+    else if (!edge)
+      compute(std::false_type{}, std::false_type{});
+    else if (has)
+      compute(std::true_type{}, std::true_type{});
+    else
+      compute(std::true_type{}, std::false_type{});
+    asm volatile("" ::: "memory");  // the line buffers are reused by the next line
+    float *qc = q + base;
+#pragma unroll
+    for (int u = 0; u < NP4; ++u) {
+      const int z = u * 4 * kWave + 4 * (int)lane;
+      if (z < nz) {
+        if (OBJ) {
+          dot += (double)obj_term(out[u].x, rb[u].x, rc[u].x) + (double)obj_term(out[u].y, rb[u].y, rc[u].y) +
+                 (double)obj_term(out[u].z, rb[u].z, rc[u].z) + (double)obj_term(out[u].w, rb[u].w, rc[u].w);
+        } else {
+          *reinterpret_cast<af4 *>(qc + z) = out[u];
+          if (DOT)
+            dot += (double)__fmul_rn(rc[u].x, out[u].x) + (double)__fmul_rn(rc[u].y, out[u].y) +
+                   (double)__fmul_rn(rc[u].z, out[u].z) + (double)__fmul_rn(rc[u].w, out[u].w);
+        }
+      }
+    }
+  }
+  if (DOT) {
+    const double tot = block_sum(dot);
+    if (threadIdx.x == 0 && threadIdx.y == 0) A.partials[blockIdx.x] = tot;
+  }
+}
+
 int aligned_blocks(Dim3i dd) {
   const long long nb = ((long long)dd.x * dd.y + kLinesPerBlock - 1) / kLinesPerBlock;
   // 4096 workgroups = 4 lines per wave: amortises the per-wave set-up (table, LDS aprons) and
@@ -247,6 +426,34 @@ static void launch_lines(AlignedArgs &G, int npt, size_t lds, const int *done, h
   const double *partials = G.partials;
   const float *objb = G.objb;
   const dim3 grid(aligned_blocks(dd)), block(kWave, kLinesPerBlock);
+  // 16-byte form: lines that are whole vectors (nz % 4 == 0, 16-byte aligned volumes), <= 512 long
+  static const bool no_v4 = getenv("UNIRES_ALIGNED_V4") && getenv("UNIRES_ALIGNED_V4")[0] == '0';
+  const uintptr_t al = (uintptr_t)G.p | (uintptr_t)G.q | (uintptr_t)(objb ? objb : G.p);
+  if (!no_v4 && dd.z % 4 == 0 && dd.z <= 8 * kWave && (al & 15u) == 0) {
+    AlignedArgs V = G;
+    const int np4 = dd.z <= 4 * kWave ? 1 : 2;
+    V.padl = (G.padl + 3) & ~3;
+    V.wave_floats = (V.padl + dd.z + G.padr + G.xdz + 1 + 3) & ~3;
+    const size_t lds4 = ((size_t)4 * np4 * 4 * kWave + kAlignedMaxTaps + (size_t)kLinesPerBlock * V.wave_floats) *
+                        sizeof(float);
+    if (lds4 <= 64 * 1024) {
+#define LAUNCH_ALIGNED4(NPV)                                                                    \
+  do {                                                                                          \
+    if (objb)                                                                                   \
+      hipLaunchKernelGGL((k_ata_aligned4<NPV, true, true>), grid, block, lds4, st, V, done);    \
+    else if (partials)                                                                          \
+      hipLaunchKernelGGL((k_ata_aligned4<NPV, true, false>), grid, block, lds4, st, V, done);   \
+    else                                                                                        \
+      hipLaunchKernelGGL((k_ata_aligned4<NPV, false, false>), grid, block, lds4, st, V, done);  \
+  } while (0)
+      if (np4 == 1)
+        LAUNCH_ALIGNED4(1);
+      else
+        LAUNCH_ALIGNED4(2);
+#undef LAUNCH_ALIGNED4
+      return;
+    }
+  }
 #define LAUNCH_ALIGNED(NPV)                                                                  \
   do {                                                                                       \
     if (objb)                                                                                \

@@ -209,8 +209,7 @@ __global__ void __launch_bounds__(kBlock)
 // an agent-scope release per workgroup, an L2 write-back each: 4 200 -> 1 550 iterations/s.  Here
 // nothing crosses workgroups inside a launch: every consumer workgroup reads the producer's <= 8192
 // partials (L2 hits, 64 KB at most) after the kernel boundary and sums them in the same fixed
-// order.  The vector kernels run as 1024 persistent workgroups so that the prologue is paid once
-// per workgroup and all of them are resident together.)
+// order.)
 __device__ __forceinline__ double reduce_all(const double *__restrict__ part, int g) {
   __shared__ double s_tot[kBlock / kWave];
   double v = 0.0;
@@ -233,10 +232,16 @@ __device__ __forceinline__ double reduce_all(const double *__restrict__ part, in
   return tot;  // the same value, bit for bit, in every thread of every workgroup
 }
 
+// Chunked form of the fused updates: a workgroup takes chunks of kFoldIt * kBlock float4, ALL loads of
+// a chunk are issued before anything else, and the partial-sum reduction of the prologue runs behind
+// them (first chunk only): its round trip (L2 reads of the partials, one LDS exchange) overlaps the
+// latency of the chunk's own loads instead of preceding it.  4096 workgroups, as the unfolded kernels
+// (1024 persistent ones lost 12 % of the streaming rate: 57 instead of 50 us for the x / p update).
+constexpr int kFoldIt = 4;
 static inline int vec_blocks_fold(size_t n) {
-  size_t b = (n / 4 + kBlock - 1) / kBlock;
+  size_t b = (n / 4 + (size_t)kFoldIt * kBlock - 1) / ((size_t)kFoldIt * kBlock);
   if (b < 1) b = 1;
-  return (int)(b < 1024 ? b : 1024);
+  return (int)(b < 4096 ? b : 4096);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -244,25 +249,42 @@ __global__ void __launch_bounds__(kBlock)
                     const float *__restrict__ ap, float *__restrict__ r, size_t n,
                     double *__restrict__ part_rr, const float *__restrict__ M) {
   if (st->done) return;
-  const double pap = reduce_all(part_pap, g);
-  const double alpha_d = st->rzpp[(k - 1) & 1] / pap;
-  if (blockIdx.x == 0 && threadIdx.x == 0) st->pAp = pap, st->alpha = alpha_d;
-  const float alpha = (float)alpha_d;
-  GRID_STRIDE_VEC4(n);
+  const size_t n4 = n / 4, chunk = (size_t)kFoldIt * kBlock;
+  float alpha = 0.f;
+  bool have = false;
   double rr = 0.0;
-  for (size_t i = tid0; i < n4; i += stride) {
-    const float4 va = ld4(ap, i);
-    float4 vr = ld4(r, i);
-    vr.x = __fsub_rn(vr.x, __fmul_rn(alpha, va.x));
-    vr.y = __fsub_rn(vr.y, __fmul_rn(alpha, va.y));
-    vr.z = __fsub_rn(vr.z, __fmul_rn(alpha, va.z));
-    vr.w = __fsub_rn(vr.w, __fmul_rn(alpha, va.w));
-    st4(r, i, vr);
-    const float4 vz = zval4(vr, M, i);
-    rr += (double)__fmul_rn(vr.x, vz.x) + (double)__fmul_rn(vr.y, vz.y) +
-          (double)__fmul_rn(vr.z, vz.z) + (double)__fmul_rn(vr.w, vz.w);
+  for (size_t c = blockIdx.x; c * chunk < n4 || !have; c += gridDim.x) {
+    float4 va[kFoldIt], vr[kFoldIt];
+    size_t idx[kFoldIt];
+#pragma unroll
+    for (int u = 0; u < kFoldIt; ++u) {
+      idx[u] = c * chunk + (size_t)u * kBlock + threadIdx.x;
+      if (idx[u] < n4) va[u] = ld4(ap, idx[u]), vr[u] = ld4(r, idx[u]);
+    }
+    if (!have) {  // (wave-uniform: first trip of the loop)
+      const double pap = reduce_all(part_pap, g);
+      const double alpha_d = st->rzpp[(k - 1) & 1] / pap;
+      if (blockIdx.x == 0 && threadIdx.x == 0) st->pAp = pap, st->alpha = alpha_d;
+      alpha = (float)alpha_d;
+      have = true;
+    }
+#pragma unroll
+    for (int u = 0; u < kFoldIt; ++u) {
+      if (idx[u] < n4) {
+        float4 x = vr[u];
+        x.x = __fsub_rn(x.x, __fmul_rn(alpha, va[u].x));
+        x.y = __fsub_rn(x.y, __fmul_rn(alpha, va[u].y));
+        x.z = __fsub_rn(x.z, __fmul_rn(alpha, va[u].z));
+        x.w = __fsub_rn(x.w, __fmul_rn(alpha, va[u].w));
+        st4(r, idx[u], x);
+        const float4 vz = zval4(x, M, idx[u]);
+        rr += (double)__fmul_rn(x.x, vz.x) + (double)__fmul_rn(x.y, vz.y) + (double)__fmul_rn(x.z, vz.z) +
+              (double)__fmul_rn(x.w, vz.w);
+      }
+    }
   }
-  for (size_t i = n4 * 4 + tid0; i < n; i += stride) {
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail
+    const size_t i = n4 * 4 + threadIdx.x;
     const float vr = __fsub_rn(r[i], __fmul_rn(alpha, ap[i]));
     r[i] = vr;
     rr += (double)__fmul_rn(vr, zval1(vr, M, i));
@@ -276,33 +298,49 @@ __global__ void __launch_bounds__(kBlock)
                      const float *__restrict__ r, float *__restrict__ p, float *__restrict__ x, size_t n,
                      const float *__restrict__ M) {
   if (st->done) return;
-  const double rr = reduce_all(part_rr, g);
-  const double rz0 = st->rzpp[(k - 1) & 1];
-  const double beta_d = rr / rz0;
-  const float beta = (float)beta_d, alpha = (float)st->alpha;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    st->rzpp[k & 1] = rr;
-    st->rz = rr;
-    st->beta = beta_d;
-    st->iters = k;
+  const size_t n4 = n / 4, chunk = (size_t)kFoldIt * kBlock;
+  float alpha = 0.f, beta = 0.f;
+  bool have = false;
+  for (size_t c = blockIdx.x; c * chunk < n4 || !have; c += gridDim.x) {
+    float4 vz[kFoldIt], vp[kFoldIt], vx[kFoldIt];
+    size_t idx[kFoldIt];
+#pragma unroll
+    for (int u = 0; u < kFoldIt; ++u) {
+      idx[u] = c * chunk + (size_t)u * kBlock + threadIdx.x;
+      if (idx[u] < n4) vz[u] = zval4(ld4(r, idx[u]), M, idx[u]), vp[u] = ld4(p, idx[u]), vx[u] = ld4(x, idx[u]);
+    }
+    if (!have) {
+      const double rrs = reduce_all(part_rr, g);
+      const double rz0 = st->rzpp[(k - 1) & 1];
+      const double beta_d = rrs / rz0;
+      beta = (float)beta_d, alpha = (float)st->alpha;
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->rzpp[k & 1] = rrs;
+        st->rz = rrs;
+        st->beta = beta_d;
+        st->iters = k;
+      }
+      have = true;
+    }
+#pragma unroll
+    for (int u = 0; u < kFoldIt; ++u) {
+      if (idx[u] < n4) {
+        float4 a = vx[u], b = vp[u];
+        a.x = __fadd_rn(a.x, __fmul_rn(alpha, b.x));
+        a.y = __fadd_rn(a.y, __fmul_rn(alpha, b.y));
+        a.z = __fadd_rn(a.z, __fmul_rn(alpha, b.z));
+        a.w = __fadd_rn(a.w, __fmul_rn(alpha, b.w));
+        st4(x, idx[u], a);
+        b.x = __fadd_rn(__fmul_rn(beta, b.x), vz[u].x);
+        b.y = __fadd_rn(__fmul_rn(beta, b.y), vz[u].y);
+        b.z = __fadd_rn(__fmul_rn(beta, b.z), vz[u].z);
+        b.w = __fadd_rn(__fmul_rn(beta, b.w), vz[u].w);
+        st4(p, idx[u], b);
+      }
+    }
   }
-  GRID_STRIDE_VEC4(n);
-  for (size_t i = tid0; i < n4; i += stride) {
-    const float4 vr = zval4(ld4(r, i), M, i);
-    float4 vp = ld4(p, i);
-    float4 vx = ld4(x, i);
-    vx.x = __fadd_rn(vx.x, __fmul_rn(alpha, vp.x));
-    vx.y = __fadd_rn(vx.y, __fmul_rn(alpha, vp.y));
-    vx.z = __fadd_rn(vx.z, __fmul_rn(alpha, vp.z));
-    vx.w = __fadd_rn(vx.w, __fmul_rn(alpha, vp.w));
-    st4(x, i, vx);
-    vp.x = __fadd_rn(__fmul_rn(beta, vp.x), vr.x);
-    vp.y = __fadd_rn(__fmul_rn(beta, vp.y), vr.y);
-    vp.z = __fadd_rn(__fmul_rn(beta, vp.z), vr.z);
-    vp.w = __fadd_rn(__fmul_rn(beta, vp.w), vr.w);
-    st4(p, i, vp);
-  }
-  for (size_t i = n4 * 4 + tid0; i < n; i += stride) {
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail
+    const size_t i = n4 * 4 + threadIdx.x;
     const float vp = p[i];
     x[i] = __fadd_rn(x[i], __fmul_rn(alpha, vp));
     p[i] = __fadd_rn(__fmul_rn(beta, vp), zval1(r[i], M, i));

@@ -44,13 +44,18 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4 ld4_fast(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
-// element-wise form: every dword range-checked on its own (offsets that wrapped below zero or run
-// past the end read as 0)
-__device__ __forceinline__ f4 ld4_safe(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  f4 v;
-  v.x = buf_load(r, off, 0), v.y = buf_load(r, off + 4u, 0), v.z = buf_load(r, off + 8u, 0),
-  v.w = buf_load(r, off + 12u, 0);
-  return v;
+// element-wise form for vectors that stick out of the array: voxels below 0 or at / beyond n read as
+// 0.  The range test is explicit: the compiler folds "+ 4 e" into the instruction's immediate offset,
+// and the hardware adds that WITHOUT wrapping at 32 bits, so a negative (wrapped) base does not come
+// back into range the way 32-bit arithmetic would suggest.
+__device__ __forceinline__ f4 ld4_safe(__amdgpu_buffer_rsrc_t r, int idx, int n) {
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = idx + e;
+    v[e] = buf_load(r, (i >= 0 && i < n) ? 4u * (unsigned)i : 0x80000000u, 0);
+  }
+  return f4{v[0], v[1], v[2], v[3]};
 }
 __device__ __forceinline__ float dpp_from_lower_lane(float v) {  // lane l gets lane l - 1's value (lane 0: 0)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
@@ -64,6 +69,58 @@ __device__ __forceinline__ unsigned div_small(unsigned v, unsigned d, float inv_
   if (__umul24(q, d) > v) --q;
   if (__umul24(q + 1u, d) <= v) ++q;
   return q;
+}
+
+// One vector (four consecutive voxels of a lane).  XY = false: the caller guarantees that none of the
+// wave's voxels lies on an x or y face of the volume and that all five vectors are inside the array
+// (the common case: whole chunks away from the first / last rows and slabs), so only the z faces - a
+// line end somewhere inside the wave - are tested.
+struct FlatVec {
+  f4 cc, xm, xp, ym, yp, ob;
+  float edge;
+};
+
+template <bool XY, bool DOT, bool OBJ>
+__device__ __forceinline__ void flat_vec(const FlatArgs &A, const FlatVec &L, unsigned lane, unsigned idx0,
+                                         unsigned k0, unsigned j0, bool valid, float *__restrict__ q,
+                                         double &dot) {
+  const unsigned nz = A.nz, ny = A.ny;
+  float zlo = dpp_from_lower_lane(L.cc.w), zhi = dpp_from_upper_lane(L.cc.x);
+  zlo = lane == 0u ? L.edge : zlo;
+  zhi = lane == (unsigned)kWave - 1u ? L.edge : zhi;
+  // faces.  A line ends at most once inside the lane's four voxels (nz >= 4): after voxel w.
+  const unsigned w = nz - 1u - k0;
+  const float c4[4] = {L.cc.x, L.cc.y, L.cc.z, L.cc.w};
+  const float zm4[4] = {zlo, L.cc.x, L.cc.y, L.cc.z}, zp4[4] = {L.cc.y, L.cc.z, L.cc.w, zhi};
+  const float xm4[4] = {L.xm.x, L.xm.y, L.xm.z, L.xm.w}, xp4[4] = {L.xp.x, L.xp.y, L.xp.z, L.xp.w};
+  const float ym4[4] = {L.ym.x, L.ym.y, L.ym.z, L.ym.w}, yp4[4] = {L.yp.x, L.yp.y, L.yp.z, L.yp.w};
+  const float ob4[4] = {L.ob.x, L.ob.y, L.ob.z, L.ob.w};
+  float out[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float ce = c4[e];
+    const bool zlo_ok = e == 0 ? k0 != 0u : (unsigned)(e - 1) != w;  // not the first voxel of a line
+    const bool zhi_ok = (unsigned)e != w;                              // not the last voxel of a line
+    float xb = ce - xm4[e], yb = ce - ym4[e], yp = yp4[e];
+    if (XY) {
+      const bool wrapped = (unsigned)e > w;  // voxel e lies on the next line
+      const unsigned je = wrapped ? (j0 + 1u == ny ? 0u : j0 + 1u) : j0;
+      xb = idx0 + (unsigned)e >= A.nynz ? xb : 0.f;  // (x upper face: the load returned 0)
+      yb = je != 0u ? yb : 0.f;
+      yp = je + 1u != ny ? yp : 0.f;
+    }
+    const float xf = xp4[e] - ce, yf = yp - ce;
+    const float zb = zlo_ok ? ce - zm4[e] : 0.f, zf = (zhi_ok ? zp4[e] : 0.f) - ce;
+    const float o = A.a0 * ce + (A.cx * (xb - xf) + A.cy * (yb - yf) + A.cz * (zb - zf));
+    out[e] = o;
+    if (valid) {
+      if (OBJ)
+        dot += (double)obj_term(o, ob4[e], ce);
+      else if (DOT)
+        dot += (double)__fmul_rn(ce, o);
+    }
+  }
+  if (!OBJ && valid) *reinterpret_cast<float4 *>(q + idx0) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
 template <bool DOT, bool OBJ>
@@ -86,6 +143,32 @@ __global__ void __launch_bounds__(kBlock) k_dtd_flat(FlatArgs A, const int *__re
   for (unsigned c = c_lo + slot; c < c_hi; c += cnt) {
     const unsigned e0 = A.head + c * (unsigned)kFlatChunk;       // first voxel of the chunk (wave-uniform)
     const unsigned line0 = e0 / nz, kb = e0 - line0 * nz, jb = line0 % ny;
+    // whole chunk away from the x / y faces, every vector of every lane inside the array: the rows it
+    // touches are jb .. jb + (kb + chunk - 1) / nz, its slabs lie strictly between the first and last
+    const unsigned rows = (kb + (unsigned)kFlatChunk - 1u) / nz;
+    const bool plain = jb >= 1u && jb + rows + 1u < ny && e0 >= nynz &&
+                       (unsigned long long)e0 + kFlatChunk + nynz <= n &&
+                       (c + 1u) * (unsigned)(kFlatChunk / 4) <= A.nvec;
+    if (plain) {
+      FlatVec L[kFlatVecs];
+      unsigned k0[kFlatVecs];
+#pragma unroll
+      for (int v = 0; v < kFlatVecs; ++v) {  // all loads of the chunk first
+        const unsigned t = (unsigned)v * kBlock + tid, bo = 4u * (e0 + 4u * t);
+        L[v].cc = ld4_fast(rp, bo), L[v].ym = ld4_fast(rp, bo - 4u * nz), L[v].yp = ld4_fast(rp, bo + 4u * nz);
+        L[v].xm = ld4_fast(rp, bo - 4u * nynz), L[v].xp = ld4_fast(rp, bo + 4u * nynz);
+        L[v].ob = f4{0.f, 0.f, 0.f, 0.f};
+        if (OBJ) L[v].ob = ld4_fast(rb, bo);
+        L[v].edge = 0.f;
+        if (lane == 0u || lane == (unsigned)kWave - 1u) L[v].edge = buf_load(rp, lane == 0u ? bo - 4u : bo + 16u, 0);
+        const unsigned u = kb + 4u * t;
+        k0[v] = u - __umul24(div_small(u, nz, A.inv_nz), nz);
+      }
+#pragma unroll
+      for (int v = 0; v < kFlatVecs; ++v)
+        flat_vec<false, DOT, OBJ>(A, L[v], lane, e0 + 4u * ((unsigned)v * kBlock + tid), k0[v], 1u, true, q, dot);
+      continue;
+    }
 #pragma unroll
     for (int v = 0; v < kFlatVecs; ++v) {
       const unsigned t = (unsigned)v * kBlock + tid;
@@ -98,51 +181,24 @@ __global__ void __launch_bounds__(kBlock) k_dtd_flat(FlatArgs A, const int *__re
       // all five vectors of every lane wholly inside the array?  (false only in the first / last x
       // slab and in the last, partial wave: those take the element-wise loads)
       const bool inner = valid && idx0 >= nynz && idx0 + nynz + 4u <= n;
-      f4 cc, xm, xp, ym, yp, ob = {0.f, 0.f, 0.f, 0.f};
+      FlatVec L;
+      L.ob = f4{0.f, 0.f, 0.f, 0.f};
       if (__builtin_amdgcn_ballot_w64(!inner) == 0ull) {
-        cc = ld4_fast(rp, bo), ym = ld4_fast(rp, bo - 4u * nz), yp = ld4_fast(rp, bo + 4u * nz);
-        xm = ld4_fast(rp, bo - 4u * nynz), xp = ld4_fast(rp, bo + 4u * nynz);
-        if (OBJ) ob = ld4_fast(rb, bo);
+        L.cc = ld4_fast(rp, bo), L.ym = ld4_fast(rp, bo - 4u * nz), L.yp = ld4_fast(rp, bo + 4u * nz);
+        L.xm = ld4_fast(rp, bo - 4u * nynz), L.xp = ld4_fast(rp, bo + 4u * nynz);
+        if (OBJ) L.ob = ld4_fast(rb, bo);
       } else {
-        cc = ld4_safe(rp, bo), ym = ld4_safe(rp, bo - 4u * nz), yp = ld4_safe(rp, bo + 4u * nz);
-        xm = ld4_safe(rp, bo - 4u * nynz), xp = ld4_safe(rp, bo + 4u * nynz);
-        if (OBJ) ob = ld4_safe(rb, bo);
+        const int i0 = (int)idx0, in = (int)n;
+        L.cc = ld4_safe(rp, i0, in), L.ym = ld4_safe(rp, i0 - (int)nz, in), L.yp = ld4_safe(rp, i0 + (int)nz, in);
+        L.xm = ld4_safe(rp, i0 - (int)nynz, in), L.xp = ld4_safe(rp, i0 + (int)nynz, in);
+        if (OBJ) L.ob = ld4_safe(rb, i0, in);
       }
-      float edge = 0.f;  // lane 0: the voxel below its first, lane 63: the voxel above its last
-      if (lane == 0u || lane == (unsigned)kWave - 1u) edge = buf_load(rp, lane == 0u ? bo - 4u : bo + 16u, 0);
-      float zlo = dpp_from_lower_lane(cc.w), zhi = dpp_from_upper_lane(cc.x);
-      zlo = lane == 0u ? edge : zlo;
-      zhi = lane == (unsigned)kWave - 1u ? edge : zhi;
-      // faces.  A line ends at most once inside the lane's four voxels (nz >= 4): after voxel w.
-      const unsigned w = nz - 1u - k0;
-      const float c4[4] = {cc.x, cc.y, cc.z, cc.w};
-      const float zm4[4] = {zlo, cc.x, cc.y, cc.z}, zp4[4] = {cc.y, cc.z, cc.w, zhi};
-      const float xm4[4] = {xm.x, xm.y, xm.z, xm.w}, xp4[4] = {xp.x, xp.y, xp.z, xp.w};
-      const float ym4[4] = {ym.x, ym.y, ym.z, ym.w}, yp4[4] = {yp.x, yp.y, yp.z, yp.w};
-      const float ob4[4] = {ob.x, ob.y, ob.z, ob.w};
-      float out[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float ce = c4[e];
-        const bool wrapped = (unsigned)e > w;                  // voxel e lies on the next line
-        const bool zlo_ok = e == 0 ? k0 != 0u : (unsigned)(e - 1) != w;  // not the first voxel of a line
-        const bool zhi_ok = (unsigned)e != w;                  // not the last voxel of a line
-        const unsigned je = wrapped ? (j0 + 1u == ny ? 0u : j0 + 1u) : j0;
-        const bool ylo_ok = je != 0u, yhi_ok = je + 1u != ny;
-        const bool xlo_ok = idx0 + (unsigned)e >= nynz;        // (x upper face: the load returned 0)
-        const float xb = xlo_ok ? ce - xm4[e] : 0.f, xf = xp4[e] - ce;
-        const float yb = ylo_ok ? ce - ym4[e] : 0.f, yf = (yhi_ok ? yp4[e] : 0.f) - ce;
-        const float zb = zlo_ok ? ce - zm4[e] : 0.f, zf = (zhi_ok ? zp4[e] : 0.f) - ce;
-        const float o = A.a0 * ce + (A.cx * (xb - xf) + A.cy * (yb - yf) + A.cz * (zb - zf));
-        out[e] = o;
-        if (valid) {
-          if (OBJ)
-            dot += (double)obj_term(o, ob4[e], ce);
-          else if (DOT)
-            dot += (double)__fmul_rn(ce, o);
-        }
+      L.edge = 0.f;  // lane 0: the voxel below its first, lane 63: the voxel above its last
+      if (lane == 0u || lane == (unsigned)kWave - 1u) {
+        const int ie = lane == 0u ? (int)idx0 - 1 : (int)idx0 + 4;
+        L.edge = buf_load(rp, (ie >= 0 && ie < (int)n) ? 4u * (unsigned)ie : 0x80000000u, 0);
       }
-      if (!OBJ && valid) *reinterpret_cast<float4 *>(q + idx0) = make_float4(out[0], out[1], out[2], out[3]);
+      flat_vec<true, DOT, OBJ>(A, L, lane, idx0, k0, j0, valid, q, dot);
     }
   }
   // the few voxels in front of the first and behind the last vector
