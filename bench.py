@@ -135,18 +135,28 @@ def alg_bytes_matvec(x_c, dim_y, do_proj=True):
 def pmc_traffic(workload):
     """HBM bytes per matvec launch from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE in separate runs; gfx950 FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes).  None if no profile of this workload is committed."""
-    for name in ('r02_traffic.json', 'r01_traffic_aligned.json'):
+    MI355X_MICROARCH.md prescribes).  The figure is STATIC - read from a committed profile, not
+    measured in this run (PMC passes need rocprofv3 around the process) - and is tagged with the
+    profile file and its git blob hash so that it can be checked against the tree.
+    None if no profile of this workload is committed."""
+    import hashlib
+    for name in ('r03_traffic.json', 'r02_traffic.json', 'r01_traffic_aligned.json'):
+        path = os.path.join(ROOT, 'profiles', name)
         try:
-            rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            raw = open(path, 'rb').read()
+            rec = json.loads(raw)
             if rec.get('workload') == workload:
-                return rec['bytes_per_launch']
+                blob = hashlib.sha1(b'blob %d\0' % len(raw) + raw).hexdigest()
+                return {'bytes_per_launch': rec['bytes_per_launch'], 'static': True,
+                        'source': 'profiles/' + name, 'git_blob': blob,
+                        'note': 'PMC passes of the kernels as committed with that profile; re-run '
+                                'tools/refresh_profiles_r03.sh to refresh'}
         except (OSError, ValueError, KeyError):
             pass
     return None
 
 
-def time_matvec(x, y, rho, sett, reps=16, ring=2, graph=True):
+def time_matvec(x, y, rho, sett, reps=16, ring=2, graph=True, channels=None):
     """Average duration of one CG matvec (mean over the subject's channels, whose rigid
     transforms - and therefore kernel costs - differ), HIP events on the launch stream.
     The launches cycle through channels and ``ring`` distinct (p, q) pairs per channel
@@ -156,15 +166,16 @@ def time_matvec(x, y, rho, sett, reps=16, ring=2, graph=True):
     (aligned kernel: 35.7 us hot, 42 us cold)."""
     from unires_amd._project import _channel_plan
     dev = y[0].dat.device
-    C = len(x)
-    plans = [_channel_plan(x[c], y[c], sett.method, sett.do_proj) for c in range(C)]
-    ps = [[torch.rand(y[c].dim, device=dev) for _ in range(ring)] for c in range(C)]
-    qs = [[torch.empty_like(ps[c][0]) for _ in range(ring)] for c in range(C)]
+    chans = list(range(len(x))) if channels is None else list(channels)
+    C = len(chans)
+    plans = [_channel_plan(x[c], y[c], sett.method, sett.do_proj) for c in chans]
+    ps = [[torch.rand(y[c].dim, device=dev) for _ in range(ring)] for c in chans]
+    qs = [[torch.empty_like(ps[k][0]) for _ in range(ring)] for k in range(C)]
 
     def sweep(n):
         for i in range(n):
-            for c in range(C):
-                plans[c].matvec(ps[c][i % ring], rho, y[c].lam, out=qs[c][i % ring])
+            for k, c in enumerate(chans):
+                plans[k].matvec(ps[k][i % ring], rho, y[c].lam, out=qs[k][i % ring])
 
     sweep(ring + 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -298,44 +309,61 @@ def cpu_baseline(wl, seconds_budget=25.0, device=None):
     """CPU oracle ("port" of the reference composition) on one channel of the same
     workload: fixed-iteration CG, as many iterations as fit the budget (>= 1).
 
-    The first oracle matvec is also the full-size parity check of SURVEY 8(d): the HIP matvec
+    The oracle does not scale with threads (its trilinear push is eight ``index_add_`` passes over the
+    whole grid: 128 threads are slower than one), so the thread count is CHOSEN first: one matvec of
+    the same operator at half the linear size is timed at 1, 8, 16, 32, 64 and all host threads, and the
+    full-size sample then runs at the fastest of them - ``cores`` is that count, ``thread_scan`` holds
+    all of them.
+
+    The first full-size oracle matvec is also the full-size parity check of SURVEY 8(d): the HIP matvec
     runs on the SAME operator and the SAME input and the float32 relative / max-abs error is
-    reported next to the timing (gate 1e-4).  A single-thread timing of the same operator on a
-    problem of half the linear size gives the n = 1 figure (a 256^3 single-thread matvec would
-    take minutes)."""
+    reported next to the timing (gate 1e-4)."""
     from oracle import nitorch_restated as N
     dim_y = wl['dim_y']
-    P = oracle_channel(wl, dim_y)
-    lhs = oracle_lhs(wl, P)
-    t0 = time.perf_counter()
-    q_cpu = lhs(P['b'])  # one matvec: sizes the sample AND is the parity reference
-    t_mv = time.perf_counter() - t0
-    parity = matvec_parity(wl, P, q_cpu, device) if device is not None else None
-    n_it = max(1, min(20, int(seconds_budget / max(t_mv, 1e-3)) - 1))
-    t0 = time.perf_counter()
-    N.cg(lhs, P['b'], P['yc'].dat, max_iter=n_it, tolerance=0, stop='max_gain')
-    dt = time.perf_counter() - t0
-    cores = torch.get_num_threads()
-    # n = 1 thread: same operator shape at half the linear size, one matvec
+    all_threads = torch.get_num_threads()
+    # ---- thread scan on the half-size problem (a fraction of a second per point) ----
     small = tuple(max(16, d // 2) for d in dim_y)
     Ps = oracle_channel(wl, small, seed=1)
     lhs_s = oracle_lhs(wl, Ps)
-    torch.set_num_threads(1)
+    nvox_s = small[0] * small[1] * small[2]
+    scan = {}
+    try:
+        for nt in sorted(set(t for t in (1, 8, 16, 32, 64, all_threads) if t <= all_threads)):
+            torch.set_num_threads(nt)
+            lhs_s(Ps['b'])  # warm
+            t0 = time.perf_counter()
+            lhs_s(Ps['b'])
+            scan[nt] = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(all_threads)
+    best = min(scan, key=scan.get)
+    # ---- the bounded full-size sample at the fastest thread count ----
+    P = oracle_channel(wl, dim_y)
+    lhs = oracle_lhs(wl, P)
+    torch.set_num_threads(best)
     try:
         t0 = time.perf_counter()
-        lhs_s(Ps['b'])
-        t1 = time.perf_counter() - t0
+        q_cpu = lhs(P['b'])  # one matvec: sizes the sample AND is the parity reference
+        t_mv = time.perf_counter() - t0
+        parity = matvec_parity(wl, P, q_cpu, device) if device is not None else None
+        n_it = max(1, min(20, int(seconds_budget / max(t_mv, 1e-3)) - 1))
+        t0 = time.perf_counter()
+        N.cg(lhs, P['b'], P['yc'].dat, max_iter=n_it, tolerance=0, stop='max_gain')
+        dt = time.perf_counter() - t0
     finally:
-        torch.set_num_threads(cores)
+        torch.set_num_threads(all_threads)
     nvox = dim_y[0] * dim_y[1] * dim_y[2]
-    nvox_s = small[0] * small[1] * small[2]
     # cg(tolerance=0) does n_it + 1 matvecs for n_it iterations; report iterations/s
-    out = dict(value=n_it / dt, unit='cg_iters/s', cores=cores, kind='port', cpu_model=host_cpu_model(),
+    out = dict(value=n_it / dt, unit='cg_iters/s', cores=best, kind='port', cpu_model=host_cpu_model(),
+               host_threads=all_threads,
                sample='%d CG iterations (tol=0) of one %dx%dx%d channel, oracle/unires_restated '
-                      '(torch-CPU, unfused as the reference composes it); matvec %.2f s'
-                      % (n_it, dim_y[0], dim_y[1], dim_y[2], t_mv),
+                      '(torch-CPU, unfused as the reference composes it) on %d threads - the fastest of '
+                      'the scanned counts; matvec %.2f s' % (n_it, dim_y[0], dim_y[1], dim_y[2], best, t_mv),
                matvec_s=t_mv, matvec_Mvox_per_s=nvox / t_mv / 1e6,
-               single_thread={'cores': 1, 'matvec_s': t1, 'matvec_Mvox_per_s': nvox_s / t1 / 1e6,
+               thread_scan={'sample': 'one matvec of a %dx%dx%d channel (same operator shape)' % small,
+                            'matvec_s': {str(k): v for k, v in scan.items()},
+                            'matvec_Mvox_per_s': {str(k): nvox_s / v / 1e6 for k, v in scan.items()}},
+               single_thread={'cores': 1, 'matvec_s': scan.get(1), 'matvec_Mvox_per_s': nvox_s / scan[1] / 1e6,
                               'sample': 'one matvec of a %dx%dx%d channel (same operator shape)' % small})
     if parity is not None:
         out['parity'] = parity
@@ -386,7 +414,7 @@ def variants(name, x, y, z, w, rho, tmp, sett, device):
         xa, ya, za, wa, rhoa, setta = build_subject(WORKLOADS[alt], device, seed=1234)
         ta = torch.zeros_like(ya[0].dat)
         t = time_steps(run(xa, ya, za, wa, rhoa, ta, setta), 3, 1)
-        t_mv = time_matvec(xa, ya, rhoa, setta)
+        t_mv = time_matvec(xa, ya, rhoa, setta, graph=False)
         b_mv = alg_bytes_matvec(xa[0], WORKLOADS[alt]['dim_y'])
         out[alt] = {'cg_iters_per_sec': len(xa) * setta.cgs_max_iter / t, 'ms_per_step': t * 1e3,
                     'matvec_us': t_mv * 1e6, 'matvec_GBps': b_mv / t_mv / 1e9,
@@ -503,12 +531,14 @@ def main():
         t_subject = float(t.item())
     out = None
     if rank == 0:
-        # two HIP-event timings of the same launches: replayed as one hipGraph (how unires_cg_solve
-        # runs them) and launched one by one; launch gaps differ from box to box, the kernels do not,
-        # so the smaller of the two is the one closest to the kernels' own durations (rocprofv3)
+        # the headline figure is ONE fixed method (r1's): plain launches on the stream, HIP events around
+        # them - the figure that must agree with the rocprofv3 kernel durations committed under
+        # profiles/ (kernel sum 123.3 us vs 123 - 125 us by events; a hipGraph replay of the same launches
+        # carries ~2.5 us of barrier packet per kernel and is reported next to it, never mixed in)
         t_mv_graph = time_matvec(x, y, rho, sett)
         t_mv_eager = time_matvec(x, y, rho, sett, graph=False)
-        t_mv = min(t_mv_graph, t_mv_eager)
+        t_mv = t_mv_eager
+        per_channel = [time_matvec(x, y, rho, sett, ring=4, channels=[c], graph=False) * 1e6 for c in range(len(x))]
         b_mv = alg_bytes_matvec(x[0], wl['dim_y'], sett.do_proj)
         achieved = b_mv / t_mv / 1e9
         out = {
@@ -530,7 +560,8 @@ def main():
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.workload),
                          'alg_bytes_per_launch': b_mv, 'us_per_launch': t_mv * 1e6,
-                         'us_per_launch_graph': t_mv_graph * 1e6, 'us_per_launch_eager': t_mv_eager * 1e6},
+                         'us_per_launch_graph': t_mv_graph * 1e6, 'us_per_launch_eager': t_mv_eager * 1e6,
+                         'us_per_launch_by_channel': per_channel, 'timing': 'plain launches, HIP events on the launch stream'},
         }
         if world == 1 and not args.no_variants:
             out['variants'] = variants(args.workload, x, y, z, w, rho, tmp, sett, device)

@@ -211,7 +211,7 @@ int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const float *b, f
 /* UPDATE z and w  (_update.py:160-193), all channels:
  *   u_c = w_c/rho + lam_c D y_c ;  s = max(|u| - 1/rho, 0) / (|u| + 1e-7), |u| joint over c,d
  *   z_c = s u_c ;  w_c += rho (lam_c D y_c - z_c)
- * y_ptrs / lam: HOST arrays of n_channels device pointers / scalars (n_channels <= 8);
+ * y_ptrs / lam: HOST arrays of n_channels device pointers / scalars (any n_channels >= 1; more than 8 run as chained launches);
  * z, w: (C,3,X,Y,Z) device, updated in place; jtv: (X,Y,Z) device, receives s (the
  * reference returns it as `tmp`, _update.py:195).  alpha is the over-relaxation
  * parameter (1 = none). */

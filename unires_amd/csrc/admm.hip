@@ -13,10 +13,13 @@
 
 namespace unires {
 
-struct ChanPtrs {  // up to 8 channels per launch
+struct ChanPtrs {  // up to 8 channels per launch; more channels run as chained launches
   const float *y[8];
   float lam[8];
   int n;
+  int c0;     // index of y[0] among the subject's channels (offset into w / z_old)
+  int first;  // 0: the squared magnitude of the earlier channels is read from `scale`
+  int last;   // 0: the running squared magnitude is stored to `scale` instead of the final result
 };
 
 // forward differences of y at (i,j,k), zero bound, times lam / vx
@@ -50,11 +53,13 @@ __global__ void __launch_bounds__(kBlock)
     const int k = kc * kWave + threadIdx.x, j = jq * 4 + threadIdx.y;
     if (k >= d.z || j >= d.y) continue;
     const size_t idx = ((size_t)i * d.y + j) * d.z + k;
-    float acc = 0.f;
+    // (more than 8 channels: the sum over channels continues, in the same order and the same float32
+    // arithmetic, from the value the previous launch left in `scale`)
+    float acc = C.first ? 0.f : scale[idx];
     for (int c = 0; c < C.n; ++c) {
       float gx, gy, gz;
       grad_at(C.y[c], idx, i, j, k, d, C.lam[c] * ivx, C.lam[c] * ivy, C.lam[c] * ivz, gx, gy, gz);
-      const size_t o = (size_t)c * 3 * n + idx;
+      const size_t o = (size_t)(C.c0 + c) * 3 * n + idx;
       if (alpha != 1.f) {  // Dy = alpha*Dy + (1-alpha)*z_old   (_update.py:169-170)
         gx = alpha * gx + (1.f - alpha) * z_old[o];
         gy = alpha * gy + (1.f - alpha) * z_old[o + n];
@@ -65,6 +70,10 @@ __global__ void __launch_bounds__(kBlock)
       }
       acc += gx * gx + gy * gy + gz * gz;
     }
+    if (!C.last) {
+      scale[idx] = acc;
+      continue;
+    }
     const float nrm = sqrtf(acc);
     if (norm_only) {
       tot += (double)nrm;
@@ -72,7 +81,7 @@ __global__ void __launch_bounds__(kBlock)
       scale[idx] = fmaxf(nrm - irho, 0.f) / (nrm + 1e-7f);
     }
   }
-  if (partials) {  // one float64 atomic per workgroup (<= 2048 per launch, once per ADMM iteration)
+  if (partials && C.last) {  // one float64 atomic per workgroup (<= 2048 per launch, once per ADMM iteration)
     const double s = block_sum(tot);
     if (threadIdx.x == 0 && threadIdx.y == 0) atomicAdd(partials, s);
   }
@@ -240,13 +249,19 @@ static inline int tile_blocks(Dim3i d) {
 int launch_jtv_scale(const float *const *y, const float *lam, int nc, const float *w,
                      const float *z_old, Dim3i d, const float vx[3], float rho, float alpha,
                      float *scale, double *partials, int norm_only, hipStream_t st) {
-  if (nc > 8) return -1;
-  ChanPtrs C;
-  C.n = nc;
-  for (int c = 0; c < nc; ++c) C.y[c] = y[c], C.lam[c] = lam[c];
+  // The joint-TV magnitude couples all channels of a voxel (unires/_update.py:166-173 loops over any
+  // C); the kernel takes 8 channel pointers by value, so more channels run as a chain of launches
+  // that carry the running sum of squares in `scale`.
+  if (nc > 8 && !scale) return -1;
   const int g = tile_blocks(d);
-  hipLaunchKernelGGL(k_jtv_scale, dim3(g), vblock(), 0, st, C, w, z_old, d, 1.f / vx[0],
-                     1.f / vx[1], 1.f / vx[2], rho, alpha, scale, partials, norm_only);
+  for (int c0 = 0; c0 < nc; c0 += 8) {
+    ChanPtrs C;
+    C.n = nc - c0 < 8 ? nc - c0 : 8;
+    C.c0 = c0, C.first = c0 == 0, C.last = c0 + 8 >= nc;
+    for (int c = 0; c < 8; ++c) C.y[c] = y[c0 + (c < C.n ? c : 0)], C.lam[c] = lam[c0 + (c < C.n ? c : 0)];
+    hipLaunchKernelGGL(k_jtv_scale, dim3(g), vblock(), 0, st, C, w, z_old, d, 1.f / vx[0],
+                       1.f / vx[1], 1.f / vx[2], rho, alpha, scale, partials, norm_only);
+  }
   return g;
 }
 

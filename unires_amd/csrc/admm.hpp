@@ -5,7 +5,8 @@
 namespace unires {
 
 // scale = JTV shrinkage factor (norm_only == 0) or partials of sum(JTV norm) (norm_only == 1);
-// returns the number of partials written (or -1 if nc > 8).
+// any number of channels (more than 8: chained launches carrying the sum of squares in `scale`, which
+// must then be given); returns the number of partials written (or -1 if nc > 8 without `scale`).
 int launch_jtv_scale(const float *const *y, const float *lam, int nc, const float *w,
                      const float *z_old, Dim3i d, const float vx[3], float rho, float alpha,
                      float *scale, double *partials, int norm_only, hipStream_t st);

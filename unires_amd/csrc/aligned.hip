@@ -235,8 +235,11 @@ __device__ __forceinline__ float a4_upper(float v) {  // lane l gets lane l + 1'
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
 }
 
+#ifndef UNIRES_ALIGNED4_WAVES
+#define UNIRES_ALIGNED4_WAVES 6
+#endif
 template <int NP4, bool DOT, bool OBJ>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, NP4 == 1 ? UNIRES_ALIGNED4_WAVES : 4)
     k_ata_aligned4(AlignedArgs A, const int *__restrict__ done) {
   if (done && *done) return;
   extern __shared__ __align__(16) float smem[];
@@ -268,6 +271,11 @@ __global__ void __launch_bounds__(kBlock)
   }
   __syncthreads();
   // ---- lane constants (independent of the line): the conv_up pair of each of the lane's voxels ----
+  // (Measured, r3: re-reading them from the LDS table for every line (-DUNIRES_ALIGNED4_LDSTAB) to get
+  // from 76 to 64 registers / from 6 to 8 waves per SIMD: 33.6 - 34.2 us instead of 31.0; requesting
+  // the x + 1 line one line ahead: 35.2 us - loads and stores share one in-order counter on gfx9, so
+  // every wait drains the look-ahead load and the previous store as well.)
+#ifndef UNIRES_ALIGNED4_LDSTAB
   float ew0[NP4][4], ew1[NP4][4];
   int exo[NP4][4];
 #pragma unroll
@@ -277,6 +285,7 @@ __global__ void __launch_bounds__(kBlock)
       const float4 tb = ztab[u * 4 * kWave + 4 * lane + e];
       ew0[u][e] = tb.y, ew1[u][e] = tb.z, exo[u][e] = __float_as_int(tb.x);
     }
+#endif
   const float *__restrict__ p = A.p;
   float *__restrict__ q = A.q;
   const int nlines = dd.x * dd.y;
@@ -350,7 +359,15 @@ __global__ void __launch_bounds__(kBlock)
         for (int e = 0; e < 4; ++e) {
           const float c = c4[e];
           float h = 0.f;
+#ifndef UNIRES_ALIGNED4_LDSTAB
           if (HAS) h = ew0[u][e] * xs[exo[u][e]] + ew1[u][e] * xs[exo[u][e] + 1];
+#else
+          if (HAS) {
+            const float4 tb = ztab[u * 4 * kWave + 4 * lane + e];
+            const float *xo = xs + __float_as_int(tb.x);
+            h = tb.y * xo[0] + tb.z * xo[1];
+          }
+#endif
           float xf, xb, yf, yb;
           if (EDGE) {
             xf = (hx ? xp4[e] : 0.f) - c, xb = lx ? c - xm4[e] : 0.f;
@@ -383,7 +400,8 @@ __global__ void __launch_bounds__(kBlock)
           dot += (double)obj_term(out[u].x, rb[u].x, rc[u].x) + (double)obj_term(out[u].y, rb[u].y, rc[u].y) +
                  (double)obj_term(out[u].z, rb[u].z, rc[u].z) + (double)obj_term(out[u].w, rb[u].w, rc[u].w);
         } else {
-          *reinterpret_cast<af4 *>(qc + z) = out[u];
+          // (nt store: 29.7 vs 30.9 us - q is not read again before the next kernel)
+          __builtin_nontemporal_store(out[u], reinterpret_cast<af4 *>(qc + z));
           if (DOT)
             dot += (double)__fmul_rn(rc[u].x, out[u].x) + (double)__fmul_rn(rc[u].y, out[u].y) +
                    (double)__fmul_rn(rc[u].z, out[u].z) + (double)__fmul_rn(rc[u].w, out[u].w);

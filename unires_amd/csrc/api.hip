@@ -1053,8 +1053,9 @@ static int cg_enqueue(unires_plan *pl, float rho, float lam, const float *b, flo
   }
   launch_sc_init(S, pl->part0, pl->part1, gv, stop_mode, check ? 1 : 0, st);
 
-  // UNIRES_CG_FOLD=0: alpha / beta in one-block kernels of their own (the r1 / r2 form)
-  static const bool fold_on = !(getenv("UNIRES_CG_FOLD") && getenv("UNIRES_CG_FOLD")[0] == '0');
+  // UNIRES_CG_FOLD=1: alpha / beta in the prologues of the vector kernels instead of one-block
+  // kernels of their own
+  static const bool fold_on = getenv("UNIRES_CG_FOLD") && getenv("UNIRES_CG_FOLD")[0] == '1';
   const int gf = vec_num_blocks_fold(ny);
   for (int k = 1; k <= max_iter; ++k) {
     const int g = matvec(pl, rho, lam, pl->p, pl->ap, pl->part0, done, st);
@@ -1169,7 +1170,7 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
 // --------------------------------------------------------------------------
 static int check_channels(const float *const *y_ptrs, const float *lam, int32_t n) {
   if (!y_ptrs || !lam) return fail(UNIRES_ERR_NULL, "null argument");
-  if (n < 1 || n > 8) return fail(UNIRES_ERR_UNSUPPORTED, "1..8 channels per call");
+  if (n < 1 || n > 4096) return fail(UNIRES_ERR_ARG, "channel count out of range");
   for (int c = 0; c < n; ++c)
     if (!y_ptrs[c]) return fail(UNIRES_ERR_NULL, "null channel pointer");
   return UNIRES_OK;
@@ -1205,8 +1206,10 @@ extern "C" int unires_nll_prior(const float *const *y_ptrs, const float *lam, in
   if (!vx_ok(vx)) return fail(UNIRES_ERR_ARG, "voxel size must be positive");
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(double), st));
-  launch_jtv_scale(y_ptrs, lam, n_channels, nullptr, nullptr, mk(dim), vx, 1.f, 1.f, nullptr,
-                   out_dev, 1, st);
+  float *acc = nullptr;  // more than 8 channels: the running sum of squares needs a volume of scratch
+  if (n_channels > 8) HIP_TRY(hipMallocAsync((void **)&acc, mk(dim).numel() * sizeof(float), st));
+  launch_jtv_scale(y_ptrs, lam, n_channels, nullptr, nullptr, mk(dim), vx, 1.f, 1.f, acc, out_dev, 1, st);
+  if (acc) HIP_TRY(hipFreeAsync(acc, st));
   CHECK_LAUNCH();
   return UNIRES_OK;
 }

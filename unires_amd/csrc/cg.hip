@@ -244,47 +244,37 @@ static inline int vec_blocks_fold(size_t n) {
   return (int)(b < 4096 ? b : 4096);
 }
 
+// r update: 1024 persistent workgroups (3 volume passes keep the streaming rate at this size; its
+// <= 1024 partial sums are what the 4096 workgroups of the x / p update re-reduce - 4 loads per thread)
+static inline int vec_blocks_rfold(size_t n) {
+  size_t b = (n / 4 + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  return (int)(b < 1024 ? b : 1024);
+}
 __global__ void __launch_bounds__(kBlock)
     k_update_r_fold(CgState *__restrict__ st, const double *__restrict__ part_pap, int g, int k,
                     const float *__restrict__ ap, float *__restrict__ r, size_t n,
                     double *__restrict__ part_rr, const float *__restrict__ M) {
   if (st->done) return;
-  const size_t n4 = n / 4, chunk = (size_t)kFoldIt * kBlock;
-  float alpha = 0.f;
-  bool have = false;
+  const double pap = reduce_all(part_pap, g);
+  const double alpha_d = st->rzpp[(k - 1) & 1] / pap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->pAp = pap, st->alpha = alpha_d;
+  const float alpha = (float)alpha_d;
+  GRID_STRIDE_VEC4(n);
   double rr = 0.0;
-  for (size_t c = blockIdx.x; c * chunk < n4 || !have; c += gridDim.x) {
-    float4 va[kFoldIt], vr[kFoldIt];
-    size_t idx[kFoldIt];
-#pragma unroll
-    for (int u = 0; u < kFoldIt; ++u) {
-      idx[u] = c * chunk + (size_t)u * kBlock + threadIdx.x;
-      if (idx[u] < n4) va[u] = ld4(ap, idx[u]), vr[u] = ld4(r, idx[u]);
-    }
-    if (!have) {  // (wave-uniform: first trip of the loop)
-      const double pap = reduce_all(part_pap, g);
-      const double alpha_d = st->rzpp[(k - 1) & 1] / pap;
-      if (blockIdx.x == 0 && threadIdx.x == 0) st->pAp = pap, st->alpha = alpha_d;
-      alpha = (float)alpha_d;
-      have = true;
-    }
-#pragma unroll
-    for (int u = 0; u < kFoldIt; ++u) {
-      if (idx[u] < n4) {
-        float4 x = vr[u];
-        x.x = __fsub_rn(x.x, __fmul_rn(alpha, va[u].x));
-        x.y = __fsub_rn(x.y, __fmul_rn(alpha, va[u].y));
-        x.z = __fsub_rn(x.z, __fmul_rn(alpha, va[u].z));
-        x.w = __fsub_rn(x.w, __fmul_rn(alpha, va[u].w));
-        st4(r, idx[u], x);
-        const float4 vz = zval4(x, M, idx[u]);
-        rr += (double)__fmul_rn(x.x, vz.x) + (double)__fmul_rn(x.y, vz.y) + (double)__fmul_rn(x.z, vz.z) +
-              (double)__fmul_rn(x.w, vz.w);
-      }
-    }
+  for (size_t i = tid0; i < n4; i += stride) {
+    const float4 va = ld4(ap, i);
+    float4 vr = ld4(r, i);
+    vr.x = __fsub_rn(vr.x, __fmul_rn(alpha, va.x));
+    vr.y = __fsub_rn(vr.y, __fmul_rn(alpha, va.y));
+    vr.z = __fsub_rn(vr.z, __fmul_rn(alpha, va.z));
+    vr.w = __fsub_rn(vr.w, __fmul_rn(alpha, va.w));
+    st4(r, i, vr);
+    const float4 vz = zval4(vr, M, i);
+    rr += (double)__fmul_rn(vr.x, vz.x) + (double)__fmul_rn(vr.y, vz.y) +
+          (double)__fmul_rn(vr.z, vz.z) + (double)__fmul_rn(vr.w, vz.w);
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail
-    const size_t i = n4 * 4 + threadIdx.x;
+  for (size_t i = n4 * 4 + tid0; i < n; i += stride) {
     const float vr = __fsub_rn(r[i], __fmul_rn(alpha, ap[i]));
     r[i] = vr;
     rr += (double)__fmul_rn(vr, zval1(vr, M, i));
@@ -443,10 +433,10 @@ __global__ void __launch_bounds__(kBlock) k_sum_to(const double *part, int g, do
 
 // ---- launchers -------------------------------------------------------------
 int vec_num_blocks(size_t n) { return vec_blocks(n); }
-int vec_num_blocks_fold(size_t n) { return vec_blocks_fold(n); }
+int vec_num_blocks_fold(size_t n) { return vec_blocks_rfold(n); }  // partials the r update writes
 void launch_update_r_fold(CgState *s, const double *part_pap, int g, int k, const float *ap, float *r,
                           size_t n, double *part_rr, const float *M, hipStream_t st) {
-  hipLaunchKernelGGL(k_update_r_fold, dim3(vec_blocks_fold(n)), dim3(kBlock), 0, st, s, part_pap, g, k, ap, r,
+  hipLaunchKernelGGL(k_update_r_fold, dim3(vec_blocks_rfold(n)), dim3(kBlock), 0, st, s, part_pap, g, k, ap, r,
                      n, part_rr, M);
 }
 void launch_update_px_fold(CgState *s, const double *part_rr, int g, int k, const float *r, float *p,

@@ -570,8 +570,11 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
     for (int i = threadIdx.x; i < P.tabn; i += kWave * kS2Waves) {
       float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i >= 64 && i - 64 < P.gn) e = P.tab[i - 64];
+      // (.w = the grid coordinate the entry belongs to, as a float: the z-profile kernels take k from
+      // the table instead of converting it, and the 16-byte read costs the LDS 4 cycles where the 12-byte
+      // one costs 8)
       tabs[i] = make_float4(__int_as_float((int)(step4 * (unsigned)__float_as_int(e.x))), P.alpha * e.y,
-                            P.alpha * e.z, 0.f);
+                            P.alpha * e.z, (float)(i - 64));
     }
     __syncthreads();
   }
@@ -709,6 +712,7 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
           (void)code;
         } else if (AXIS == 2) {
           const float4 tb = tabs[k + 64];
+          Bt.kf[u] = tb.w;
           const unsigned a = __umul24(code, P.row_stride4) + (unsigned)__float_as_int(tb.x);
           const uint2 pr = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a, 0, 0));
           Bt.w0[u] = tb.y, Bt.w1[u] = tb.z, Bt.s0[u] = __uint_as_float(pr.x), Bt.s1[u] = __uint_as_float(pr.y);

@@ -23,7 +23,10 @@
 
 namespace unires {
 
-constexpr int kFlatVecs = 2;                           // float4 per thread and chunk
+#ifndef UNIRES_FLAT_VECS
+#define UNIRES_FLAT_VECS 1
+#endif
+constexpr int kFlatVecs = UNIRES_FLAT_VECS;            // float4 per thread and chunk
 constexpr int kFlatChunk = kBlock * 4 * kFlatVecs;     // voxels per chunk (2048)
 
 struct FlatArgs {
@@ -120,7 +123,7 @@ __device__ __forceinline__ void flat_vec(const FlatArgs &A, const FlatVec &L, un
         dot += (double)__fmul_rn(ce, o);
     }
   }
-  if (!OBJ && valid) *reinterpret_cast<float4 *>(q + idx0) = make_float4(out[0], out[1], out[2], out[3]);
+  if (!OBJ && valid) __builtin_nontemporal_store(f4{out[0], out[1], out[2], out[3]}, reinterpret_cast<f4 *>(q + idx0));
 }
 
 template <bool DOT, bool OBJ>

@@ -50,8 +50,6 @@ def fit(x, y, sett):
     Returns (dat_y, mat_y, R, info): reconstructions stacked to (dim_y, C) float32, the
     output affine, the rigid matrices (N, 4, 4) and a dict with the objective trace
     ``obj`` (n_iter, 3), the iteration count and the regularisation schedule."""
-    if len(y) > 8:  # unires_zw_update / unires_nll_prior couple all channels in one launch
-        raise NotImplementedError('unires_amd: at most 8 channels per subject (joint-TV kernels)')
     if len(x) != len(y):
         raise ValueError('one output per channel')
     with torch.no_grad():
