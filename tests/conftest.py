@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    config.addinivalue_line('markers', 'slow: minutes of CPU oracle at full size (still part of -m gpu)')
 
 
 @pytest.fixture(scope='session')

@@ -121,3 +121,65 @@ def test_full_size_config1_shape_matches_oracle(dev):
     """181 x 217 x 181 (BrainWeb shape, non-multiple-of-tile tails), R1 and R0."""
     _check(dev, 'cfg2_181c3_1mm', (181, 217, 181), seed=1, rhs=False)
     _check(dev, 'cfg1_181c1_denoise', (181, 217, 181), seed=1, rhs=False)
+
+
+def _solve_both(dev, wl, dim_y, seed, max_iter, tolerance, threads=16):
+    """The same CG solve (nitorch cg as UniRes calls it, unires/_update.py:142-148) on the oracle and
+    on the HIP path: RHS assembled by each side from the same observation / z / w, zero start."""
+    from unires_amd._project import _channel_plan
+    import unires_amd as U
+    P = bench.oracle_channel(wl, dim_y, seed=seed)
+    regime = wl.get('regime', 'sr')
+    method = 'super-resolution' if regime == 'sr' else 'denoising'
+    g = torch.Generator().manual_seed(seed + 100)
+    z = 0.05 * torch.randn((3,) + tuple(dim_y), generator=g)
+    w = 0.05 * torch.randn((3,) + tuple(dim_y), generator=g)
+    vx = N.voxel_size(P['mat_y']).float()
+    rho = 0.9
+    all_threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, all_threads))  # (the oracle's index_add_ passes anti-scale beyond ~16)
+    try:
+        b_ref = O.y_rhs(P['xc'], P['yc'], z, w, torch.tensor(rho), vx, method, regime != 'id')
+        lhs = bench.oracle_lhs(wl, P, rho=rho)
+        y_ref, it_ref, obj_ref = N.cg(lhs, b_ref, torch.zeros(dim_y), max_iter=max_iter, tolerance=tolerance,
+                                      stop='max_gain', return_info=True)
+    finally:
+        torch.set_num_threads(all_threads)
+    po_g = U._proj_info(dim_y, P['mat_y'], P['dim_x'], P['mat_x'], rigid=P['rigid'], prof_ip=0, prof_tp=0,
+                        device=dev)
+    xg = [U._input(P['dat_x'].to(dev), P['mat_x'], P['tau'], po_g)]
+    yg = U._output(torch.zeros(dim_y, device=dev), P['mat_y'], P['lam'])
+    plan = _channel_plan(xg, yg, method, regime != 'id')
+    b = plan.rhs([xg[0].dat], w.to(dev), z.to(dev), rho, P['lam'])
+    x = torch.zeros(dim_y, device=dev)
+    it, obj = plan.cg(b, x, rho, P['lam'], max_iter=max_iter, tolerance=tolerance, stop='max_gain')
+    ties, _ = bench.fov_tie_voxels(wl, P)
+    return dict(y_ref=y_ref, it_ref=it_ref, obj_ref=obj_ref, y=x.cpu(), it=it, obj=obj, keep=~ties)
+
+
+@pytest.mark.slow
+def test_full_size_config3_cg_iterations_match_oracle(dev):
+    """BASELINE configs[2] geometry at FULL size (256^3, one channel): the RHS and three iterations of
+    the reference-faithful CG (stop='max_gain': the objective 0.5 sum x (Ax - 2b) after every iteration,
+    one extra A(x) each) - iterate and objective trace against the oracle.  ~1 minute of CPU oracle."""
+    wl = dict(bench.WORKLOADS['cfg3_256c3_thick6z'])
+    r = _solve_both(dev, wl, (256, 256, 256), seed=0, max_iter=3, tolerance=1e-30)
+    assert r['it'] == r['it_ref'] == 3
+    assert torch.allclose(torch.tensor(r['obj'], dtype=torch.float64), r['obj_ref'].double(), rtol=1e-5, atol=0)
+    assert rel_err(r['y'][r['keep']], r['y_ref'][r['keep']]) < GATE
+    n_vox = 256 ** 3
+    assert rel_err(r['y'], r['y_ref']) < GATE + 4.0 * math.sqrt(((~r['keep']).sum().item() + 1) / n_vox)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_max_gain_iteration_counts_at_128(dev, seed):
+    """The reference-faithful stopping rule (cgs_tol = 1e-3 on the 'max_gain' objective, struct.py:65-67)
+    on the configuration-3 geometry at 128^3: the realised iteration count is the oracle's and so are the
+    iterate and the objective trace.  (At 256^3 the bench's three channels stop after 10 / 2 / 3
+    iterations, `variants.cg_tol1e-3_max_gain` of the bench line.)"""
+    wl = dict(bench.WORKLOADS['cfg3_256c3_thick6z'])
+    r = _solve_both(dev, wl, (128, 128, 128), seed=seed, max_iter=20, tolerance=1e-3)
+    assert r['it'] == r['it_ref'], (r['it'], r['it_ref'])
+    assert torch.allclose(torch.tensor(r['obj'], dtype=torch.float64), r['obj_ref'].double(), rtol=1e-5, atol=0)
+    assert rel_err(r['y'][r['keep']], r['y_ref'][r['keep']]) < GATE

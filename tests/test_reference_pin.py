@@ -18,7 +18,8 @@ from oracle import unires_restated as O
 from tests.helpers import rel_err
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = ['ref_sr_2ch', 'ref_sr_2rep', 'ref_dn_1ch', 'ref_id_2rep', 'ref_sr_fine']
+CASES = ['ref_sr_2ch', 'ref_sr_2rep', 'ref_dn_1ch', 'ref_id_2rep', 'ref_sr_fine', 'ref_sr_gauss',
+         'ref_sr_fine_gauss']
 TOL = 1e-6
 
 
@@ -35,7 +36,8 @@ def load_case(name):
             dat = torch.from_numpy(g['x_' + k])
             mat_x = torch.from_numpy(g['mat_x_' + k])
             po = O.proj_info(dim_y, mat_y, tuple(dat.shape), mat_x, rigid=torch.from_numpy(g['rigid_' + k]),
-                             prof_ip=0, prof_tp=0, scl=float(g['scl_' + k]))
+                             prof_ip=int(g['prof_ip']) if 'prof_ip' in g else 0, prof_tp=0,
+                             scl=float(g['scl_' + k]))
             xn = O.make_input(dat.clone(), mat_x, torch.tensor(float(g['tau_' + k])), po)
             xn.rigid_q = torch.from_numpy(g['rigid_q_' + k]).clone()
             xc.append(xn)
@@ -96,7 +98,7 @@ def _after_admm(g, x, y, method, do_proj, tag='_a15'):
     return y
 
 
-@pytest.mark.parametrize('name', ['ref_sr_2ch', 'ref_sr_2rep', 'ref_sr_fine'])
+@pytest.mark.parametrize('name', ['ref_sr_2ch', 'ref_sr_2rep', 'ref_sr_fine', 'ref_sr_gauss', 'ref_sr_fine_gauss'])
 def test_update_scaling(name):
     """_update_scaling (:270-393): two Gauss-Newton iterations with line search."""
     g, method, do_proj, dim_y, x, y = load_case(name)
@@ -108,7 +110,8 @@ def test_update_scaling(name):
             np.testing.assert_allclose(float(xn.po.scl), float(g['scl1_%d_%d' % (c, n)]), rtol=1e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize('name', ['ref_sr_2ch', 'ref_sr_2rep', 'ref_dn_1ch', 'ref_sr_fine'])
+@pytest.mark.parametrize('name', ['ref_sr_2ch', 'ref_sr_2rep', 'ref_dn_1ch', 'ref_sr_fine', 'ref_sr_gauss',
+                                  'ref_sr_fine_gauss'])
 def test_update_rigid_channel(name):
     """_update_rigid_channel (:541-710), no sub-sampling, same se(3) basis as the fixture."""
     g, method, do_proj, dim_y, x, y = load_case(name)
@@ -116,7 +119,8 @@ def test_update_rigid_channel(name):
     basis = torch.from_numpy(g['basis'])
     for c in range(len(x)):
         xc, sll = O.update_rigid_channel(x[c], y[c], method, basis, max_niter_gn=1, num_linesearch=4,
-                                         samp=int(g['rigid_samp']))
+                                         samp=int(g['rigid_samp']),
+                                         prof_ip=int(g['prof_ip']) if 'prof_ip' in g else 0)
         np.testing.assert_allclose(float(sll), float(g['rig_sll_%d' % c]), rtol=1e-6)
         for n, xn in enumerate(xc):
             np.testing.assert_allclose(xn.rigid_q.numpy(), g['rig_q1_%d_%d' % (c, n)], rtol=1e-5, atol=1e-8)

@@ -269,6 +269,10 @@ struct Repeat {
   // 4): the x / y part runs as 1-D passes through a (gf.x, gf.y, xd.z) intermediate, the z part
   // stays fused in the pull / splat kernels, which then cost what they cost for a z-only profile
   bool hyb = false;
+  // forward-only hybrid (r3): many-tap profiles (sep) whose z part the window pull can still fuse -
+  // any number of z taps - while conv_up keeps its 1-D passes (the splat tabulates a fan-in of 2 only):
+  // the default Gaussian in-plane profile of BASELINE config 4
+  bool hybf = false;
   Taps Tz, Txy;
   Dim3i dim_h;
   // device tables for the on-the-fly conv_up of k_gather2: [0] no scaling (AtA), [1] S(scl) (At)
@@ -370,7 +374,7 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
   out.sep = (long long)out.Tf.n[0] * out.Tf.n[1] * out.Tf.n[2] > 64;
   for (int d = 0; d < 3; ++d)
     if ((out.Tf.n[d] + out.Tf.s[d] - 1) / out.Tf.s[d] > 2) out.sep = true;
-  out.hyb = false;
+  out.hyb = out.hybf = false;
   if (pl->regime == UNIRES_REGIME_SUPERRES) {
     static const bool no_hyb = getenv("UNIRES_NO_HYBRID") != nullptr;
     auto dirac = [&](int d) { return out.Tf.n[d] == 1 && out.Tf.s[d] == 1 && out.Tf.t[d][0] == 1.f; };
@@ -378,9 +382,11 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
     const bool z_ok = (out.Tf.n[2] + out.Tf.s[2] - 1) / out.Tf.s[2] <= 2 && out.dim_x.z >= 2;
     int nconv = 0;
     for (int d = 0; d < 3; ++d) nconv += !dirac(d);
-    if (!no_hyb && xy && nconv > 1 && z_ok) {
-      out.hyb = true;
-      out.sep = false;
+    const bool both = !no_hyb && xy && nconv > 1 && z_ok;
+    const bool fwd_only = !no_hyb && !both && out.sep && xy && !dirac(2) && out.dim_x.z >= 2;
+    if (both || fwd_only) {
+      out.hyb = both, out.hybf = fwd_only;
+      if (both) out.sep = false;
       out.Tz = out.Tf, out.Txy = out.Tf;
       for (int d = 0; d < 2; ++d) out.Tz.n[d] = out.Tz.s[d] = 1, out.Tz.t[d][0] = 1.f;
       out.Txy.n[2] = out.Txy.s[2] = 1, out.Txy.t[2][0] = 1.f;
@@ -502,7 +508,7 @@ static void build_pull(unires_plan *pl, Repeat &R) {
   R.pplan.valid = false;
   if (pl->regime == UNIRES_REGIME_DENOISE)
     (void)pull2_build(R.pplan, pl->dy, R.A, R.T, R.dim_g, R.dim_g, pl->fov_tol);
-  else if (pl->regime == UNIRES_REGIME_SUPERRES && R.hyb)
+  else if (pl->regime == UNIRES_REGIME_SUPERRES && (R.hyb || R.hybf))
     (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tz, R.dim_h, R.dim_gf, pl->fov_tol);
   else if (pl->regime == UNIRES_REGIME_SUPERRES && !R.sep)
     (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tf, R.dim_x, R.dim_gf, pl->fov_tol);
@@ -674,7 +680,7 @@ static Scaling scaling_xy(const Scaling &S) { return S.dim == 2 ? Scaling{1.f, 1
 // hybrid forward: out = S conv_down_xy (conv_down_z pull(in));  false: not available for this repeat
 static bool hybrid_forward(unires_plan *pl, const Repeat &R, const float *in, const Scaling &S, float *out,
                            const int *done, hipStream_t st) {
-  if (!R.hyb || !pl->gbuf2 || !R.pplan.valid) return false;
+  if (!(R.hyb || R.hybf) || !pl->gbuf2 || !R.pplan.valid) return false;
   if (launch_pull_conv2(R.pplan, in, pl->dy, R.Af, R.Tz, scaling_z(S), pl->gbuf, R.dim_h, R.dim_gf,
                         pl->fov_tol, done, st))
     return false;
