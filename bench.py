@@ -35,6 +35,8 @@ WORKLOADS = {
     # name: dim_y, channels, thick ratio, thick axis per channel
     'cfg3_256c3_thick6z': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 2, 2)),
     'cfg3_256c3_thick6z_aligned': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 2, 2), rigid='identity'),
+    # the same subject translated by a fraction of a voxel per channel, no rotation (shift.hip)
+    'cfg3_256c3_thick6z_shift': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 2, 2), rigid='shift'),
     'cfg3_256c3_thick6xyz': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(0, 1, 2)),
     'cfg4_384c4_iso2': dict(dim_y=(384, 384, 384), C=4, thick=2, axes=None),
     # the same with the reference's default in-plane profile (Gaussian, struct.py:95; fan-in > 2)
@@ -102,6 +104,8 @@ def build_subject(wl, device, seed):
         rigid = rigid_matrix((u[:3] * 5.0).tolist(), (u[3:] * 0.1).tolist())
         if wl.get('rigid') == 'identity':  # grid-aligned observations (no motion between scans)
             rigid = torch.eye(4, dtype=torch.float64)
+        if wl.get('rigid') == 'shift':  # translated (+-5 mm, fractions of a voxel), not rotated
+            rigid = rigid_matrix((u[:3] * 5.0).tolist(), [0.0, 0.0, 0.0])
         regime = wl.get('regime', 'sr')
         method = 'super-resolution' if regime == 'sr' else 'denoising'
         if regime == 'id':

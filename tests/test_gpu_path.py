@@ -29,6 +29,12 @@ CASES = {
                          n_repeats=2),
     'sr_aligned': dict(dim_y=(16, 14, 24), n_channels=2, thick=3, regime='sr', thick_axes=[2, 2], rot=0.0,
                        trans=0.0, scl=0.1),
+    # translated by a fraction of a voxel, not rotated: the factorised one-kernel matvec (shift.hip); nz % 4 == 0
+    'sr_shift': dict(dim_y=(16, 14, 24), n_channels=2, thick=3, regime='sr', thick_axes=[2, 2], rot=0.0,
+                     trans=1.7, scl=0.1),
+    'sr_shift_big': dict(dim_y=(13, 11, 40), n_channels=1, thick=4, regime='sr', thick_axes=[2], rot=0.0,
+                         trans=6.3),
+    'dn_shift': dict(dim_y=(15, 13, 12), n_channels=2, regime='dn', rot=0.0, trans=2.4),
     'dn_2ch': dict(dim_y=(15, 13, 11), n_channels=2, regime='dn', rot=0.1, trans=1.5),
     'dn_2rep': dict(dim_y=(12, 12, 10), n_channels=1, regime='dn', n_repeats=2),
     'id_1ch': dict(dim_y=(18, 17, 13), n_channels=1, regime='id'),

@@ -19,6 +19,7 @@
 #include "fused.hpp"
 #include "ops.hpp"
 #include "pull2.hpp"
+#include "shift.hpp"
 #include "splat2.hpp"
 #include "stencil.hpp"
 
@@ -287,6 +288,7 @@ struct Repeat {
   float *xytab_dev[2] = {nullptr, nullptr};  // axis 3: conv_up tables along x and y (schedule build)
   int xytab_cap[2] = {0, 0};
   PullPlan pplan;  // LDS-window pull: per-workgroup geometry of this operator (pull2.hip)
+  ShiftPlan shift;  // translation-only operators: factors of AtA for the one-kernel matvec (shift.hip)
 };
 
 struct unires_plan {
@@ -341,6 +343,7 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
   memset(&out, 0, sizeof(out));
   out.sched = SplatSched();
   out.pplan = PullPlan();
+  out.shift = ShiftPlan();
   out.ctab_step = 1;
   out.tau = in->tau;
   out.scl = in->scl;
@@ -512,12 +515,18 @@ static void build_pull(unires_plan *pl, Repeat &R) {
     (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tz, R.dim_h, R.dim_gf, pl->fov_tol);
   else if (pl->regime == UNIRES_REGIME_SUPERRES && !R.sep)
     (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tf, R.dim_x, R.dim_gf, pl->fov_tol);
+  // translation-only operator (and a single repeat: the kernel is the whole matvec)
+  R.shift.valid = false;
+  if (pl->reps.size() == 1 && pl->regime != UNIRES_REGIME_IDENTITY)
+    (void)shift_build(R.shift, pl->dy, R.dim_gf, R.dim_x, R.Tf, make_scaling(2.f * R.scl, R.dim_thick), R.Af,
+                      pl->fov_tol);
   (void)hipGetLastError();
 }
 
 static void free_sched(Repeat &R) {
   splat2_free(R.sched);
   pull2_free(R.pplan);
+  shift_free(R.shift);
   for (int v = 0; v < 2; ++v) {
     if (R.ctab_dev[v]) (void)hipFree(R.ctab_dev[v]), R.ctab_dev[v] = nullptr;
     if (R.xytab_dev[v]) (void)hipFree(R.xytab_dev[v]), R.xytab_dev[v] = nullptr;
@@ -643,6 +652,7 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   // the schedule and conv tables keep their device allocations; contents are rebuilt below
   tmp.sched = plan->reps[n].sched;
   tmp.pplan = plan->reps[n].pplan;
+  tmp.shift = plan->reps[n].shift;
   tmp.ctab_dev[0] = plan->reps[n].ctab_dev[0];
   tmp.ctab_dev[1] = plan->reps[n].ctab_dev[1];
   tmp.ctab_cap = plan->reps[n].ctab_cap;
@@ -876,6 +886,9 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
                             make_scaling(2.f * R.scl, R.dim_thick), R.Af, R.tau, 0.f, c * ivx,
                             c * ivy, c * ivz, part, objb, done, st))
       return part ? aligned_blocks(pl->dy) : 0;
+    // ... or translated by a fraction of a voxel (no rotation): the factorised one-kernel matvec
+    if (!launch_ata_shift(R.shift, p, q, pl->dy, R.Af, R.tau, 0.f, c * ivx, c * ivy, c * ivz, part, objb, done, st))
+      return part ? shift_blocks(pl->dy) : 0;
   }
   // regimes 1/2: two kernels per repeat; the last one also adds c DtD p and the dot
   int npart = 0;
