@@ -9,14 +9,22 @@ g = torch.Generator().manual_seed(int(os.environ.get('SEED', '0')))
 worst = 0.0
 for it in range(int(os.environ.get('N', '12'))):
     dims = tuple(int(v) for v in torch.randint(10, int(os.environ.get('DMAX', '40')), (3,), generator=g))
-    regime = ['sr', 'sr', 'dn'][int(torch.randint(0, 3, (1,), generator=g))]
+    regime = ['sr', 'sr', 'dn', 'id'][int(torch.randint(0, 4, (1,), generator=g))]
+    rot = float(torch.rand(1, generator=g)) * 0.25
+    if int(torch.randint(0, 3, (1,), generator=g)) == 0:
+        # translated, not rotated, line length a multiple of 4: the one-kernel matvecs (shift.hip; aligned.hip
+        # when the draw is an integer shift), regime 'id': the flat stencil kernel
+        rot = 0.0
+        dims = (dims[0], dims[1], 4 * (dims[2] // 4 + 1))
     kw = dict(dim_y=dims, n_channels=int(torch.randint(1, 3, (1,), generator=g)), regime=regime,
-              rot=float(torch.rand(1, generator=g)) * 0.25, trans=float(torch.rand(1, generator=g)) * 4,
-              seed=1000 + it)
+              rot=rot, trans=float(torch.rand(1, generator=g)) * 4, seed=1000 + it)
     if regime == 'sr':
         kw.update(thick=int(torch.randint(2, 6, (1,), generator=g)), scl=float(torch.rand(1, generator=g)) * 0.2,
                   n_repeats=int(torch.randint(1, 3, (1,), generator=g)))
-        if int(torch.randint(0, 3, (1,), generator=g)) == 0:  # profile along several axes (per-axis ratios 1..3)
+        if rot == 0.0:
+            kw['thick_axes'] = [2] * kw['n_channels']
+            kw['n_repeats'] = 1
+        elif int(torch.randint(0, 3, (1,), generator=g)) == 0:  # profile along several axes (per-axis ratios 1..3)
             kw['iso'] = tuple(int(v) for v in torch.randint(1, 4, (3,), generator=g))
     try:
         prob = make_problem(**kw)

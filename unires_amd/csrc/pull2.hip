@@ -51,6 +51,10 @@ constexpr int kP2Items = 10;                    // 16-byte window pieces staged 
 #endif
 constexpr int kP2TI = UNIRES_P2_TI, kP2TJ = UNIRES_P2_TJ;  // grid rows per workgroup (profile along z only)
 constexpr int kP2Rows = 64;                     // ... and at most, in any layout
+#ifndef UNIRES_P2_BAND
+#define UNIRES_P2_BAND 4
+#endif
+constexpr int kP2Band = UNIRES_P2_BAND;         // block rows walked together (see the kernel's block mapping)
 
 struct P2Geom {
   Affine A;
@@ -176,8 +180,19 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const P2Geom &G = P.G;
   // (each XCD walks one contiguous run of workgroups: neighbours share window columns in its L2)
-  const int blk = xcd_chunked_block((int)blockIdx.x, (int)gridDim.x);
-  const int bc = blk % G.nbc, bj = (blk / G.nbc) % G.nbj, bi = blk / (G.nbc * G.nbj);
+  // Inside the run the (bi, bj) pairs are walked in BANDS of kP2Band values of bi (bc fastest, then bi
+  // inside the band, then bj): a workgroup shares window columns with its neighbours in i and in j
+  // (each column of p is wanted by ~2.2 workgroups), and the row-major walk puts the i-neighbour
+  // nbj * nbc workgroups = 7 MB of windows away at 384^3 - beyond the XCD's 4 MB L2: the pull fetched
+  // 508 MB for a 226 MB volume there (profiles/r03_traffic_other_configs.jsonl), and HBM is what bounds
+  // it at that size.
+  const int blk0 = xcd_chunked_block((int)blockIdx.x, (int)gridDim.x);
+  const int bc = blk0 % G.nbc, pair = blk0 / G.nbc;
+  const int nbi = (int)gridDim.x / (G.nbc * G.nbj);
+  const int band = pair / (kP2Band * G.nbj), rem = pair - band * (kP2Band * G.nbj);
+  const int bh = min(kP2Band, nbi - band * kP2Band);  // height of this band (the last one may be short)
+  const int bj = rem / bh, bi = band * kP2Band + (rem - bj * bh);
+  const int blk = (bi * G.nbj + bj) * G.nbc + bc;  // index of the plan's record
   const int i0 = GEN ? bi * G.oi * G.si : bi * TI, j0 = GEN ? bj * G.oj * G.sj : bj * TJ;
   const int nrows = GEN ? G.pi * G.pj : ROWS;
   const int kk0 = bc * G.m, k0 = kk0 * G.sk;
