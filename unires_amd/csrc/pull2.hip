@@ -153,6 +153,7 @@ struct P2Args {
   Dim3i xd;
   float tol;
   int W;             // window extent along x (cells); along y it is the template parameter H
+  int band;          // block rows walked together (see the kernel's block mapping)
   unsigned long long *prof;  // -DUNIRES_P2_PROF builds: per-workgroup timeline (100 MHz ticks)
   int dbg;           // UNIRES_P2_DBG ablation bits (measurement only): 1 no staging, 2 no sampling, 4 no conv / store
 };
@@ -185,13 +186,15 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   // (each column of p is wanted by ~2.2 workgroups), and the row-major walk puts the i-neighbour
   // nbj * nbc workgroups = 7 MB of windows away at 384^3 - beyond the XCD's 4 MB L2: the pull fetched
   // 508 MB for a 226 MB volume there (profiles/r03_traffic_other_configs.jsonl), and HBM is what bounds
-  // it at that size.
+  // it at that size.  (Where one block row's windows DO fit - config 3: 3.2 MB - the plain order is kept:
+  // bands cut by the XCD runs' ends fetched 79 MB instead of 72 there.)
   const int blk0 = xcd_chunked_block((int)blockIdx.x, (int)gridDim.x);
   const int bc = blk0 % G.nbc, pair = blk0 / G.nbc;
   const int nbi = (int)gridDim.x / (G.nbc * G.nbj);
-  const int band = pair / (kP2Band * G.nbj), rem = pair - band * (kP2Band * G.nbj);
-  const int bh = min(kP2Band, nbi - band * kP2Band);  // height of this band (the last one may be short)
-  const int bj = rem / bh, bi = band * kP2Band + (rem - bj * bh);
+  const int bandh = P.band;  // kP2Band, or nbi (= plain row-major order) where a block row's windows fit the L2
+  const int band = pair / (bandh * G.nbj), rem = pair - band * (bandh * G.nbj);
+  const int bh = min(bandh, nbi - band * bandh);  // height of this band (the last one may be short)
+  const int bj = rem / bh, bi = band * bandh + (rem - bj * bh);
   const int blk = (bi * G.nbj + bj) * G.nbc + bc;  // index of the plan's record
   const int i0 = GEN ? bi * G.oi * G.si : bi * TI, j0 = GEN ? bj * G.oj * G.sj : bj * TJ;
   const int nrows = GEN ? G.pi * G.pj : ROWS;
@@ -598,6 +601,11 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
   // the window, or the conv scratch that aliases it (64 rows x 65 floats) if that is larger
   const size_t lds = std::max((size_t)W * H * kP2SZ, (size_t)kP2Rows * (kWave + 1)) * sizeof(float);
   const dim3 grid((unsigned)p2_blocks(P.G, xd)), block(kBlock);
+  {
+    const long long nbi = (long long)grid.x / ((long long)P.G.nbc * P.G.nbj);
+    const bool row_fits_l2 = (double)P.G.nbj * P.G.nbc * (double)lds < 3.5e6;
+    P.band = (int)(row_fits_l2 ? std::max<long long>(nbi, 1) : kP2Band);
+  }
   P.prof = nullptr;
 #ifdef UNIRES_P2_PROF
   static unsigned long long *prof_dev = nullptr;
