@@ -221,6 +221,11 @@ def test_spatial_facade_recovers_the_affine_of_a_dense_grid():
     import pytest
     with pytest.raises(NotImplementedError):
         spatial._affine_of_grid(bent)
+    # a deformation away from the corners / centre (where r2's four probes sat) is caught as well
+    bent2 = g.clone()
+    bent2[1, 1, 1, 2] -= 0.3
+    with pytest.raises(NotImplementedError):
+        spatial._affine_of_grid(bent2)
     from unires_amd._util import _bids_name
     assert _bids_name('/a/b/sub-01_T1w.nii') == '/a/b/sub-01_space-unires_T1w.nii'
     assert _bids_name('img.nii.gz') == 'space-unires_img.nii.gz'

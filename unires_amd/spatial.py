@@ -59,15 +59,16 @@ def _affine_of_grid(grid):
             idx = [0, 0, 0]
             idx[d] = shape[d] - 1
             mat[:3, d] = (g[tuple(idx)] - o) / (shape[d] - 1)
-    # every probe point must lie on the affine (float32 grids: a few ulps of the coordinates)
-    probes = [(shape[0] - 1, shape[1] - 1, shape[2] - 1), (shape[0] // 2, shape[1] // 3, shape[2] // 2),
-              (shape[0] // 3, shape[1] - 1, 0), (0, shape[1] // 2, shape[2] - 1)]
+    # EVERY grid point must lie on the affine (float32 grids: a few ulps of the coordinates): a dense
+    # deformation that happens to vanish at a handful of probe points must not be sampled as if it were
+    # one (one vectorised pass on the host; this facade is a convenience path, not the hot one)
     tol = 1e-4 * max(1.0, float(g.abs().max()))
-    for pt in probes:
-        want = mat[:3, :3] @ torch.tensor(pt, dtype=torch.float64) + mat[:3, 3]
-        if (g[pt] - want).abs().max() > tol:
-            raise NotImplementedError('unires_amd: only affine sampling grids are built (the reference '
-                                      'path never makes another kind, unires/_project.py:159)')
+    ax = [torch.arange(n, dtype=torch.float64) for n in shape]
+    ijk = torch.stack(torch.meshgrid(*ax, indexing='ij'), -1)
+    want = ijk @ mat[:3, :3].T + mat[:3, 3]
+    if float((g - want).abs().max()) > tol:
+        raise NotImplementedError('unires_amd: only affine sampling grids are built (the reference '
+                                  'path never makes another kind, unires/_project.py:159)')
     return mat, shape
 
 
