@@ -545,6 +545,7 @@ def main():
         per_channel = [time_matvec(x, y, rho, sett, ring=4, channels=[c], graph=False) * 1e6 for c in range(len(x))]
         b_mv = alg_bytes_matvec(x[0], wl['dim_y'], sett.do_proj)
         achieved = b_mv / t_mv / 1e9
+        traffic = pmc_traffic(args.workload)
         out = {
             'metric': 'cg_iters_per_sec', 'value': total_iters / elapsed, 'unit': 'cg_iters/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -562,7 +563,10 @@ def main():
                                      '(%.2f ms per ADMM iteration)' % (n_admm, t_subject, t_subject / n_admm * 1e3),
             'roofline': {'bound': 'hbm', 'kernel': 'ata_matvec (per launch, mean over channels, cold operands)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(args.workload),
+                         'frac': achieved / HBM_PEAK_GBS,
+                         # HBM bytes per launch from the PMC counters (null if no profile of this workload is
+                         # committed); STATIC: read from the committed profile named in traffic_source
+                         'traffic': (traffic or {}).get('bytes_per_launch'), 'traffic_source': traffic,
                          'alg_bytes_per_launch': b_mv, 'us_per_launch': t_mv * 1e6,
                          'us_per_launch_graph': t_mv_graph * 1e6, 'us_per_launch_eager': t_mv_eager * 1e6,
                          'us_per_launch_by_channel': per_channel, 'timing': 'plain launches, HIP events on the launch stream'},
