@@ -415,6 +415,145 @@ __global__ void __launch_bounds__(kBlock, NP4 == 1 ? UNIRES_ALIGNED4_WAVES : 4)
   }
 }
 
+// ---- two lines per trip (r3): the 16-byte form on PAIRS of y-adjacent lines (ny even, nz <= 256) -------
+// The line kernel's time is latency, not work: per line a wave issues its loads, waits, goes through four
+// dependent LDS round trips, stores, and - loads and stores sharing one in-order counter - drains that
+// store at the next line's first wait.  Two y-adjacent lines per trip halve the trips: eight loads serve
+// two lines (each is the other's y neighbour) instead of ten, twice the bytes are in flight per wave, and
+// the drain is paid once per pair.
+template <bool DOT, bool OBJ>
+__global__ void __launch_bounds__(kBlock) k_ata_aligned4x2(AlignedArgs A, const int *__restrict__ done) {
+  if (done && *done) return;
+  extern __shared__ __align__(16) float smem[];
+  const unsigned lane = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const Dim3i dd = A.dd;
+  const int nz = dd.z;
+  constexpr int ZP = 4 * kWave;
+  float4 *ztab = reinterpret_cast<float4 *>(smem);  // per output z: {x-space offset, w0, w1, -}
+  float *kzs = smem + 4 * ZP;
+  float *buf = kzs + kAlignedMaxTaps + w * 2 * A.wave_floats;  // two line buffers per wave
+  float *pl[2] = {buf + A.padl, buf + A.wave_floats + A.padl};
+  float *xs[2] = {pl[0] + nz + A.padr, pl[1] + nz + A.padr};
+  if (w == 0 && lane < kAlignedMaxTaps) kzs[lane] = A.kz[lane];
+  for (int i = lane; i < 2 * A.wave_floats; i += kWave) buf[i] = 0.f;  // aprons stay zero
+  __syncthreads();
+  for (int z = w * kWave + (int)lane; z < ZP; z += kBlock) {
+    const int uz = z - A.oz;
+    float w0 = 0.f, w1 = 0.f;
+    int koff = 0;
+    if (uz >= 0 && uz < A.gz && z < nz) {
+      int klo, khi;
+      up_range(uz, A.nk, A.s, A.xdz, klo, khi);
+      const int n = khi - klo + 1;
+      if (n >= 1) w0 = kzs[uz - A.s * klo], koff = klo;
+      if (n >= 2) w1 = kzs[uz - A.s * (klo + 1)];
+    }
+    ztab[z] = make_float4(__int_as_float(koff), w0, w1, 0.f);
+  }
+  __syncthreads();
+  float ew0[4], ew1[4];
+  int exo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float4 tb = ztab[4 * lane + e];
+    ew0[e] = tb.y, ew1[e] = tb.z, exo[e] = __float_as_int(tb.x);
+  }
+  const float *__restrict__ p = A.p;
+  float *__restrict__ q = A.q;
+  const int hy2 = dd.y / 2, npairs = dd.x * hy2;
+  const size_t sx = (size_t)dd.y * nz, sy = nz;
+  double dot = 0.0;
+  const int lb = xcd_chunked_block(blockIdx.x, gridDim.x);
+  const int pair_step = gridDim.x * kLinesPerBlock;
+  const int z0 = 4 * (int)lane;
+  const bool in = z0 < nz;
+  const int zc = in ? z0 : 0;
+  const af4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int pr = lb * kLinesPerBlock + w; pr < npairs; pr += pair_step) {
+    const int vx = pr / hy2, vy0 = 2 * (pr - vx * hy2);
+    const size_t base = ((size_t)vx * dd.y + vy0) * nz;
+    const bool hx = vx + 1 < dd.x, lx = vx > 0, ly = vy0 > 0, hy = vy0 + 2 < dd.y;
+    const float *pc = p + base + zc;
+    af4 rc[2], rxp[2], rxm[2], ryo[2], rb[2];  // ryo: line 0's y - 1, line 1's y + 1 (the other y neighbour is the partner)
+    rc[0] = *reinterpret_cast<const af4 *>(pc), rc[1] = *reinterpret_cast<const af4 *>(pc + sy);
+    ryo[0] = *reinterpret_cast<const af4 *>(ly ? pc - sy : pc);
+    ryo[1] = *reinterpret_cast<const af4 *>(hy ? pc + 2 * sy : pc);
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      rxm[l] = *reinterpret_cast<const af4 *>(lx ? pc + l * sy - sx : pc);
+      rxp[l] = *reinterpret_cast<const af4 *>(hx ? pc + l * sy + sx : pc);
+      rb[l] = zero;
+      if (OBJ) rb[l] = *reinterpret_cast<const af4 *>(A.objb + base + l * sy + zc);
+    }
+    if (!in) rc[0] = zero, rc[1] = zero;
+    const int ux = vx - A.ox, uy0 = vy0 - A.oy;
+    const bool hasx = ux >= 0 && ux < A.gx;
+    const bool has[2] = {hasx && uy0 >= 0 && uy0 < A.gy, hasx && uy0 + 1 >= 0 && uy0 + 1 < A.gy};
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+      if (has[l] && in) *reinterpret_cast<af4 *>(pl[l] + z0) = rc[l];
+    asm volatile("" ::: "memory");  // single wave: LDS ops execute in order
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      if (!has[l]) continue;
+      for (int k0 = 0; k0 < A.xdz; k0 += kWave) {
+        const int k = k0 + (int)lane;
+        if (k < A.xdz) {
+          const float *bin = pl[l] + (k * A.s + A.oz);
+          float acc = 0.f;
+          for (int t = 0; t < A.nk; ++t) acc = fmaf(kzs[t], bin[t], acc);
+          xs[l][k] = acc * ((k & 1) ? A.so2 : A.se2);
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+    af4 out[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      float zlo = a4_lower(rc[l].w), zhi = a4_upper(rc[l].x);
+      zlo = lane == 0 ? rc[l].x : zlo;  // the line's first voxel has no backward term
+      const float c4[4] = {rc[l].x, rc[l].y, rc[l].z, rc[l].w};
+      const float zm4[4] = {zlo, rc[l].x, rc[l].y, rc[l].z}, zp4[4] = {rc[l].y, rc[l].z, rc[l].w, zhi};
+      const float xp4[4] = {rxp[l].x, rxp[l].y, rxp[l].z, rxp[l].w}, xm4[4] = {rxm[l].x, rxm[l].y, rxm[l].z, rxm[l].w};
+      const af4 ym = l == 0 ? ryo[0] : rc[0], yp = l == 0 ? rc[1] : ryo[1];
+      const float yp4[4] = {yp.x, yp.y, yp.z, yp.w}, ym4[4] = {ym.x, ym.y, ym.z, ym.w};
+      const bool lyl = l == 0 ? ly : true, hyl = l == 0 ? true : hy;
+      float o4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float c = c4[e];
+        float h = 0.f;
+        if (has[l]) h = ew0[e] * xs[l][exo[e]] + ew1[e] * xs[l][exo[e] + 1];
+        const float xf = (hx ? xp4[e] : 0.f) - c, xb = lx ? c - xm4[e] : 0.f;
+        const float yf = (hyl ? yp4[e] : 0.f) - c, yb = lyl ? c - ym4[e] : 0.f;
+        const float zf = zp4[e] - c, zb = c - zm4[e];
+        o4[e] = A.tau * h + A.a0 * c + (A.cx * (xb - xf) + A.cy * (yb - yf) + A.cz * (zb - zf));
+      }
+      out[l] = af4{o4[0], o4[1], o4[2], o4[3]};
+    }
+    asm volatile("" ::: "memory");  // the line buffers are reused by the next pair
+    if (in) {
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        if (OBJ) {
+          dot += (double)obj_term(out[l].x, rb[l].x, rc[l].x) + (double)obj_term(out[l].y, rb[l].y, rc[l].y) +
+                 (double)obj_term(out[l].z, rb[l].z, rc[l].z) + (double)obj_term(out[l].w, rb[l].w, rc[l].w);
+        } else {
+          __builtin_nontemporal_store(out[l], reinterpret_cast<af4 *>(q + base + l * sy + z0));
+          if (DOT)
+            dot += (double)__fmul_rn(rc[l].x, out[l].x) + (double)__fmul_rn(rc[l].y, out[l].y) +
+                   (double)__fmul_rn(rc[l].z, out[l].z) + (double)__fmul_rn(rc[l].w, out[l].w);
+        }
+      }
+    }
+  }
+  if (DOT) {
+    const double tot = block_sum(dot);
+    if (threadIdx.x == 0 && threadIdx.y == 0) A.partials[blockIdx.x] = tot;
+  }
+}
+
 int aligned_blocks(Dim3i dd) {
   const long long nb = ((long long)dd.x * dd.y + kLinesPerBlock - 1) / kLinesPerBlock;
   // 4096 workgroups = 4 lines per wave: amortises the per-wave set-up (table, LDS aprons) and
@@ -454,6 +593,17 @@ static void launch_lines(AlignedArgs &G, int npt, size_t lds, const int *done, h
     V.wave_floats = (V.padl + dd.z + G.padr + G.xdz + 1 + 3) & ~3;
     const size_t lds4 = ((size_t)4 * np4 * 4 * kWave + kAlignedMaxTaps + (size_t)kLinesPerBlock * V.wave_floats) *
                         sizeof(float);
+    static const bool no_x2 = getenv("UNIRES_ALIGNED_X2") && getenv("UNIRES_ALIGNED_X2")[0] == '0';
+    const size_t lds42 = ((size_t)4 * 4 * kWave + kAlignedMaxTaps + (size_t)2 * kLinesPerBlock * V.wave_floats) * sizeof(float);
+    if (!no_x2 && np4 == 1 && dd.y % 2 == 0 && lds42 <= 64 * 1024) {
+      if (objb)
+        hipLaunchKernelGGL((k_ata_aligned4x2<true, true>), grid, block, lds42, st, V, done);
+      else if (partials)
+        hipLaunchKernelGGL((k_ata_aligned4x2<true, false>), grid, block, lds42, st, V, done);
+      else
+        hipLaunchKernelGGL((k_ata_aligned4x2<false, false>), grid, block, lds42, st, V, done);
+      return;
+    }
     if (lds4 <= 64 * 1024) {
 #define LAUNCH_ALIGNED4(NPV)                                                                    \
   do {                                                                                          \

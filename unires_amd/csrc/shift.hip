@@ -168,6 +168,132 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift(ShiftArgs A, const int *__
   }
 }
 
+// Two y-adjacent lines per trip (ny even): twelve loads serve two lines instead of eighteen, twice the
+// bytes in flight per wave, one store drain per pair (see k_ata_aligned4x2).
+template <bool DOT, bool OBJ>
+__global__ void __launch_bounds__(kBlock) k_ata_shift2(ShiftArgs A, const int *__restrict__ done) {
+  if (done && *done) return;
+  extern __shared__ __align__(16) float smem[];
+  const unsigned lane = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const Dim3i dd = A.dd;
+  const int nz = dd.z;
+  float *fl = smem;
+  float *buf = smem + A.xdz * kShiftMaxTaps + w * 2 * A.wave_floats;
+  for (int i = threadIdx.y * kWave + lane; i < A.xdz * kShiftMaxTaps; i += kBlock) fl[i] = A.f[i];
+  float *pl[2] = {buf + A.padl, buf + A.wave_floats + A.padl};
+  float *xs[2] = {pl[0] + nz + A.padr, pl[1] + nz + A.padr};
+  for (int i = lane; i < 2 * A.wave_floats; i += kWave) buf[i] = 0.f;
+  __syncthreads();
+  float e0[4], e1[4], e2[4];
+  int kb[4];
+  const int z0 = 4 * (int)lane;
+  const bool in = z0 < nz;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float4 t = A.e[in ? z0 + e : 0];
+    kb[e] = __float_as_int(t.x), e0[e] = in ? t.y : 0.f, e1[e] = in ? t.z : 0.f, e2[e] = in ? t.w : 0.f;
+  }
+  const float *__restrict__ p = A.p;
+  float *__restrict__ q = A.q;
+  const int hy2 = dd.y / 2, npairs = dd.x * hy2;
+  const size_t sxl = (size_t)dd.y * nz, syl = nz;
+  double dot = 0.0;
+  const int lb = xcd_chunked_block(blockIdx.x, gridDim.x);
+  const int pair_step = gridDim.x * kShiftLines;
+  const int zc = in ? z0 : 0;
+  const sf4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int pr = lb * kShiftLines + w; pr < npairs; pr += pair_step) {
+    const int vx = pr / hy2, vy0 = 2 * (pr - vx * hy2);
+    const size_t base = ((size_t)vx * dd.y + vy0) * nz;
+    const bool hx = vx + 1 < dd.x, lx = vx > 0, ly = vy0 > 0, hy = vy0 + 2 < dd.y;
+    const float *pc = p + base + zc;
+    const long long ox[3] = {lx ? -(long long)sxl : 0, 0, hx ? (long long)sxl : 0};
+    // four rows of y: vy0 - 1, vy0, vy0 + 1, vy0 + 2 (missing ones read line vy0; their coefficients are 0)
+    const long long oy[4] = {ly ? -(long long)syl : 0, 0, (long long)syl, hy ? 2 * (long long)syl : 0};
+    sf4 v[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v[a][b] = *reinterpret_cast<const sf4 *>(pc + ox[a] + oy[b]);
+    sf4 rb[2] = {zero, zero};
+    if (OBJ) {
+      rb[0] = *reinterpret_cast<const sf4 *>(A.objb + base + zc);
+      rb[1] = *reinterpret_cast<const sf4 *>(A.objb + base + syl + zc);
+    }
+    const float4 cxv = *reinterpret_cast<const float4 *>(A.cx + 4 * vx);
+    const float4 cy0 = *reinterpret_cast<const float4 *>(A.cy + 4 * vy0);
+    const float4 cy1 = *reinterpret_cast<const float4 *>(A.cy + 4 * (vy0 + 1));
+    const float cxa[3] = {cxv.x, cxv.y, cxv.z};
+    sf4 B[2] = {zero, zero};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      B[0] += cxa[a] * (cy0.x * v[a][0] + cy0.y * v[a][1] + cy0.z * v[a][2]);
+      B[1] += cxa[a] * (cy1.x * v[a][1] + cy1.y * v[a][2] + cy1.z * v[a][3]);
+    }
+    sf4 rc[2] = {v[1][1], v[1][2]};
+    if (!in) rc[0] = rc[1] = B[0] = B[1] = zero;
+    if (in) *reinterpret_cast<sf4 *>(pl[0] + z0) = B[0], *reinterpret_cast<sf4 *>(pl[1] + z0) = B[1];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+      for (int k0 = 0; k0 < A.xdz; k0 += kWave) {
+        const int k = k0 + (int)lane;
+        if (k < A.xdz) {
+          const float *bin = pl[l] + (k * A.s + A.oz);
+          const float *fk = fl + k * kShiftMaxTaps;
+          float acc = 0.f;
+          for (int t = 0; t < A.nf; ++t) acc = fmaf(fk[t], bin[t], acc);
+          xs[l][k] = acc;
+        }
+      }
+    asm volatile("" ::: "memory");
+    sf4 out[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      float zlo = s4_lower(rc[l].w), zhi = s4_upper(rc[l].x);
+      zlo = lane == 0 ? rc[l].x : zlo;
+      const float c4[4] = {rc[l].x, rc[l].y, rc[l].z, rc[l].w};
+      const float zm4[4] = {zlo, rc[l].x, rc[l].y, rc[l].z}, zp4[4] = {rc[l].y, rc[l].z, rc[l].w, zhi};
+      const sf4 xp = v[2][1 + l], xm = v[0][1 + l], yp = v[1][2 + l], ym = v[1][l];
+      const float xp4[4] = {xp.x, xp.y, xp.z, xp.w}, xm4[4] = {xm.x, xm.y, xm.z, xm.w};
+      const float yp4[4] = {yp.x, yp.y, yp.z, yp.w}, ym4[4] = {ym.x, ym.y, ym.z, ym.w};
+      const bool lyl = l == 0 ? ly : true, hyl = l == 0 ? true : hy;
+      float o4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float c = c4[e];
+        const float *xo = xs[l] + kb[e];
+        const float h = e0[e] * xo[0] + e1[e] * xo[1] + e2[e] * xo[2];
+        const float xf = (hx ? xp4[e] : 0.f) - c, xb = lx ? c - xm4[e] : 0.f;
+        const float yf = (hyl ? yp4[e] : 0.f) - c, yb = lyl ? c - ym4[e] : 0.f;
+        const float zf = zp4[e] - c, zb = c - zm4[e];
+        o4[e] = A.tau * h + A.a0 * c + (A.sx * (xb - xf) + A.sy * (yb - yf) + A.sz * (zb - zf));
+      }
+      out[l] = sf4{o4[0], o4[1], o4[2], o4[3]};
+    }
+    asm volatile("" ::: "memory");
+    if (in) {
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        if (OBJ) {
+          dot += (double)obj_term(out[l].x, rb[l].x, rc[l].x) + (double)obj_term(out[l].y, rb[l].y, rc[l].y) +
+                 (double)obj_term(out[l].z, rb[l].z, rc[l].z) + (double)obj_term(out[l].w, rb[l].w, rc[l].w);
+        } else {
+          __builtin_nontemporal_store(out[l], reinterpret_cast<sf4 *>(q + base + l * syl + z0));
+          if (DOT)
+            dot += (double)__fmul_rn(rc[l].x, out[l].x) + (double)__fmul_rn(rc[l].y, out[l].y) +
+                   (double)__fmul_rn(rc[l].z, out[l].z) + (double)__fmul_rn(rc[l].w, out[l].w);
+        }
+      }
+    }
+  }
+  if (DOT) {
+    const double tot = block_sum(dot);
+    if (threadIdx.x == 0 && threadIdx.y == 0) A.partials[blockIdx.x] = tot;
+  }
+}
+
 // --------------------------------------------------------------------------
 // host: the three factors of AtA
 // --------------------------------------------------------------------------
@@ -335,6 +461,17 @@ int launch_ata_shift(const ShiftPlan &S, const float *p, float *q, Dim3i dd, con
   G.padl = S.padl, G.padr = S.padr, G.wave_floats = S.wave_floats;
   const size_t lds = ((size_t)S.xdz * kShiftMaxTaps + (size_t)kShiftLines * S.wave_floats) * sizeof(float);
   const dim3 grid(shift_blocks(dd)), block(kWave, kShiftLines);
+  static const bool no_x2 = getenv("UNIRES_SHIFT_X2") && getenv("UNIRES_SHIFT_X2")[0] == '0';
+  const size_t lds2 = ((size_t)S.xdz * kShiftMaxTaps + (size_t)2 * kShiftLines * S.wave_floats) * sizeof(float);
+  if (!no_x2 && dd.y % 2 == 0 && lds2 <= 64 * 1024) {
+    if (objb)
+      hipLaunchKernelGGL((k_ata_shift2<true, true>), grid, block, lds2, st, G, done);
+    else if (partials)
+      hipLaunchKernelGGL((k_ata_shift2<true, false>), grid, block, lds2, st, G, done);
+    else
+      hipLaunchKernelGGL((k_ata_shift2<false, false>), grid, block, lds2, st, G, done);
+    return 0;
+  }
   if (objb)
     hipLaunchKernelGGL((k_ata_shift<true, true>), grid, block, lds, st, G, done);
   else if (partials)
