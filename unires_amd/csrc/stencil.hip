@@ -19,6 +19,8 @@
 //     integers, no integer division.
 // The stencil is evaluated in difference form ((c - lower) - (upper - c), zero bound above, no
 // backward term on the first plane), like dtd_at() of the other kernels.
+#include <stdlib.h>
+
 #include "stencil.hpp"
 
 namespace unires {
@@ -40,9 +42,14 @@ struct FlatArgs {
   unsigned nvec;    // whole vectors after the head
   unsigned nchunk;  // ceil(nvec * 4 / kFlatChunk)
   float a0, cx, cy, cz;
+  // chunk ranges of the XCDs, composed on the host (no division in the kernel's prologue): XCD x walks
+  // chunks cb[x] .. cb[x + 1] with its G / nx (+ 1 for x < rem) workgroups; nx = 8, or 1 for tiny grids
+  unsigned nx, per_xcd, rem, cb[9];
 };
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+constexpr int kAuxNt = 2;  // cache-policy bit of the buffer instructions: non-temporal (q is not read again soon)
 
 __device__ __forceinline__ f4 ld4_fast(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
@@ -85,7 +92,7 @@ struct FlatVec {
 
 template <bool XY, bool DOT, bool OBJ>
 __device__ __forceinline__ void flat_vec(const FlatArgs &A, const FlatVec &L, unsigned lane, unsigned idx0,
-                                         unsigned k0, unsigned j0, bool valid, float *__restrict__ q,
+                                         unsigned k0, unsigned j0, bool valid, __amdgpu_buffer_rsrc_t rq,
                                          double &dot) {
   const unsigned nz = A.nz, ny = A.ny;
   float zlo = dpp_from_lower_lane(L.cc.w), zhi = dpp_from_upper_lane(L.cc.x);
@@ -123,7 +130,8 @@ __device__ __forceinline__ void flat_vec(const FlatArgs &A, const FlatVec &L, un
         dot += (double)__fmul_rn(ce, o);
     }
   }
-  if (!OBJ && valid) __builtin_nontemporal_store(f4{out[0], out[1], out[2], out[3]}, reinterpret_cast<f4 *>(q + idx0));
+  if (!OBJ && valid)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, f4{out[0], out[1], out[2], out[3]}), rq, 4u * idx0, 0, kAuxNt);
 }
 
 template <bool DOT, bool OBJ>
@@ -134,15 +142,13 @@ __global__ void __launch_bounds__(kBlock) k_dtd_flat(FlatArgs A, const int *__re
   const __amdgpu_buffer_rsrc_t rp = make_rsrc(A.p, (size_t)n * 4);
   const __amdgpu_buffer_rsrc_t rb = make_rsrc(OBJ ? A.objb : A.p, (size_t)n * 4);
   float *__restrict__ q = A.q;
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(A.q, (size_t)n * 4);
   double dot = 0.0;
   // every XCD (workgroup b sits on XCD b % 8) walks one contiguous range of chunks: the x / y halo
   // lines of a chunk are then in that XCD's L2 already, or will be used from it next
-  const unsigned G = gridDim.x, nx = G < 8u ? G : 8u;
-  const unsigned xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
-  const unsigned cnt = (G - xcd + nx - 1u) / nx;                 // workgroups of this XCD
-  const unsigned before = xcd * (G / nx) + (xcd < G % nx ? xcd : G % nx);  // workgroups of the XCDs below
-  const unsigned c_lo = (unsigned)((unsigned long long)A.nchunk * before / G),
-                 c_hi = (unsigned)((unsigned long long)A.nchunk * (before + cnt) / G);
+  const unsigned xcd = A.nx == 8u ? blockIdx.x & 7u : 0u, slot = A.nx == 8u ? blockIdx.x >> 3 : blockIdx.x;
+  const unsigned cnt = A.per_xcd + (xcd < A.rem ? 1u : 0u);      // workgroups of this XCD
+  const unsigned c_lo = A.cb[xcd], c_hi = A.cb[xcd + 1u];
   for (unsigned c = c_lo + slot; c < c_hi; c += cnt) {
     const unsigned e0 = A.head + c * (unsigned)kFlatChunk;       // first voxel of the chunk (wave-uniform)
     const unsigned line0 = e0 / nz, kb = e0 - line0 * nz, jb = line0 % ny;
@@ -162,14 +168,15 @@ __global__ void __launch_bounds__(kBlock) k_dtd_flat(FlatArgs A, const int *__re
         L[v].xm = ld4_fast(rp, bo - 4u * nynz), L[v].xp = ld4_fast(rp, bo + 4u * nynz);
         L[v].ob = f4{0.f, 0.f, 0.f, 0.f};
         if (OBJ) L[v].ob = ld4_fast(rb, bo);
-        L[v].edge = 0.f;
-        if (lane == 0u || lane == (unsigned)kWave - 1u) L[v].edge = buf_load(rp, lane == 0u ? bo - 4u : bo + 16u, 0);
+        // the voxel below lane 0's first / above lane 63's last; issued by every lane, after the vectors
+        // (a load under a lane mask in front of them made the compiler drain it before the other four)
+        L[v].edge = buf_load(rp, lane == (unsigned)kWave - 1u ? bo + 16u : bo - 4u, 0);
         const unsigned u = kb + 4u * t;
         k0[v] = u - __umul24(div_small(u, nz, A.inv_nz), nz);
       }
 #pragma unroll
       for (int v = 0; v < kFlatVecs; ++v)
-        flat_vec<false, DOT, OBJ>(A, L[v], lane, e0 + 4u * ((unsigned)v * kBlock + tid), k0[v], 1u, true, q, dot);
+        flat_vec<false, DOT, OBJ>(A, L[v], lane, e0 + 4u * ((unsigned)v * kBlock + tid), k0[v], 1u, true, rq, dot);
       continue;
     }
 #pragma unroll
@@ -201,7 +208,7 @@ __global__ void __launch_bounds__(kBlock) k_dtd_flat(FlatArgs A, const int *__re
         const int ie = lane == 0u ? (int)idx0 - 1 : (int)idx0 + 4;
         L.edge = buf_load(rp, (ie >= 0 && ie < (int)n) ? 4u * (unsigned)ie : 0x80000000u, 0);
       }
-      flat_vec<true, DOT, OBJ>(A, L, lane, idx0, k0, j0, valid, q, dot);
+      flat_vec<true, DOT, OBJ>(A, L, lane, idx0, k0, j0, valid, rq, dot);
     }
   }
   // the few voxels in front of the first and behind the last vector
@@ -223,8 +230,12 @@ __global__ void __launch_bounds__(kBlock) k_dtd_flat(FlatArgs A, const int *__re
 }
 
 static int flat_grid(unsigned nchunk) {
-  const unsigned cap = 4096;  // (kMaxPartials = 8192 partial sums at most)
-  return (int)(nchunk < cap ? (nchunk < 1 ? 1 : nchunk) : cap);
+  // every workgroup the same number of chunks (a grid capped at 4096 gave 356 of an XCD's 512
+  // workgroups two chunks and the others one); UNIRES_FLAT_BLOCKS overrides the cap (<= kMaxPartials)
+  static const unsigned cap = getenv("UNIRES_FLAT_BLOCKS") ? (unsigned)atoi(getenv("UNIRES_FLAT_BLOCKS")) : 4096u;
+  if (nchunk < 1) return 1;
+  const unsigned per = (nchunk + cap - 1) / cap;
+  return (int)((nchunk + per - 1) / per);
 }
 
 int dtd_flat_blocks(Dim3i dd) {
@@ -246,9 +257,15 @@ int launch_dtd_flat(const float *p, float *q, Dim3i dd, float a0, float cx, floa
   A.nvec = (A.n - A.head) / 4u;
   A.nchunk = (A.nvec * 4u + kFlatChunk - 1u) / (unsigned)kFlatChunk;
   A.a0 = a0, A.cx = cx, A.cy = cy, A.cz = cz;
+  const unsigned G = (unsigned)dtd_flat_blocks(dd);
+  A.nx = G >= 8u ? 8u : 1u, A.per_xcd = G / A.nx, A.rem = G % A.nx;
+  for (unsigned x = 0, before = 0; x <= A.nx; ++x) {
+    A.cb[x] = (unsigned)((unsigned long long)A.nchunk * before / G);
+    before += A.per_xcd + (x < A.rem ? 1u : 0u);
+  }
   // the number of partials must not depend on q's alignment: callers size their reduction with
   // dtd_flat_blocks(dd)
-  const dim3 grid(dtd_flat_blocks(dd)), block(kBlock);
+  const dim3 grid(G), block(kBlock);
   if (objb)
     hipLaunchKernelGGL((k_dtd_flat<true, true>), grid, block, 0, st, A, done);
   else if (partials)
