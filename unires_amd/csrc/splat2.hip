@@ -25,6 +25,9 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 namespace unires {
@@ -543,19 +546,20 @@ struct S2Args {
   int dbg;  // UNIRES_S2_DBG ablation bits (read only by -DUNIRES_ABLATE builds)
   int prio_rot;  // rotate the waves' issue priority per tile (UNIRES_S2_PRIO=0 switches it off)
   int xlo[9];  // tile range [xlo[x], xlo[x + 1]) of partition x (an XCD when the grid has >= 8 workgroups)
+  int active;  // workgroups that take tiles (the rest of the grid only clears its partials)
   unsigned long long *prof;  // -DUNIRES_S2_PROF builds: per-wave timeline (100 MHz ticks)
 };
 
-template <int AXIS>
-__global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int *__restrict__ done) {
+template <int AXIS, int NW>
+__global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__restrict__ done) {
   if (done && *done) return;
   using T = S2Tile;
   constexpr int TX = T::TX, TY = T::TY, L = T::L, G = kWave / L;
   constexpr int SY = T::SY, SZ = T::SZ, N = T::N, XS = T::XS, YS = T::YS;
   constexpr bool CONV = AXIS >= 0;
-  __shared__ __align__(16) float acc_all[kS2Waves][N];
-  __shared__ __align__(16) uint4 ring_all[kS2Waves][kWave];  // 2 chunks of 32 segment entries
-  __shared__ __align__(16) uint4 ring2_all[AXIS == 3 ? kS2Waves : 1][AXIS == 3 ? 2 * kWave : 1];  // their S2Ext
+  __shared__ __align__(16) float acc_all[NW][N];
+  __shared__ __align__(16) uint4 ring_all[NW][kWave];  // 2 chunks of 32 segment entries
+  __shared__ __align__(16) uint4 ring2_all[AXIS == 3 ? NW : 1][AXIS == 3 ? 2 * kWave : 1];  // their S2Ext
   extern __shared__ float4 tabs[];  // CONV: {byte offset, alpha w0, alpha w1, -}, tabn entries
   const int lane = threadIdx.x & (kWave - 1), grp = lane / L, gl = lane & (L - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -567,7 +571,7 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
   float *__restrict__ dst = P.dst;
   if (CONV) {
     const unsigned step4 = (AXIS == 2 || AXIS == 3) ? 4u : P.tab_step4;  // the per-lane table runs along z
-    for (int i = threadIdx.x; i < P.tabn; i += kWave * kS2Waves) {
+    for (int i = threadIdx.x; i < P.tabn; i += kWave * NW) {
       float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i >= 64 && i - 64 < P.gn) e = P.tab[i - 64];
       // (.w = the grid coordinate the entry belongs to, as a float: the z-profile kernels take k from
@@ -583,17 +587,26 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
   // run of tiles so that neighbouring tiles (shared stencil halos, schedule lines) share an L2.
   // (Tried and dropped: a contiguous, cost-balanced range of tiles per wave - 103 us instead of
   // 95 us: waves that sweep the run together share cache lines, waves far apart do not.)
-  const int nxcd = min(8, (int)gridDim.x);
+  // Only as many workgroups as the chip holds AT ONCE take tiles (P.active, a multiple of 8): the table
+  // above is part of the workgroup's LDS, and with 384 + 128 entries a CU holds three workgroups, not
+  // four - the fourth quarter of a 1024-workgroup grid then started when the first three were done and
+  // the kernel took twice a workgroup's time (config 4: 424 us where 16.5 M points cost 81 us in config 3).
+  if ((int)blockIdx.x >= P.active) {
+    if (P.partials && lane == 0) P.partials[blockIdx.x * NW + wave] = 0.0;
+    return;
+  }
+  const int nwg = P.active;
+  const int nxcd = min(8, nwg);
   const int xcd = blockIdx.x % nxcd;
   const int t_lo = P.xlo[xcd], t_hi = P.xlo[xcd + 1];
-  const int slot = (blockIdx.x / nxcd) * kS2Waves + wave;
-  const int slots = ((gridDim.x + nxcd - 1 - xcd) / nxcd) * kS2Waves;
+  const int slot = (blockIdx.x / nxcd) * NW + wave;
+  const int slots = ((nwg + nxcd - 1 - xcd) / nxcd) * NW;
   const float c0 = P.A.m[2], c1 = P.A.m[6], c2 = P.A.m[10];
   const float t0 = P.A.m[3], t1 = P.A.m[7], t2 = P.A.m[11];
   const int lane_m64 = lane - 64;
   double dot = 0.0;
 #ifdef UNIRES_S2_PROF
-  unsigned long long *pw = P.prof ? P.prof + (size_t)(blockIdx.x * kS2Waves + wave) * 32 : nullptr;
+  unsigned long long *pw = P.prof ? P.prof + (size_t)(blockIdx.x * NW + wave) * 32 : nullptr;
   int ptile = 0;
   if (pw && lane == 0) pw[0] = wall_clock64();
 #endif
@@ -898,11 +911,39 @@ __global__ void __launch_bounds__(kWave *kS2Waves) k_splat2(S2Args P, const int 
 #endif
   if (P.partials) {
     const double tot = wave_sum(dot);
-    if (lane == 0) P.partials[blockIdx.x * kS2Waves + wave] = tot;
+    if (lane == 0) P.partials[blockIdx.x * NW + wave] = tot;
   }
 }
 
 int splat2_blocks(Dim3i dd) { return s2_grid(dd) * kS2Waves; }  // partials written
+
+// Workgroups of k_splat2<axis> the device holds at once with `lds` bytes of table (asked of the
+// runtime once per kernel and table size), rounded down to whole rounds over the 8 XCDs.
+static int s2_active(int axis, size_t lds, int grid) {
+  static std::map<std::pair<int, size_t>, int> cache;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(axis, lds);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    int per_cu = 0, dev = 0, ncu = 0;
+    const void *fn = axis == 0   ? (const void *)k_splat2<0, kS2Waves>
+                     : axis == 1 ? (const void *)k_splat2<1, kS2Waves>
+                     : axis == 2 ? (const void *)k_splat2<2, kS2Waves>
+                     : axis == 3 ? (const void *)k_splat2<3, kS2Waves>
+                                 : (const void *)k_splat2<-1, kS2Waves>;
+    static const int force = getenv("UNIRES_SPLAT2_RESIDENT") ? atoi(getenv("UNIRES_SPLAT2_RESIDENT")) : 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave * kS2Waves, lds) != hipSuccess) per_cu = 0;
+    if (force > 0) per_cu = force;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
+    const int n = per_cu > 0 && ncu > 0 ? per_cu * ncu : 1 << 30;
+    it = cache.emplace(key, n).first;
+  }
+  int n = std::min(grid, it->second);
+  if (n >= 8) n -= n % 8;
+  return n;
+}
 
 int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const float4 *tab_dev, int gn,
                   unsigned row_stride, unsigned tab_step, unsigned xs_sy, unsigned xs_sx, const Affine &A,
@@ -943,12 +984,27 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
 #endif
   const size_t lds = S.axis >= 0 ? (size_t)P.tabn * sizeof(float4) : 0;
   if (lds > 24 * 1024) return 1;
+  P.active = s2_active(S.axis, lds, (int)grid.x);
+  // A table too long for four 4-wave workgroups per CU (each carries its own copy): ONE 16-wave
+  // workgroup per CU shares a single copy - the same 16 waves and the same wave -> tile walk.
+  static const bool wide_ok = !(getenv("UNIRES_SPLAT2_WIDE") && atoi(getenv("UNIRES_SPLAT2_WIDE")) == 0);
+  constexpr int kWide = 16, kRatio = kWide / kS2Waves;
+  if (wide_ok && P.active < (int)grid.x && S.axis >= 0 && S.axis <= 2 && grid.x % kRatio == 0 && grid.x / kRatio >= 8) {
+    const dim3 gridw(grid.x / kRatio), blockw(kWave * kWide);
+    P.active = (int)gridw.x;
+    switch (S.axis) {
+      case 0: hipLaunchKernelGGL((k_splat2<0, kWide>), gridw, blockw, lds, st, P, done); break;
+      case 1: hipLaunchKernelGGL((k_splat2<1, kWide>), gridw, blockw, lds, st, P, done); break;
+      default: hipLaunchKernelGGL((k_splat2<2, kWide>), gridw, blockw, lds, st, P, done); break;
+    }
+    return 0;
+  }
   switch (S.axis) {
-    case 0: hipLaunchKernelGGL((k_splat2<0>), grid, block, lds, st, P, done); break;
-    case 1: hipLaunchKernelGGL((k_splat2<1>), grid, block, lds, st, P, done); break;
-    case 2: hipLaunchKernelGGL((k_splat2<2>), grid, block, lds, st, P, done); break;
-    case 3: hipLaunchKernelGGL((k_splat2<3>), grid, block, lds, st, P, done); break;
-    default: hipLaunchKernelGGL((k_splat2<-1>), grid, block, lds, st, P, done); break;
+    case 0: hipLaunchKernelGGL((k_splat2<0, kS2Waves>), grid, block, lds, st, P, done); break;
+    case 1: hipLaunchKernelGGL((k_splat2<1, kS2Waves>), grid, block, lds, st, P, done); break;
+    case 2: hipLaunchKernelGGL((k_splat2<2, kS2Waves>), grid, block, lds, st, P, done); break;
+    case 3: hipLaunchKernelGGL((k_splat2<3, kS2Waves>), grid, block, lds, st, P, done); break;
+    default: hipLaunchKernelGGL((k_splat2<-1, kS2Waves>), grid, block, lds, st, P, done); break;
   }
 #ifdef UNIRES_S2_PROF
   {
