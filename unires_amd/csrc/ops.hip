@@ -366,11 +366,18 @@ __global__ void __launch_bounds__(kBlock)
     }
   }
 }
+// (r3: kUpZRows x slabs per trip - their row loads are issued together.  With one row per trip a wave
+// had ONE 256-byte load in flight: 186 us for the 384 x 384 x 192 -> 387 volume of config 4, 1.8 TB/s.)
+#ifndef UNIRES_UPZ_ROWS
+#define UNIRES_UPZ_ROWS 4
+#endif
+constexpr int kUpZRows = UNIRES_UPZ_ROWS;
 __global__ void __launch_bounds__(kBlock)
     k_conv1d_up_z(const float *__restrict__ src, Dim3i sd, Taps1 K, int n, int s, float se, float so,
                   float *__restrict__ dst, Dim3i dd) {
+  constexpr int SW = kWave + UNIRES_MAX_TAPS + 2;
   __shared__ float taps[UNIRES_MAX_TAPS];
-  __shared__ float stage[kBlock / kWave][kWave + UNIRES_MAX_TAPS + 2];
+  __shared__ float stage[kBlock / kWave][kUpZRows][SW];
   const int lane = threadIdx.x, w = threadIdx.y;
   const int tid = w * kWave + lane;
   if (tid < UNIRES_MAX_TAPS) taps[tid] = K.t[tid];
@@ -387,20 +394,39 @@ __global__ void __launch_bounds__(kBlock)
   const int nw = min(hi - lo + 1, UNIRES_MAX_TAPS / 4);
   for (int c = 0; c < UNIRES_MAX_TAPS / 4; ++c)
     wgt[c] = c < nw ? taps[u - s * (lo + c)] * (((lo + c) & 1) ? so : se) : 0.f;
-  for (int i = blockIdx.z; i < dd.x; i += gridDim.z) {  // several x slabs per workgroup
-    const float *row = src + ((size_t)i * sd.y + j) * sd.z;
-    asm volatile("" ::: "memory");
-    for (int t = lane; t <= c1 - c0; t += kWave) stage[w][t] = row[c0 + t];
-    asm volatile("" ::: "memory");
-    if (u < dd.z) {
-      float acc = 0.f;
+  const int span = c1 - c0 + 1;  // <= kWave + taps: at most two loads per lane and row
+  const int G = (int)gridDim.z;
+  for (int i = blockIdx.z; i < dd.x; i += kUpZRows * G) {  // several x slabs per workgroup
+    float v0[kUpZRows], v1[kUpZRows];
 #pragma unroll
-      for (int c = 0; c < UNIRES_MAX_TAPS / 4; ++c)
-        if (c < nw) acc = fmaf(wgt[c], stage[w][lo - c0 + c], acc);
-      for (int c = lo + UNIRES_MAX_TAPS / 4; c <= hi; ++c)  // fan-in beyond 8: generic tail
-        acc = fmaf(taps[u - s * c] * ((c & 1) ? so : se), stage[w][c - c0], acc);
-      dst[((size_t)i * dd.y + j) * dd.z + u] = acc;
+    for (int r = 0; r < kUpZRows; ++r) {
+      const int ir = min(i + r * G, dd.x - 1);
+      const float *row = src + ((size_t)ir * sd.y + j) * sd.z + c0;
+      v0[r] = lane < span ? row[lane] : 0.f;
+      v1[r] = lane + kWave < span ? row[lane + kWave] : 0.f;
     }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < kUpZRows; ++r) {
+      stage[w][r][lane] = v0[r];
+      if (lane + kWave < SW) stage[w][r][lane + kWave] = v1[r];
+    }
+    asm volatile("" ::: "memory");  // one wave, LDS ops in order
+    if (u < dd.z) {
+#pragma unroll
+      for (int r = 0; r < kUpZRows; ++r) {
+        const int ir = i + r * G;
+        if (ir >= dd.x) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < UNIRES_MAX_TAPS / 4; ++c)
+          if (c < nw) acc = fmaf(wgt[c], stage[w][r][lo - c0 + c], acc);
+        for (int c = lo + UNIRES_MAX_TAPS / 4; c <= hi; ++c)  // fan-in beyond 8: generic tail
+          acc = fmaf(taps[u - s * c] * ((c & 1) ? so : se), stage[w][r][c - c0], acc);
+        dst[((size_t)ir * dd.y + j) * dd.z + u] = acc;
+      }
+    }
+    asm volatile("" ::: "memory");
   }
 }
 
