@@ -1,0 +1,26 @@
+"""Prints sha256 digests of A p, At v and AtA p for an isotropic 2 x down-sampling whose x-space z
+extent is a multiple of 4 (run by test_gpu_ops.py in two processes: UNIRES_CONV_XY=1 / 0 - the
+switch is read once per process)."""
+import hashlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import unires_amd as U  # noqa: E402
+from tests.helpers import rigid_matrix  # noqa: E402
+
+dev = torch.device('cuda:0')
+dim_y = (22, 18, 24)
+mat_y = torch.eye(4, dtype=torch.float64)
+mat_x = mat_y @ torch.diag(torch.tensor([2.0, 2.0, 2.0, 1.0], dtype=torch.float64))
+dim_x = tuple(d // 2 for d in dim_y)
+rigid = rigid_matrix([0.4, -0.3, 0.2], [0.03, -0.02, 0.04])
+po = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, device=dev, scl=float(sys.argv[1]) if len(sys.argv) > 1 else 0.0)
+torch.manual_seed(3)
+p = (torch.rand(dim_y) + 0.5).to(dev)
+v = (torch.rand(dim_x) + 0.5).to(dev)
+for op, arg in (('A', p), ('At', v), ('AtA', p)):
+    out = U._proj_apply(op, arg[None, None], po, method='super-resolution')[0, 0]
+    print(op, hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest())

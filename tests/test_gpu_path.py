@@ -27,6 +27,9 @@ CASES = {
     'sr_iso2_scl_x': dict(dim_y=(16, 14, 12), n_channels=1, thick=2, regime='sr', iso=True, scl=0.1),
     'sr_223_scl_z': dict(dim_y=(14, 12, 18), n_channels=2, thick=3, regime='sr', iso=(2, 2, 3), scl=0.1,
                          n_repeats=2),
+    # x-space z extent a multiple of 4: the 16-byte 1-D passes, and the fused x-y pass of the hybrid path
+    'sr_iso2_z8': dict(dim_y=(18, 14, 16), n_channels=2, thick=2, regime='sr', iso=True, scl=0.1),
+    'sr_iso3_z8': dict(dim_y=(15, 18, 24), n_channels=1, thick=3, regime='sr', iso=True, rot=0.02),
     'sr_aligned': dict(dim_y=(16, 14, 24), n_channels=2, thick=3, regime='sr', thick_axes=[2, 2], rot=0.0,
                        trans=0.0, scl=0.1),
     # translated by a fraction of a voxel, not rotated: the factorised one-kernel matvec (shift.hip); nz % 4 == 0

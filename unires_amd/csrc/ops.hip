@@ -337,6 +337,146 @@ __global__ void __launch_bounds__(kBlock)
     dst[((size_t)i * dd.y + j) * z4 + k] = acc;
   }
 }
+// The x and y passes of conv_down / conv_up as ONE kernel (r3): the separable passes of an isotropic
+// down-sampling (config 4: 3 taps, stride 2 along x and y) write and re-read a scratch volume between
+// them - 113 + 57 + 57 + 28 MB for what needs 113 + 28.  Here a lane forms the intermediate values of
+// its output in registers.  Same products, same order (y chain, scaling, then x chain for conv_down;
+// x chain then y chain for conv_up), so the results are bit-identical to the two passes.
+struct Taps2 {
+  float x[8], y[8];
+};
+constexpr int kConvXYMax = 8;  // taps (conv_down) / fan-in (conv_up) per axis the fused forms take
+__global__ void __launch_bounds__(kBlock)
+    k_conv2d_down_xy_v4(const float4 *__restrict__ src, Dim3i sd, Taps2 K, int nx, int sx, int ny, int sy,
+                        float sex, float sox, float sey, float soy, float4 *__restrict__ dst, Dim3i dd,
+                        const int *__restrict__ done) {
+  if (done && *done) return;
+  // (threads run over the flattened (y, z / 4) plane of an x slab: rows of 192 voxels are 48 float4 -
+  // a 64-lane row per z line left a quarter of the lanes idle)
+  const int z4 = dd.z >> 2;
+  const unsigned t = blockIdx.x * (unsigned)kBlock + threadIdx.y * kWave + threadIdx.x;
+  if (t >= (unsigned)dd.y * (unsigned)z4) return;
+  const int j = (int)(t / (unsigned)z4), k = (int)(t - (unsigned)j * (unsigned)z4);
+  const size_t sstr_x = (size_t)sd.y * z4, sstr_y = (size_t)z4;
+  const float scy = (j & 1) ? soy : sey;
+  for (int i = blockIdx.y; i < dd.x; i += gridDim.y) {
+    const float4 *base = src + ((size_t)(sx * i) * sd.y + (size_t)sy * j) * z4 + k;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ta = 0; ta < nx; ++ta) {
+      const float4 *row = base + (size_t)ta * sstr_x;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      int tb = 0;
+      for (; tb + 4 <= ny; tb += 4) {
+        const float4 v0 = row[(size_t)tb * sstr_y], v1 = row[(size_t)(tb + 1) * sstr_y],
+                     v2 = row[(size_t)(tb + 2) * sstr_y], v3 = row[(size_t)(tb + 3) * sstr_y];
+        t = fma4(K.y[tb], v0, t), t = fma4(K.y[tb + 1], v1, t);
+        t = fma4(K.y[tb + 2], v2, t), t = fma4(K.y[tb + 3], v3, t);
+      }
+      for (; tb < ny; ++tb) t = fma4(K.y[tb], row[(size_t)tb * sstr_y], t);
+      t = make_float4(t.x * scy, t.y * scy, t.z * scy, t.w * scy);
+      acc = fma4(K.x[ta], t, acc);
+    }
+    const float sc = (i & 1) ? sox : sex;
+    dst[((size_t)i * dd.y + j) * z4 + k] = make_float4(acc.x * sc, acc.y * sc, acc.z * sc, acc.w * sc);
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+    k_conv2d_up_xy_v4(const float4 *__restrict__ src, Dim3i sd, Taps1 KX, Taps1 KY, int nx, int sx, int ny,
+                      int sy, float sex, float sox, float sey, float soy, float4 *__restrict__ dst, Dim3i dd) {
+  __shared__ float tx[UNIRES_MAX_TAPS], ty[UNIRES_MAX_TAPS];
+  const int tid = threadIdx.y * kWave + threadIdx.x;
+  if (tid < UNIRES_MAX_TAPS) tx[tid] = KX.t[tid], ty[tid] = KY.t[tid];
+  __syncthreads();
+  const int z4 = dd.z >> 2;
+  const unsigned t = blockIdx.x * (unsigned)kBlock + threadIdx.y * kWave + threadIdx.x;
+  if (t >= (unsigned)dd.y * (unsigned)z4) return;
+  const int j = (int)(t / (unsigned)z4), k = (int)(t - (unsigned)j * (unsigned)z4);
+  const size_t sstr_x = (size_t)sd.y * z4;
+  int lo_y, hi_y;
+  up_range_f(j, ny, sy, 1.f / (float)sy, sd.y, lo_y, hi_y);
+  float wy[kConvXYMax];
+#pragma unroll
+  for (int c = 0; c < kConvXYMax; ++c)
+    wy[c] = lo_y + c <= hi_y ? ty[j - sy * (lo_y + c)] * (((lo_y + c) & 1) ? soy : sey) : 0.f;
+  const float inv_sx = 1.f / (float)sx;
+  for (int i = blockIdx.y; i < dd.x; i += gridDim.y) {
+    int lo, hi;
+    up_range_f(i, nx, sx, inv_sx, sd.x, lo, hi);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int cy = 0; cy < kConvXYMax; ++cy) {
+      if (lo_y + cy > hi_y) break;
+      const float4 *col = src + ((size_t)lo * sd.y + (size_t)(lo_y + cy)) * z4 + k;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int c = lo; c <= hi; ++c, col += sstr_x) t = fma4(tx[i - sx * c] * ((c & 1) ? sox : sex), *col, t);
+      acc = fma4(wy[cy], t, acc);
+    }
+    dst[((size_t)i * dd.y + j) * z4 + k] = acc;
+  }
+}
+// Same, for fan-ins <= FX x FY known at compile time, R consecutive x slabs per thread: every load of
+// the R outputs is issued before the first product (the run-time form above has one short dependent
+// chain per thread - 27 648 workgroups that live 3.4 us each at 384 x 384 x 192: 46 us, 3 TB/s).
+// Taps beyond a voxel's range are skipped, not multiplied by zero: bit-identical to the two passes.
+template <int FX, int FY, int R>
+__global__ void __launch_bounds__(kBlock)
+    k_conv2d_up_xy_v4_t(const float4 *__restrict__ src, Dim3i sd, Taps1 KX, Taps1 KY, int nx, int sx, int ny,
+                        int sy, float sex, float sox, float sey, float soy, float4 *__restrict__ dst, Dim3i dd) {
+  __shared__ float tx[UNIRES_MAX_TAPS], ty[UNIRES_MAX_TAPS];
+  const int tid = threadIdx.y * kWave + threadIdx.x;
+  if (tid < UNIRES_MAX_TAPS) tx[tid] = KX.t[tid], ty[tid] = KY.t[tid];
+  __syncthreads();
+  const int z4 = dd.z >> 2;
+  const unsigned t = blockIdx.x * (unsigned)kBlock + (unsigned)tid;
+  if (t >= (unsigned)dd.y * (unsigned)z4) return;
+  const int j = (int)(t / (unsigned)z4), k = (int)(t - (unsigned)j * (unsigned)z4);
+  int lo_y, hi_y;
+  up_range_f(j, ny, sy, 1.f / (float)sy, sd.y, lo_y, hi_y);
+  float wy[FY];
+  unsigned rowy[FY];  // float4 offset of source row lo_y + cy (clamped into the range) at this lane's k
+#pragma unroll
+  for (int c = 0; c < FY; ++c) {
+    const int cy = min(lo_y + c, hi_y);
+    wy[c] = ty[j - sy * cy] * ((cy & 1) ? soy : sey);
+    rowy[c] = (unsigned)cy * (unsigned)z4 + (unsigned)k;
+  }
+  const int i0 = (int)blockIdx.y * R;
+  const float inv_sx = 1.f / (float)sx;
+  const unsigned sstr_x = (unsigned)sd.y * (unsigned)z4;  // (source volumes < 2^32 float4: checked by the launcher)
+  float4 v[R][FY][FX];
+  float wx[R][FX];
+  int nxr[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = min(i0 + r, dd.x - 1);
+    int lo, hi;
+    up_range_f(i, nx, sx, inv_sx, sd.x, lo, hi);
+    nxr[r] = hi - lo + 1;
+#pragma unroll
+    for (int cx = 0; cx < FX; ++cx) {
+      const int c = min(lo + cx, hi);
+      wx[r][cx] = tx[i - sx * c] * ((c & 1) ? sox : sex);
+#pragma unroll
+      for (int cy = 0; cy < FY; ++cy) v[r][cy][cx] = src[(size_t)((unsigned)c * sstr_x + rowy[cy])];
+    }
+  }
+  const int nyr = hi_y - lo_y + 1;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (i0 + r >= dd.x) break;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int cy = 0; cy < FY; ++cy) {
+      if (cy >= nyr) break;
+      float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int cx = 0; cx < FX; ++cx)
+        if (cx < nxr[r]) u = fma4(wx[r][cx], v[r][cy][cx], u);
+      acc = fma4(wy[cy], u, acc);
+    }
+    dst[((size_t)(i0 + r) * dd.y + j) * z4 + k] = acc;
+  }
+}
 static inline bool conv1d_v4_ok(const void *a, const void *b, const Dim3i &sd, const Dim3i &dd) {
   return (sd.z & 3) == 0 && sd.z == dd.z && (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
 }
@@ -434,6 +574,11 @@ __global__ void __launch_bounds__(kBlock)
 static inline dim3 conv1d_grid(const Dim3i &d) {
   return dim3((d.z + kWave - 1) / kWave, (d.y + 3) / 4, d.x < 48 ? d.x : 48);
 }
+// grid of the fused x-y passes: the (y, z / 4) plane flattened along x, x slabs along y
+static inline dim3 conv2d_grid(const Dim3i &d) {
+  const unsigned plane = (unsigned)d.y * (unsigned)(d.z / 4);
+  return dim3((plane + kBlock - 1) / kBlock, d.x < 65535 ? d.x : 65535, 1);
+}
 static inline Dim3i with_axis(Dim3i d, int axis, int v) {
   if (axis == 0) d.x = v;
   if (axis == 1) d.y = v;
@@ -457,8 +602,20 @@ void launch_conv_down_sep(const float *g, Dim3i gd, const Taps &T, const Scaling
     (void)hipMemcpyAsync(dst, g, gd.numel() * sizeof(float), hipMemcpyDeviceToDevice, st);
     return;
   }
+  static const bool fuse_xy = !(getenv("UNIRES_CONV_XY") && atoi(getenv("UNIRES_CONV_XY")) == 0);
   for (int ax = 2; ax >= 0; --ax) {
     if (axis_is_dirac(T, ax) && S.dim != ax) continue;
+    if (ax == 1 && fuse_xy && todo == 2 && T.n[0] <= kConvXYMax && T.n[1] <= kConvXYMax && T.n[0] * T.n[1] <= 16 &&
+        conv1d_v4_ok(cur, dst, cd, xd)) {
+      // y and x passes in one kernel (cur is z-complete: cd.z == xd.z)
+      Taps2 K2;
+      for (int t = 0; t < 8; ++t) K2.x[t] = T.t[0][t], K2.y[t] = T.t[1][t];
+      hipLaunchKernelGGL(k_conv2d_down_xy_v4, conv2d_grid(xd), vol_block(), 0, st,
+                         (const float4 *)cur, cd, K2, T.n[0], T.s[0], T.n[1], T.s[1], S.dim == 0 ? S.e : 1.f,
+                         S.dim == 0 ? S.o : 1.f, S.dim == 1 ? S.e : 1.f, S.dim == 1 ? S.o : 1.f, (float4 *)dst, xd,
+                         done);
+      return;
+    }
     const Dim3i od = with_axis(cd, ax, axis_len(xd, ax));
     float *out = --todo == 0 ? dst : (cur == a ? b : a);
     Taps1 K;
@@ -484,8 +641,39 @@ float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scalin
   const float *cur = xs;
   Dim3i cd = xd;
   float *out = nullptr;
+  static const bool fuse_xy = !(getenv("UNIRES_CONV_XY") && atoi(getenv("UNIRES_CONV_XY")) == 0);
+  auto active = [&](int ax) { return !(axis_is_dirac(T, ax) && S.dim != ax); };
+  auto fan = [&](int ax) { return (T.n[ax] + T.s[ax] - 1) / T.s[ax]; };
   for (int ax = 0; ax < 3; ++ax) {
-    if (axis_is_dirac(T, ax) && S.dim != ax) continue;
+    if (!active(ax)) continue;
+    if (ax == 0 && fuse_xy && active(1) && fan(0) <= kConvXYMax && fan(1) <= kConvXYMax && fan(0) * fan(1) <= 16) {
+      // x and y passes in one kernel
+      const Dim3i od = Dim3i{gd.x, gd.y, cd.z};
+      float *o2 = cur == a ? b : a;
+      if (conv1d_v4_ok(cur, o2, cd, od)) {
+        Taps1 KX, KY;
+        for (int t = 0; t < UNIRES_MAX_TAPS; ++t) KX.t[t] = T.t[0][t], KY.t[t] = T.t[1][t];
+        const float sex = S.dim == 0 ? S.e : 1.f, sox = S.dim == 0 ? S.o : 1.f, sey = S.dim == 1 ? S.e : 1.f,
+                    soy = S.dim == 1 ? S.o : 1.f;
+        const bool small = cd.numel() / 4 < (1ull << 32);
+        dim3 g = conv2d_grid(od);
+        if (small && fan(0) <= 2 && fan(1) <= 2) {
+          g.y = (od.x + 3) / 4;
+          hipLaunchKernelGGL((k_conv2d_up_xy_v4_t<2, 2, 4>), g, vol_block(), 0, st, (const float4 *)cur, cd, KX, KY,
+                             T.n[0], T.s[0], T.n[1], T.s[1], sex, sox, sey, soy, (float4 *)o2, od);
+        } else if (small && fan(0) <= 3 && fan(1) <= 3) {
+          g.y = (od.x + 1) / 2;
+          hipLaunchKernelGGL((k_conv2d_up_xy_v4_t<3, 3, 2>), g, vol_block(), 0, st, (const float4 *)cur, cd, KX, KY,
+                             T.n[0], T.s[0], T.n[1], T.s[1], sex, sox, sey, soy, (float4 *)o2, od);
+        } else {
+          hipLaunchKernelGGL(k_conv2d_up_xy_v4, g, vol_block(), 0, st, (const float4 *)cur, cd, KX, KY, T.n[0],
+                             T.s[0], T.n[1], T.s[1], sex, sox, sey, soy, (float4 *)o2, od);
+        }
+        out = o2, cur = o2, cd = od;
+        ax = 1;  // (the loop continues with z)
+        continue;
+      }
+    }
     const Dim3i od = with_axis(cd, ax, axis_len(gd, ax));
     out = cur == a ? b : a;
     Taps1 K;
