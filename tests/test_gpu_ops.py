@@ -262,3 +262,32 @@ def test_fused_xy_conv_pass_is_bit_identical_to_the_two_passes(dev, scl):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.split()[0] in ('A', 'At', 'AtA')])
     assert len(outs[0]) == 3 and outs[0] == outs[1]
+
+
+@pytest.mark.parametrize('prof_ip', [0, 2])
+@pytest.mark.parametrize('rot', [(1.25, 0.0, 0.0), (0.0, 1.3, 0.2)])
+def test_isotropic_downsampling_under_large_rotations(dev, prof_ip, rot):
+    """Rotations that take the grid's z axis far from the volume's (|M22| <= 0.5): the LDS-window pull
+    is outside its domain, so the hybrid form (z profile inside pull / splat, x / y as 1-D passes) is
+    not available and the plan is rebuilt as the separable / fused forms (build_repeat_kernels).
+    Same operators as the oracle either way."""
+    import unires_amd as U
+    from oracle import unires_restated as O
+    dim_y = (20, 18, 24)
+    mat_y = torch.eye(4, dtype=torch.float64)
+    mat_x = mat_y @ torch.diag(torch.tensor([2.0, 2.0, 2.0, 1.0], dtype=torch.float64))
+    dim_x = tuple(d // 2 for d in dim_y)
+    # rotate about the volume's centre so that most of the grid stays inside the field of view
+    c = torch.eye(4, dtype=torch.float64)
+    c[:3, 3] = torch.tensor([(d - 1) / 2 for d in dim_y], dtype=torch.float64)
+    rigid = c @ rigid_matrix([0.3, -0.2, 0.1], list(rot)) @ torch.linalg.inv(c)
+    po_o = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=prof_ip, scl=0.1)
+    po_g = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=prof_ip, scl=0.1, device=dev)
+    torch.manual_seed(11)
+    p = torch.rand(dim_y) + 0.5
+    v = torch.rand(dim_x) + 0.5
+    for op, arg in (('A', p), ('At', v), ('AtA', p)):
+        ref = O.proj_apply(op, arg[None, None], po_o, method='super-resolution')[0, 0]
+        out = U._proj_apply(op, arg[None, None].to(dev), po_g, method='super-resolution')[0, 0].cpu()
+        err = float((out - ref).abs().max()) / float(ref.abs().max())
+        assert err < 1e-5, '%s differs from the oracle: %.3g' % (op, err)

@@ -266,6 +266,7 @@ struct Repeat {
   Taps Tf;
   SplatSafety safe;  // of Af (the linear part is the same for A)
   bool sep = false;  // many-tap profile: convolutions run as separable 1-D passes
+  bool sep0 = false; // ... as decided from the taps alone (the hybrid form clears `sep`; kept for its fallback)
   // profile along x and / or y AND z with a z fan-in <= 2 (isotropic down-sampling, BASELINE config
   // 4): the x / y part runs as 1-D passes through a (gf.x, gf.y, xd.z) intermediate, the z part
   // stays fused in the pull / splat kernels, which then cost what they cost for a z-only profile
@@ -377,6 +378,7 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
   out.sep = (long long)out.Tf.n[0] * out.Tf.n[1] * out.Tf.n[2] > 64;
   for (int d = 0; d < 3; ++d)
     if ((out.Tf.n[d] + out.Tf.s[d] - 1) / out.Tf.s[d] > 2) out.sep = true;
+  out.sep0 = out.sep;
   out.hyb = out.hybf = false;
   if (pl->regime == UNIRES_REGIME_SUPERRES) {
     static const bool no_hyb = getenv("UNIRES_NO_HYBRID") != nullptr;
@@ -523,6 +525,27 @@ static void build_pull(unires_plan *pl, Repeat &R) {
   (void)hipGetLastError();
 }
 
+// schedule + window plan of one repeat.  A hybrid operator (z profile inside the pull / splat kernels,
+// x / y profiles as 1-D passes) whose kernels turn out to be unavailable - window plan outside
+// pull2's domain, or no axis-2 schedule (atomics needed, table too long for LDS, a tile overflowing
+// the segment lists) - is rebuilt as what the taps alone would have chosen: the separable passes for
+// a many-tap profile (with the forward half of the hybrid where its window plan exists), not the dense
+// 3-D conv kernels the general fall-through ends in.
+static int build_repeat_kernels(unires_plan *pl, Repeat &R) {
+  int rc = build_sched(pl, R);
+  if (rc) return rc;
+  build_pull(pl, R);
+  if (R.hyb && !(R.pplan.valid && R.sched.valid && R.sched.axis == 2)) {
+    R.hyb = false;
+    R.sep = R.sep0;
+    R.hybf = R.sep0 && R.pplan.valid;  // (the window plan of the forward half is the one just built)
+    rc = build_sched(pl, R);
+    if (rc) return rc;
+    if (!R.hybf) build_pull(pl, R);
+  }
+  return UNIRES_OK;
+}
+
 static void free_sched(Repeat &R) {
   splat2_free(R.sched);
   pull2_free(R.pplan);
@@ -604,8 +627,7 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
   }
   for (Repeat &R : pl->reps) {
     int rc = upload_ztabs(pl, R);
-    if (!rc) rc = build_sched(pl, R);
-    if (!rc) build_pull(pl, R);
+    if (!rc) rc = build_repeat_kernels(pl, R);
     if (rc) {
       for (Repeat &Q : pl->reps) free_ztabs(Q), free_sched(Q);
       (void)hipFree(pl->ws);
@@ -659,8 +681,7 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   for (int d = 0; d < 2; ++d) tmp.xytab_dev[d] = plan->reps[n].xytab_dev[d], tmp.xytab_cap[d] = plan->reps[n].xytab_cap[d];
   plan->reps[n] = tmp;
   rc = upload_ztabs(plan, plan->reps[n]);
-  if (!rc) rc = build_sched(plan, plan->reps[n]);
-  if (!rc) build_pull(plan, plan->reps[n]);
+  if (!rc) rc = build_repeat_kernels(plan, plan->reps[n]);
   return rc;
 }
 
