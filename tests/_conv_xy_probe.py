@@ -17,7 +17,9 @@ mat_y = torch.eye(4, dtype=torch.float64)
 mat_x = mat_y @ torch.diag(torch.tensor([2.0, 2.0, 2.0, 1.0], dtype=torch.float64))
 dim_x = tuple(d // 2 for d in dim_y)
 rigid = rigid_matrix([0.4, -0.3, 0.2], [0.03, -0.02, 0.04])
-po = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, device=dev, scl=float(sys.argv[1]) if len(sys.argv) > 1 else 0.0)
+scl = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
+prof = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0: rect (fan-in 2 x 2), 1: triangle (3 x 3)
+po = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, device=dev, scl=scl, prof_ip=prof, prof_tp=prof)
 torch.manual_seed(3)
 p = (torch.rand(dim_y) + 0.5).to(dev)
 v = (torch.rand(dim_x) + 0.5).to(dev)

@@ -245,8 +245,9 @@ def test_identity_regime_stencil_any_shape_and_alignment(dev, dim, shift):
     assert bool((qbuf[:off] == 7.0).all()) and bool((qbuf[off + n:] == 7.0).all())
 
 
+@pytest.mark.parametrize('prof', ['0', '1'])
 @pytest.mark.parametrize('scl', ['0.0', '0.1'])
-def test_fused_xy_conv_pass_is_bit_identical_to_the_two_passes(dev, scl):
+def test_fused_xy_conv_pass_is_bit_identical_to_the_two_passes(dev, scl, prof):
     """k_conv2d_down_xy_v4 / k_conv2d_up_xy_v4 (one kernel for the x and y passes of an isotropic
     down-sampling) form the same products in the same order as k_conv1d_*_v4 run twice: A p, At v and
     AtA p must not change by a single bit when the fused pass is switched off."""
@@ -257,7 +258,7 @@ def test_fused_xy_conv_pass_is_bit_identical_to_the_two_passes(dev, scl):
     outs = []
     for sw in ('1', '0'):
         env = dict(os.environ, UNIRES_CONV_XY=sw)
-        r = subprocess.run([sys.executable, os.path.join(here, '_conv_xy_probe.py'), scl], env=env, capture_output=True,
+        r = subprocess.run([sys.executable, os.path.join(here, '_conv_xy_probe.py'), scl, prof], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.split()[0] in ('A', 'At', 'AtA')])

@@ -380,43 +380,10 @@ __global__ void __launch_bounds__(kBlock)
     dst[((size_t)i * dd.y + j) * z4 + k] = make_float4(acc.x * sc, acc.y * sc, acc.z * sc, acc.w * sc);
   }
 }
-__global__ void __launch_bounds__(kBlock)
-    k_conv2d_up_xy_v4(const float4 *__restrict__ src, Dim3i sd, Taps1 KX, Taps1 KY, int nx, int sx, int ny,
-                      int sy, float sex, float sox, float sey, float soy, float4 *__restrict__ dst, Dim3i dd) {
-  __shared__ float tx[UNIRES_MAX_TAPS], ty[UNIRES_MAX_TAPS];
-  const int tid = threadIdx.y * kWave + threadIdx.x;
-  if (tid < UNIRES_MAX_TAPS) tx[tid] = KX.t[tid], ty[tid] = KY.t[tid];
-  __syncthreads();
-  const int z4 = dd.z >> 2;
-  const unsigned t = blockIdx.x * (unsigned)kBlock + threadIdx.y * kWave + threadIdx.x;
-  if (t >= (unsigned)dd.y * (unsigned)z4) return;
-  const int j = (int)(t / (unsigned)z4), k = (int)(t - (unsigned)j * (unsigned)z4);
-  const size_t sstr_x = (size_t)sd.y * z4;
-  int lo_y, hi_y;
-  up_range_f(j, ny, sy, 1.f / (float)sy, sd.y, lo_y, hi_y);
-  float wy[kConvXYMax];
-#pragma unroll
-  for (int c = 0; c < kConvXYMax; ++c)
-    wy[c] = lo_y + c <= hi_y ? ty[j - sy * (lo_y + c)] * (((lo_y + c) & 1) ? soy : sey) : 0.f;
-  const float inv_sx = 1.f / (float)sx;
-  for (int i = blockIdx.y; i < dd.x; i += gridDim.y) {
-    int lo, hi;
-    up_range_f(i, nx, sx, inv_sx, sd.x, lo, hi);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int cy = 0; cy < kConvXYMax; ++cy) {
-      if (lo_y + cy > hi_y) break;
-      const float4 *col = src + ((size_t)lo * sd.y + (size_t)(lo_y + cy)) * z4 + k;
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int c = lo; c <= hi; ++c, col += sstr_x) t = fma4(tx[i - sx * c] * ((c & 1) ? sox : sex), *col, t);
-      acc = fma4(wy[cy], t, acc);
-    }
-    dst[((size_t)i * dd.y + j) * z4 + k] = acc;
-  }
-}
-// Same, for fan-ins <= FX x FY known at compile time, R consecutive x slabs per thread: every load of
-// the R outputs is issued before the first product (the run-time form above has one short dependent
-// chain per thread - 27 648 workgroups that live 3.4 us each at 384 x 384 x 192: 46 us, 3 TB/s).
+// conv_up: fan-ins <= FX x FY known at compile time, R consecutive x slabs per thread: every load of
+// the R outputs is issued before the first product (a run-time form with one output per thread had one
+// short dependent chain per thread - 27 648 workgroups that live 3.4 us each at 384 x 384 x 192: 46 us,
+// 3 TB/s; this one 29 us; with fan-ins 2 x 6 it lost to the two passes, 78 vs 65 us, and was dropped).
 // Taps beyond a voxel's range are skipped, not multiplied by zero: bit-identical to the two passes.
 template <int FX, int FY, int R>
 __global__ void __launch_bounds__(kBlock)
@@ -646,7 +613,7 @@ float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scalin
   auto fan = [&](int ax) { return (T.n[ax] + T.s[ax] - 1) / T.s[ax]; };
   for (int ax = 0; ax < 3; ++ax) {
     if (!active(ax)) continue;
-    if (ax == 0 && fuse_xy && active(1) && fan(0) <= kConvXYMax && fan(1) <= kConvXYMax && fan(0) * fan(1) <= 16) {
+    if (ax == 0 && fuse_xy && active(1) && fan(0) <= 3 && fan(1) <= 3 && cd.numel() / 4 < (1ull << 32)) {
       // x and y passes in one kernel
       const Dim3i od = Dim3i{gd.x, gd.y, cd.z};
       float *o2 = cur == a ? b : a;
@@ -655,19 +622,15 @@ float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scalin
         for (int t = 0; t < UNIRES_MAX_TAPS; ++t) KX.t[t] = T.t[0][t], KY.t[t] = T.t[1][t];
         const float sex = S.dim == 0 ? S.e : 1.f, sox = S.dim == 0 ? S.o : 1.f, sey = S.dim == 1 ? S.e : 1.f,
                     soy = S.dim == 1 ? S.o : 1.f;
-        const bool small = cd.numel() / 4 < (1ull << 32);
         dim3 g = conv2d_grid(od);
-        if (small && fan(0) <= 2 && fan(1) <= 2) {
+        if (fan(0) <= 2 && fan(1) <= 2) {
           g.y = (od.x + 3) / 4;
           hipLaunchKernelGGL((k_conv2d_up_xy_v4_t<2, 2, 4>), g, vol_block(), 0, st, (const float4 *)cur, cd, KX, KY,
                              T.n[0], T.s[0], T.n[1], T.s[1], sex, sox, sey, soy, (float4 *)o2, od);
-        } else if (small && fan(0) <= 3 && fan(1) <= 3) {
+        } else {
           g.y = (od.x + 1) / 2;
           hipLaunchKernelGGL((k_conv2d_up_xy_v4_t<3, 3, 2>), g, vol_block(), 0, st, (const float4 *)cur, cd, KX, KY,
                              T.n[0], T.s[0], T.n[1], T.s[1], sex, sox, sey, soy, (float4 *)o2, od);
-        } else {
-          hipLaunchKernelGGL(k_conv2d_up_xy_v4, g, vol_block(), 0, st, (const float4 *)cur, cd, KX, KY, T.n[0],
-                             T.s[0], T.n[1], T.s[1], sex, sox, sey, soy, (float4 *)o2, od);
         }
         out = o2, cur = o2, cd = od;
         ax = 1;  // (the loop continues with z)
