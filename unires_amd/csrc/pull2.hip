@@ -605,6 +605,8 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
     const long long nbi = (long long)grid.x / ((long long)P.G.nbc * P.G.nbj);
     const bool row_fits_l2 = (double)P.G.nbj * P.G.nbc * (double)lds < 3.5e6;
     P.band = (int)(row_fits_l2 ? std::max<long long>(nbi, 1) : kP2Band);
+    static const int band_env = getenv("UNIRES_P2_BAND") ? atoi(getenv("UNIRES_P2_BAND")) : 0;  // (measurement)
+    if (band_env > 0) P.band = (int)std::min<long long>(band_env, std::max<long long>(nbi, 1));
   }
   P.prof = nullptr;
 #ifdef UNIRES_P2_PROF
