@@ -26,6 +26,13 @@ for it in range(int(os.environ.get('N', '12'))):
             kw['n_repeats'] = 1
         elif int(torch.randint(0, 3, (1,), generator=g)) == 0:  # profile along several axes (per-axis ratios 1..3)
             kw['iso'] = tuple(int(v) for v in torch.randint(1, 4, (3,), generator=g))
+            # x-space z extent a multiple of 4 half of the time: the 16-byte 1-D passes and the fused x-y pass
+            if int(torch.randint(0, 2, (1,), generator=g)) == 0:
+                rz = kw['iso'][2]
+                kw['dim_y'] = (dims[0], dims[1], 4 * rz * max(1, dims[2] // (4 * rz)))
+        # the in-plane / through-plane slice profiles of the reference's settings (rect, triangle, Gaussian)
+        kw['prof_ip'] = int(torch.randint(0, 3, (1,), generator=g))
+        kw['prof_tp'] = int(torch.randint(0, 2, (1,), generator=g))
     try:
         prob = make_problem(**kw)
     except Exception as e:  # degenerate draw (e.g. a thick axis longer than the volume)
