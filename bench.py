@@ -452,6 +452,9 @@ def main():
     ap.add_argument('--serial-channels', action='store_true',
                     help='run the channels of the y-update one after the other on one stream '
                          '(profiling aid: per-kernel durations then carry no overlap)')
+    ap.add_argument('--channel-streams', action='store_true',
+                    help='the channels of the y-update on separate HIP streams, whatever the volume size '
+                         "(settings.channel_streams = 'auto' picks streams below 10 M voxels)")
     ap.add_argument('--cpu-seconds', type=float, default=25.0)
     ap.add_argument('--admm-iters', type=int, default=50,
                     help='ADMM iterations of the subjects/sec leg (one subject = this many iterations)')
@@ -482,6 +485,8 @@ def main():
     x, y, z, w, rho, sett = build_subject(wl, device, seed=1234)
     if args.serial_channels:
         sett.channel_streams = False
+    if args.channel_streams:
+        sett.channel_streams = True
     tmp = torch.zeros_like(y[0].dat)
 
     def step():
@@ -555,7 +560,8 @@ def main():
                        'thick_ratio': wl['thick'], 'cg_iters_per_channel': sett.cgs_max_iter,
                        'cg_mode': 'fixed-iteration (tol=0), identity preconditioner',
                        'step': 'one y-update of one subject: C x (RHS + 20 CG iterations)',
-                       'channel_streams': bool(getattr(sett, 'channel_streams', True)),
+                       'channel_streams': bool(U._update.channel_streams_on(sett, y[0].dat)),
+                       'channel_streams_setting': getattr(sett, 'channel_streams', 'auto'),
                        'parallelism': 'one subject per GPU, no data-path collective'},
             'subjects_per_sec': world / t_subject,
             'subjects_per_sec_note': 'subject = %d full ADMM iterations (y-update C x 20 CG, objective, z- and '

@@ -606,3 +606,35 @@ def test_fit_with_rigid_and_scaling_updates(dev):
             assert abs(float(xg[c][n].po.scl) - float(xo[c][n].po.scl)) < 1e-4
             k += 1
         assert rel_err(dat[..., c].cpu(), y_ref[c].dat) < 5e-3
+
+
+@pytest.mark.parametrize('case', ['sr_3ch_axes', 'dn_2ch', 'sr_2rep'])
+def test_update_y_on_channel_streams_and_one_after_the_other(dev, case):
+    """settings.channel_streams: True / False / 'auto' run the same kernels per channel - streams only
+    change what overlaps.  Both forms, run twice (the second call takes sum_n tau_n At x_n from the plan's
+    cache, settings.cache_atx), give bit-identical y; the synchronous path the other tests compare with
+    the oracle assembles its right-hand side in one kernel instead of cached + prior part, so it agrees
+    to rounding."""
+    import unires_amd as U
+    from unires_amd._update import channel_streams_on
+    prob = make_problem(**CASES[case])
+    y_sync, _ = run_gpu_update_y(prob, dev, max_iter=6, tol=0.0)
+    outs = {}
+    for cs in (True, False, 'auto'):
+        x, y, sett = gpu_structs(prob, dev)
+        sett.cgs_max_iter, sett.cgs_tol, sett.channel_streams = 6, 0.0, cs
+        assert channel_streams_on(sett, y[0].dat) == (cs is not False)  # (small volume: 'auto' = streams)
+        z, w = prob['z'].to(dev), prob['w'].to(dev)
+        tmp = torch.zeros_like(y[0].dat)
+        for rep in range(2):
+            for yc, y0 in zip(y, prob['y0']):
+                yc.dat.copy_(y0.to(dev))
+            U._update_y(x, y, z, w, prob['rho'], tmp, sett)
+            torch.cuda.synchronize()
+            outs[(cs, rep)] = [yc.dat.clone() for yc in y]
+    first = outs[(True, 0)]
+    for key, ys in outs.items():
+        for c, yc in enumerate(ys):
+            assert torch.equal(yc, first[c]), 'channel %d differs for channel_streams=%r, call %d' % ((c,) + key)
+    for c, yc in enumerate(first):
+        assert rel_err(yc.cpu(), y_sync[c].cpu()) < 1e-5

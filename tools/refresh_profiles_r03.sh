@@ -5,13 +5,16 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/r03; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 # 1. the driver's command: one bench line (with cpu_baseline and variants)
 python bench.py > $OUT/bench.log 2>&1; grep '^{"metric"' $OUT/bench.log | tail -1 > $OUT/r03_bench.json
-# 2. rocprofv3 --kernel-trace --stats of the same command (three channel streams) and of the serial form
+# 2. rocprofv3 --kernel-trace --stats of the same command and of the explicitly serial form (at 256^3 the
+#    default IS one channel after the other since settings.channel_streams = 'auto'); + one bench line
+#    with the three channel streams forced
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt1 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt1 -o k -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-variants --admm-iters 5 > $OUT/bench_prof_default.log 2>&1
 cp /tmp/kt1/k_kernel_stats.csv $OUT/r03_bench_kernel_stats.csv
 rm -rf /tmp/kt2 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -o k -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-variants --serial-channels --admm-iters 5 > $OUT/bench_prof_serial.log 2>&1
 cp /tmp/kt2/k_kernel_stats.csv $OUT/r03_bench_serial_kernel_stats.csv
 grep '^{"metric"' $OUT/bench_prof_serial.log | tail -1 > $OUT/r03_bench_serial.json
+python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-variants --channel-streams --admm-iters 5 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/r03_bench_streams.json
 cd $GRAFT_REPO_ROOT
 # 3. PMC traffic (FETCH_SIZE / WRITE_SIZE in separate passes) of the matvec kernels: config 3 per channel,
 #    configs 4 (rect and Gaussian in-plane profile), 2, 1 and the aligned / translated variants

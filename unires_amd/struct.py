@@ -91,8 +91,11 @@ class settings:
         # 'fft': build-side FFT-diagonal preconditioner (circulant a I + rho lam^2 DtD)
         self.cgs_precond = 'none'
         # build-side knob: enqueue the (independent) channels of the y-update on separate HIP streams
-        # (round 2, streams vs one channel after the other: config 3 within +-4 % either way - its
-        # kernels fill the chip alone; config 2 +20 %, config 4 +15 %, the demo's shape +25 %)
-        self.channel_streams = True
+        # (True / False), or 'auto': streams for volumes below 10 M voxels.  Measured in round 3, streams
+        # vs one channel after the other (CG iterations/s): 181 x 217 x 181 (config 2, the demo's shape)
+        # +20 .. +24 % - its kernels do not fill the chip alone; 256^3: config 3 -6 %, aligned -2.5 %,
+        # translated -5.6 %, thick axis x / y / z +1.6 % - three channels' vectors (800 MB) no longer
+        # share the 256 MB Infinity Cache; 384^3 (config 4): +-1 %, Gaussian profile +3 %
+        self.channel_streams = 'auto'
         # build-side knob: keep sum_n tau_n At x_n across ADMM iterations (recomputed on change)
         self.cache_atx = True
