@@ -23,6 +23,10 @@ po = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, device=dev, scl=scl, 
 torch.manual_seed(3)
 p = (torch.rand(dim_y) + 0.5).to(dev)
 v = (torch.rand(dim_x) + 0.5).to(dev)
+# the plan-level operators (the fused pull / conv / splat kernels of the hot path; U._proj_apply composes
+# the op-level kernels and never runs the separable passes)
+from unires_amd._plan import ChannelPlan  # noqa: E402
+plan = ChannelPlan(dim_y, (1.0, 1.0, 1.0), [(po, 1.0)], 'super-resolution', True, device=dev)
 for op, arg in (('A', p), ('At', v), ('AtA', p)):
-    out = U._proj_apply(op, arg[None, None], po, method='super-resolution')[0, 0]
+    out = plan.proj_apply(0, op, arg)
     print(op, hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest())

@@ -287,8 +287,30 @@ def test_isotropic_downsampling_under_large_rotations(dev, prof_ip, rot):
     torch.manual_seed(11)
     p = torch.rand(dim_y) + 0.5
     v = torch.rand(dim_x) + 0.5
+    from unires_amd._plan import ChannelPlan
+    plan = ChannelPlan(dim_y, (1.0, 1.0, 1.0), [(po_g, 1.0)], 'super-resolution', True, device=dev)
     for op, arg in (('A', p), ('At', v), ('AtA', p)):
         ref = O.proj_apply(op, arg[None, None], po_o, method='super-resolution')[0, 0]
-        out = U._proj_apply(op, arg[None, None].to(dev), po_g, method='super-resolution')[0, 0].cpu()
-        err = float((out - ref).abs().max()) / float(ref.abs().max())
-        assert err < 1e-5, '%s differs from the oracle: %.3g' % (op, err)
+        for name, out in (('plan', plan.proj_apply(0, op, arg.to(dev)).cpu()),
+                          ('op-level', U._proj_apply(op, arg[None, None].to(dev), po_g, method='super-resolution')[0, 0].cpu())):
+            err = float((out - ref).abs().max()) / float(ref.abs().max())
+            assert err < 1e-5, '%s (%s kernels) differs from the oracle: %.3g' % (op, name, err)
+
+
+def test_sixteen_wave_splat_workgroups_give_the_same_bits(dev):
+    """k_splat2<AXIS, 16> (one 16-wave workgroup per CU sharing one conv-up table; taken when the table
+    leaves room for fewer 4-wave workgroups than the grid was sized for; UNIRES_SPLAT2_WIDE=2 forces it)
+    and a grid capped below its size (UNIRES_SPLAT2_RESIDENT=1 on a 32-workgroup grid... capped at 256)
+    walk the same tiles with the same per-tile arithmetic as the plain launch: At v and AtA p for thick
+    slices along x, y and z must not change by a bit."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = []
+    for env_extra in ({}, {'UNIRES_SPLAT2_WIDE': '2'}, {'UNIRES_SPLAT2_RESIDENT': '1', 'UNIRES_SPLAT2_WIDE': '0'}):
+        r = subprocess.run([sys.executable, os.path.join(here, '_splat_wide_probe.py')], env=dict(os.environ, **env_extra),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.split()[0] in ('At', 'AtA')])
+    assert len(outs[0]) == 9 and outs[0] == outs[1] == outs[2]

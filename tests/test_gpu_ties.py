@@ -18,6 +18,7 @@ import torch
 from oracle import nitorch_restated as N
 from oracle import unires_restated as O
 from tests.helpers import rigid_matrix
+from unires_amd._plan import ChannelPlan
 
 pytestmark = pytest.mark.gpu
 
@@ -68,19 +69,25 @@ def test_denoising_disagreements_lie_within_reach_of_fov_ties(dev, trans, rot):
     assert int(near.sum()) > 0, 'the geometry was meant to put grid points on the thresholds'
     torch.manual_seed(5)
     p = torch.rand(dim_y) + 0.5
-    # A: a flipped mask changes exactly that grid point
-    ref = O.proj_apply('A', p[None, None], po_o, method='denoising')[0, 0]
-    out = U._proj_apply('A', p[None, None].to(dev), po_g, method='denoising')[0, 0].cpu()
-    bad = (out - ref).abs() > 1e-5 * float(ref.abs().max())
-    assert not bool((bad & ~near).any()), 'A differs from the oracle away from every FOV tie'
-    # At and AtA: the flipped grid point's footprint in the output volume
     v = torch.rand(dim_g) + 0.5
     cover = _reach(near, g, dim_y, reach=2)
-    for op, arg in (('At', v), ('AtA', p)):
-        ref = O.proj_apply(op, arg[None, None], po_o, method='denoising')[0, 0]
-        out = U._proj_apply(op, arg[None, None].to(dev), po_g, method='denoising')[0, 0].cpu()
+    # both sets of kernels: the plan's (LDS-window pull, schedule-driven splat - the hot path) and the
+    # op-level ones U._proj_apply composes
+    plan = ChannelPlan(dim_y, (1.0, 1.0, 1.0), [(po_g, 1.0)], 'denoising', True, device=dev)
+    kernels = {'plan': lambda op, a: plan.proj_apply(0, op, a.to(dev)).cpu(),
+               'op-level': lambda op, a: U._proj_apply(op, a[None, None].to(dev), po_g, method='denoising')[0, 0].cpu()}
+    for name, apply in kernels.items():
+        # A: a flipped mask changes exactly that grid point
+        ref = O.proj_apply('A', p[None, None], po_o, method='denoising')[0, 0]
+        out = apply('A', p)
         bad = (out - ref).abs() > 1e-5 * float(ref.abs().max())
-        assert not bool((bad & ~cover).any()), '%s differs from the oracle out of reach of every FOV tie' % op
+        assert not bool((bad & ~near).any()), 'A (%s) differs from the oracle away from every FOV tie' % name
+        # At and AtA: the flipped grid point's footprint in the output volume
+        for op, arg in (('At', v), ('AtA', p)):
+            ref = O.proj_apply(op, arg[None, None], po_o, method='denoising')[0, 0]
+            out = apply(op, arg)
+            bad = (out - ref).abs() > 1e-5 * float(ref.abs().max())
+            assert not bool((bad & ~cover).any()), '%s (%s) differs from the oracle out of reach of every FOV tie' % (op, name)
     # and the ties are few: the operators agree on (nearly) the whole volume
     assert float(cover.float().mean()) < 0.5
 
@@ -102,11 +109,13 @@ def test_super_resolution_disagreements_lie_within_reach_of_fov_ties(dev, trans,
     torch.manual_seed(6)
     p = torch.rand(dim_y) + 0.5
     ref = O.proj_apply('A', p[None, None], po_o, method='super-resolution')[0, 0]
-    out = U._proj_apply('A', p[None, None].to(dev), po_g, method='super-resolution')[0, 0].cpu()
-    bad = (out - ref).abs() > 1e-5 * float(ref.abs().max())
     # x-space voxel k reads grid points k * ratio .. k * ratio + K - 1 along z
     K = int(po_o.smo_ker.shape[-1])
     win = torch.zeros(dim_x, dtype=torch.bool)
     for k in range(dim_x[2]):
         win[:, :, k] = near[:, :, k * thick:k * thick + K].any(dim=2)
-    assert not bool((bad & ~win).any()), 'A differs from the oracle where no FOV tie is in the window'
+    plan = ChannelPlan(dim_y, (1.0, 1.0, 1.0), [(po_g, 1.0)], 'super-resolution', True, device=dev)
+    for name, out in (('plan', plan.proj_apply(0, 'A', p.to(dev)).cpu()),
+                      ('op-level', U._proj_apply('A', p[None, None].to(dev), po_g, method='super-resolution')[0, 0].cpu())):
+        bad = (out - ref).abs() > 1e-5 * float(ref.abs().max())
+        assert not bool((bad & ~win).any()), 'A (%s) differs from the oracle where no FOV tie is in the window' % name

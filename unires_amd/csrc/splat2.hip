@@ -987,9 +987,11 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
   P.active = s2_active(S.axis, lds, (int)grid.x);
   // A table too long for four 4-wave workgroups per CU (each carries its own copy): ONE 16-wave
   // workgroup per CU shares a single copy - the same 16 waves and the same wave -> tile walk.
-  static const bool wide_ok = !(getenv("UNIRES_SPLAT2_WIDE") && atoi(getenv("UNIRES_SPLAT2_WIDE")) == 0);
+  // (UNIRES_SPLAT2_WIDE: 0 never, 2 wherever the grid allows it - the tests' way to reach the form on small volumes)
+  static const int wide_env = getenv("UNIRES_SPLAT2_WIDE") ? atoi(getenv("UNIRES_SPLAT2_WIDE")) : 1;
   constexpr int kWide = 16, kRatio = kWide / kS2Waves;
-  if (wide_ok && P.active < (int)grid.x && S.axis >= 0 && S.axis <= 2 && grid.x % kRatio == 0 && grid.x / kRatio >= 8) {
+  if (wide_env != 0 && (P.active < (int)grid.x || wide_env == 2) && S.axis >= 0 && S.axis <= 2 &&
+      grid.x % kRatio == 0 && grid.x / kRatio >= 8) {
     const dim3 gridw(grid.x / kRatio), blockw(kWave * kWide);
     P.active = (int)gridw.x;
     switch (S.axis) {
