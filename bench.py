@@ -207,6 +207,42 @@ def time_matvec(x, y, rho, sett, reps=16, ring=2, graph=True, channels=None):
     return e0.elapsed_time(e1) * 1e-3 / (reps * C)
 
 
+def time_matvec_in_solve(x, y, z, w, rho, tmp, sett):
+    """Average duration of one operator application A(p) INSIDE the CG solves of one y-update: the
+    library brackets each of them with HIP events on the stream it launches on
+    (unires_plan_time_matvecs; the solves then run as plain launches - a dependent kernel boundary costs
+    the same in a hipGraph).  This is the kernel pair as the timed region runs it - p freshly rewritten
+    by the preceding update, the other vectors streamed in between - and the figure the rocprofv3 kernel
+    durations of this command, dominated by the solves' own launches, agree with."""
+    import unires_amd as U
+    from unires_amd._project import _channel_plan
+    plans = [_channel_plan(x[c], y[c], sett.method, sett.do_proj) for c in range(len(x))]
+    # one channel after the other, whatever the setting: with the channels on separate streams (small
+    # volumes) three kernels share the chip and a launch's wall time is not the kernel's own
+    keep = getattr(sett, 'channel_streams', 'auto')
+    sett.channel_streams = False
+    for yc in y:
+        yc.dat.zero_()
+    U._update_y(x, y, z, w, rho, tmp, sett)  # (warm: plans, caches, allocator)
+    torch.cuda.synchronize()
+    for pl in plans:
+        pl.time_matvecs(True)
+    try:
+        for yc in y:
+            yc.dat.zero_()
+        U._update_y(x, y, z, w, rho, tmp, sett)
+        torch.cuda.synchronize()
+        n, us = 0, 0.0
+        for pl in plans:
+            k, t = pl.matvec_time()
+            n, us = n + k, us + t
+    finally:
+        for pl in plans:
+            pl.time_matvecs(False)
+        sett.channel_streams = keep
+    return us * 1e-6 / max(n, 1), n
+
+
 def host_cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -546,7 +582,12 @@ def main():
         # carries ~2.5 us of barrier packet per kernel and is reported next to it, never mixed in)
         t_mv_graph = time_matvec(x, y, rho, sett)
         t_mv_eager = time_matvec(x, y, rho, sett, graph=False)
-        t_mv = t_mv_eager
+        # (r3) the headline figure is the operator application as the timed region runs it: every A(p) of
+        # one y-update's CG solves between HIP events recorded by the library on its launch stream.  Since
+        # the iterate x is streamed past the caches the solver's matvecs find p warm, and the cold-operand
+        # figure (kept as us_per_launch_cold) came out ~5 % above the kernel durations rocprofv3 reports
+        # for this command.
+        t_mv, n_mv = time_matvec_in_solve(x, y, z, w, rho, tmp, sett)
         per_channel = [time_matvec(x, y, rho, sett, ring=4, channels=[c], graph=False) * 1e6 for c in range(len(x))]
         b_mv = alg_bytes_matvec(x[0], wl['dim_y'], sett.do_proj)
         achieved = b_mv / t_mv / 1e9
@@ -567,15 +608,22 @@ def main():
             'subjects_per_sec_note': 'subject = %d full ADMM iterations (y-update C x 20 CG, objective, z- and '
                                      'w-update) run on every rank between barriers, max over ranks: %.3f s '
                                      '(%.2f ms per ADMM iteration)' % (n_admm, t_subject, t_subject / n_admm * 1e3),
-            'roofline': {'bound': 'hbm', 'kernel': 'ata_matvec (per launch, mean over channels, cold operands)',
+            'roofline': {'bound': 'hbm', 'kernel': 'ata_matvec (per launch inside the CG solves of one y-update, mean over channels)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          # HBM bytes per launch from the PMC counters (null if no profile of this workload is
                          # committed); STATIC: read from the committed profile named in traffic_source
                          'traffic': (traffic or {}).get('bytes_per_launch'), 'traffic_source': traffic,
                          'alg_bytes_per_launch': b_mv, 'us_per_launch': t_mv * 1e6,
+                         'launches_timed': n_mv,
+                         'us_per_launch_cold': t_mv_eager * 1e6, 'frac_cold': b_mv / t_mv_eager / 1e9 / HBM_PEAK_GBS,
                          'us_per_launch_graph': t_mv_graph * 1e6, 'us_per_launch_eager': t_mv_eager * 1e6,
-                         'us_per_launch_by_channel': per_channel, 'timing': 'plain launches, HIP events on the launch stream'},
+                         'us_per_launch_by_channel': per_channel,
+                         'timing': 'us_per_launch: HIP events recorded by the library around every A(p) of one '
+                                   "y-update's CG solves, on the stream they are launched on (plain launches); "
+                                   '_cold = _eager: stand-alone launches cycling through more p / q buffers than the '
+                                   'Infinity Cache holds (the round-2 method), _graph: those replayed as one hipGraph, '
+                                   '_by_channel: cold, one channel at a time'},
         }
         if world == 1 and not args.no_variants:
             out['variants'] = variants(args.workload, x, y, z, w, rho, tmp, sett, device)

@@ -156,6 +156,13 @@ int unires_plan_destroy(unires_plan_t *plan);
 int unires_plan_set_repeat(unires_plan_t *plan, int32_t n, const unires_repeat_t *repeat);
 /* Bytes of device workspace the plan owns. */
 int64_t unires_plan_workspace_bytes(const unires_plan_t *plan);
+/* Measurement aid (no counterpart in the reference; bench.py's roofline leg).  While on,
+ * unires_cg_solve launches its kernels one by one (no hipGraph replay) and brackets every operator
+ * application A(p) of the solve with HIP events on the caller's stream. */
+int unires_plan_time_matvecs(unires_plan_t *plan, int32_t on);
+/* Waits for the recorded events; returns how many applications were recorded since the last call and
+ * the sum of their durations (microseconds), and forgets them. */
+int unires_plan_matvec_time(unires_plan_t *plan, int32_t *launches, double *total_us);
 
 /* _proj_apply(operator, ., po_n)  (_project.py:99-190) for repeat n, WITHOUT tau.
  * in/out sizes follow the operator (A: dim_y -> dim_x; At: dim_x -> dim_y; AtA: dim_y -> dim_y). */

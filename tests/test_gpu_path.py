@@ -638,3 +638,31 @@ def test_update_y_on_channel_streams_and_one_after_the_other(dev, case):
             assert torch.equal(yc, first[c]), 'channel %d differs for channel_streams=%r, call %d' % ((c,) + key)
     for c, yc in enumerate(first):
         assert rel_err(yc.cpu(), y_sync[c].cpu()) < 1e-5
+
+
+def test_matvec_timing_hooks_count_the_solve_and_leave_it_unchanged(dev):
+    """unires_plan_time_matvecs / unires_plan_matvec_time (bench.py's roofline leg): one event pair per
+    A(p) of the solve - max_iter of them in fixed-iteration mode - and the solve, then run as plain
+    launches instead of a hipGraph, returns the same bits."""
+    import unires_amd as U
+    from unires_amd._project import _channel_plan
+    prob = make_problem(**CASES['sr_3ch_axes'])
+    outs = []
+    for timed in (False, True):
+        x, y, sett = gpu_structs(prob, dev)
+        sett.cgs_max_iter, sett.cgs_tol = 7, 0.0
+        z, w = prob['z'].to(dev), prob['w'].to(dev)
+        tmp = torch.zeros_like(y[0].dat)
+        plans = [_channel_plan(x[c], y[c], sett.method, sett.do_proj) for c in range(len(x))]
+        for pl in plans:
+            pl.time_matvecs(timed)
+        U._update_y(x, y, z, w, prob['rho'], tmp, sett)
+        torch.cuda.synchronize()
+        for pl in plans:
+            n, us = pl.matvec_time()
+            assert n == (7 if timed else 0)
+            assert (us > 0.0) == timed
+            pl.time_matvecs(False)
+        outs.append([yc.dat.clone() for yc in y])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

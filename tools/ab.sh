@@ -8,7 +8,7 @@ last="__none__"
 b() { python bench.py --no-cpu-baseline --no-variants --admm-iters 2 "$@" 2>/dev/null | grep '^{"metric"' | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
-print('%-28s it/s %8.0f  ms/step %7.3f  matvec %7.1f us (graph %.1f eager %.1f)  frac %.3f' % (d['config']['workload'], d['value'], d['ms_per_step'], r['us_per_launch'], r['us_per_launch_graph'], r['us_per_launch_eager'], r['frac']))"; }
+print('%-28s it/s %8.0f  ms/step %7.3f  matvec %7.1f us (cold: graph %.1f eager %.1f)  frac %.3f' % (d['config']['workload'], d['value'], d['ms_per_step'], r['us_per_launch'], r['us_per_launch_graph'], r['us_per_launch_eager'], r['frac']))"; }
 k() { WL=$1 CH=${2:-1} bash tools/prof.sh tools/pmc5.py 2>&1 | grep "unires::k_" | grep -v "build\|plan" | cut -c1-110; }
 export -f b k
 while IFS='|' read -r name flags envs cmd; do

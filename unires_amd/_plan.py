@@ -101,6 +101,17 @@ class ChannelPlan:
     def workspace_bytes(self):
         return int(self.lib.unires_plan_workspace_bytes(self._h))
 
+    def time_matvecs(self, on=True):
+        """Measurement aid: bracket every operator application of the following solves with HIP events
+        (the solves then run as plain launches, not as a hipGraph)."""
+        check(self.lib.unires_plan_time_matvecs(self._h, 1 if on else 0))
+
+    def matvec_time(self):
+        """(launches, total microseconds) recorded since the last call; waits for them."""
+        n, us = C.c_int32(0), C.c_double(0.0)
+        check(self.lib.unires_plan_matvec_time(self._h, C.byref(n), C.byref(us)))
+        return int(n.value), float(us.value)
+
     @on_device
     def set_repeat(self, n, po, tau):
         keep = []

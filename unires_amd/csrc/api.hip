@@ -302,6 +302,9 @@ struct unires_plan {
   char *ws = nullptr;
   size_t ws_bytes = 0;
   float *r = nullptr, *p = nullptr, *ap = nullptr, *ax = nullptr;  // N_y each
+  // measurement aid (unires_plan_time_matvecs): event pairs around the operator applications of a solve
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
   float *gbuf = nullptr;                                           // max N_g
   float *gbuf2 = nullptr;  // second grid-space scratch, only for many-tap profiles (separable passes)
   float *xbuf = nullptr;                                           // max N_x
@@ -331,6 +334,11 @@ struct unires_plan {
 
 // Drop the captured CG solve.  A launch of it may still be in flight (the ADMM loop never syncs):
 // wait for the device before destroying the executable graph.
+static void drop_timing(unires_plan *pl) {
+  for (auto &e : pl->tev) (void)hipEventDestroy(e.first), (void)hipEventDestroy(e.second);
+  pl->tev.clear();
+}
+
 static void drop_cg_graph(unires_plan *pl) {
   if (!pl->cg_exec) return;
   (void)hipDeviceSynchronize();
@@ -644,9 +652,31 @@ extern "C" int unires_plan_destroy(unires_plan_t *plan) {
   if (plan->ws) (void)hipFree(plan->ws);
   if (plan->precM) (void)hipFree(plan->precM);
   if (plan->cg_exec) (void)hipGraphExecDestroy(plan->cg_exec);
+  drop_timing(plan);
   fftpre_destroy(plan->fft);
   for (Repeat &R : plan->reps) free_ztabs(R), free_sched(R);
   delete plan;
+  return UNIRES_OK;
+}
+
+extern "C" int unires_plan_time_matvecs(unires_plan_t *plan, int32_t on) {
+  if (!plan) return fail(UNIRES_ERR_NULL, "null argument");
+  plan->timing = on != 0;
+  if (!plan->timing) drop_timing(plan);
+  return UNIRES_OK;
+}
+
+extern "C" int unires_plan_matvec_time(unires_plan_t *plan, int32_t *launches, double *total_us) {
+  if (!plan || !launches || !total_us) return fail(UNIRES_ERR_NULL, "null argument");
+  *launches = 0, *total_us = 0.0;
+  for (auto &e : plan->tev) {
+    float ms = 0.f;
+    HIP_TRY(hipEventSynchronize(e.second));
+    HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+    *total_us += 1e3 * (double)ms;
+    ++*launches;
+  }
+  drop_timing(plan);
   return UNIRES_OK;
 }
 
@@ -1098,7 +1128,14 @@ static int cg_enqueue(unires_plan *pl, float rho, float lam, const float *b, flo
   static const bool fold_on = getenv("UNIRES_CG_FOLD") && getenv("UNIRES_CG_FOLD")[0] == '1';
   const int gf = vec_num_blocks_fold(ny);
   for (int k = 1; k <= max_iter; ++k) {
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (pl->timing && hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
+      (void)hipEventRecord(ev0, st);
     const int g = matvec(pl, rho, lam, pl->p, pl->ap, pl->part0, done, st);
+    if (ev0 && ev1) {
+      (void)hipEventRecord(ev1, st);
+      pl->tev.emplace_back(ev0, ev1);
+    }
     const bool recur = check && stop_mode == UNIRES_STOP_MAXGAIN_RECURRED;
     int obj_kind = 0;
     if (check && stop_mode == UNIRES_STOP_RESIDUAL) obj_kind = 1;
@@ -1156,7 +1193,7 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
   unires_plan::CgKey key;
   key.b = b, key.x = x, key.rho = rho, key.lam = lam, key.max_iter = max_iter, key.stop = stop_mode;
   key.pre = precond_mode, key.tol = tol;
-  const bool graphable = use_graph && !fft && max_iter > 0;
+  const bool graphable = use_graph && !fft && max_iter > 0 && !pl->timing;  // (events go with plain launches)
   if (graphable && pl->cg_exec && pl->cg_key == key) {
     HIP_TRY(hipGraphLaunch(pl->cg_exec, st));
   } else {
