@@ -41,6 +41,9 @@ constexpr int kS2Waves = 4;   // waves (= independent tiles in flight) per workg
 constexpr int kS2MaxSeg = 8;  // segments per instruction
 
 #define S2_FENCE() asm volatile("" ::: "memory")
+#ifndef S2_INTERLEAVE
+#define S2_INTERLEAVE 1
+#endif
 // phase-ablation switches: compiled in only with -DUNIRES_ABLATE (then UNIRES_S2_DBG selects bits:
 // 1 no splat, 2 no epilogue, 4 no LDS updates, 8 no source loads); product builds carry none of it
 #ifdef UNIRES_ABLATE
@@ -244,6 +247,20 @@ __global__ void __launch_bounds__(kWave)
     for (int s = 0; s < nseg; ++s) ++cnt[seg_pos(segs[s]) + 1];
     for (int i = 0; i < 32; ++i) cnt[i + 1] += cnt[i];
     for (int s = 0; s < nseg; ++s) order[cnt[seg_pos(segs[s])]++] = (unsigned short)s;
+#if S2_INTERLEAVE
+    // ... offered to the first-fit below as 0, h, 1, h + 1, ... (h = half the count).  Most segments are
+    // whole rows of the tile's ~9 x 5 cross-section - one per 32-lane half - and two rows share an
+    // instruction only if they are >= row_sep apart: in scan order a row's successors are its
+    // neighbours, the partner had to be found among rows offered much later, and the last ones found
+    // none (26 instructions per config-3 tile for 44 segments).  Offered in this order the row half the
+    // cross-section away - 4 to 5 rows over - comes right behind its partner.
+    {
+      unsigned short tmp[kSegs];
+      const int h = (nseg + 1) / 2;
+      for (int s = 0; s < nseg; ++s) tmp[s] = order[s];
+      for (int s = 0; s < nseg; ++s) order[s] = tmp[(s & 1) ? h + (s >> 1) : (s >> 1)];
+    }
+#endif
   }
   S2_FENCE();
   __syncthreads();
