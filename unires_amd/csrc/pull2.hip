@@ -564,6 +564,27 @@ int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd,
                      Q.rec);
   Q.tol = tol;
   if (hipDeviceSynchronize() != hipSuccess) return 1;
+  static const bool verbose = getenv("UNIRES_PULL2_VERBOSE") != nullptr;
+  if (verbose) {  // one line per plan: what the workgroups of this operator look like
+    std::vector<int> rec((size_t)nblk * kP2Rec);
+    if (hipMemcpy(rec.data(), Q.rec, rec.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
+      long long empty = 0, masked = 0, slow = 0, partial = 0;
+      double groups = 0.0;
+      for (long long b = 0; b < nblk; ++b) {
+        const int *r = rec.data() + (size_t)b * kP2Rec;
+        const bool e = (r[3] & 1) != 0;
+        empty += e;
+        if (e) continue;
+        masked += r[2] == 0, slow += (r[3] & 2) == 0, partial += (r[3] & 4) != 0, groups += r[1];
+      }
+      fprintf(stderr,
+              "[pull2] %lld workgroups (%d x %d rows, %d chunks along z of %d windows), window %d x %d columns x %d planes; "
+              "%lld all outside the field of view, of the rest %lld with the FOV mask, %lld staging with x / y range tests, "
+              "%lld with a partial last plane group, %.1f of %d plane groups staged on average\n",
+              nblk, G.pi, G.pj, G.nbc, G.m, W, H, kP2SZ, empty, masked, slow, partial,
+              groups / (double)std::max<long long>(1, nblk - empty), kP2SZ4);
+    }
+  }
   static_assert(sizeof(P2Geom) <= sizeof(Q.key), "PullPlan key too small");
   memset(Q.key, 0, sizeof(Q.key));
   memcpy(Q.key, &G, sizeof(G));
