@@ -30,6 +30,11 @@ CASES = {
     # x-space z extent a multiple of 4: the 16-byte 1-D passes, and the fused x-y pass of the hybrid path
     'sr_iso2_z8': dict(dim_y=(18, 14, 16), n_channels=2, thick=2, regime='sr', iso=True, scl=0.1),
     'sr_iso3_z8': dict(dim_y=(15, 18, 24), n_channels=1, thick=3, regime='sr', iso=True, rot=0.02),
+    # 6 mm slices along z, 11 and 21 of them: the window pull takes 11 conv windows per chunk instead of
+    # the 10 its 64 lanes hold (one chunk instead of two, two instead of three) and samples the three grid
+    # points per row beyond the lanes in a pass of their own
+    'sr_thick6_z66': dict(dim_y=(14, 12, 66), n_channels=2, thick=6, regime='sr', thick_axes=[2, 2], scl=0.1),
+    'sr_thick6_z126': dict(dim_y=(10, 9, 126), n_channels=1, thick=6, regime='sr', thick_axes=[2], rot=0.03),
     'sr_aligned': dict(dim_y=(16, 14, 24), n_channels=2, thick=3, regime='sr', thick_axes=[2, 2], rot=0.0,
                        trans=0.0, scl=0.1),
     # translated by a fraction of a voxel, not rotated: the factorised one-kernel matvec (shift.hip); nz % 4 == 0

@@ -51,6 +51,8 @@ constexpr int kP2Items = 10;                    // 16-byte window pieces staged 
 #endif
 constexpr int kP2TI = UNIRES_P2_TI, kP2TJ = UNIRES_P2_TJ;  // grid rows per workgroup (profile along z only)
 constexpr int kP2Rows = 64;                     // ... and at most, in any layout
+constexpr int kP2Scr = kWave + 9;               // floats per row of the z-only conv scratch (64 lanes + <= 8 extras, odd)
+constexpr int kP2MaxExt = 8;                    // extras per row at most (8 rows per wave x 8 = one pass of 64 lanes)
 #ifndef UNIRES_P2_BAND
 #define UNIRES_P2_BAND 4
 #endif
@@ -60,6 +62,11 @@ struct P2Geom {
   Affine A;
   Dim3i sd, gd;
   int sk, m;         // stride along grid z, conv windows (x-space voxels) per chunk
+  // grid points a chunk samples: (m - 1) sk + taps.  <= 64: one per lane.  A z-only profile may take ONE
+  // window more than 64 lanes hold where that saves a chunk (config 3: 42 slices = 11 + 11 + 11 + 9
+  // instead of 10 + 10 + 10 + 10 + 2): the span - 64 <= 8 points beyond the lanes ("extras", 3 for 7 taps
+  // at stride 6) of a wave's 8 rows are sampled together in one more pass, lane = (row, extra).
+  int span;
   int nbj, nbc;      // workgroups along j and chunks along z (block = (bi * nbj + bj) * nbc + bc)
   // rows of a workgroup: pi x pj grid rows = what oi x oj x-space rows need (stride si / sj,
   // ni / nj taps along x / y; 8 x 8 rows, strides 1, when the profile runs along z only)
@@ -83,7 +90,7 @@ __global__ void k_pull2_plan(P2Geom G, int nblk, float tol, int W, int H, int *_
   const int i0 = bi * G.oi * G.si, j0 = bj * G.oj * G.sj;
   const int i1 = min(i0 + G.pi, G.gd.x) - 1, j1 = min(j0 + G.pj, G.gd.y) - 1;
   const int k0 = bc * G.m * G.sk;
-  const int npts = min(kWave, G.gd.z - k0);
+  const int npts = min(max(kWave, G.span), G.gd.z - k0);
   // z extent of the workgroup's samples: 8 vertices of the (i, j, k) box
   float zmin = 1e30f, zmax = -1e30f;
   bool inside = true;  // every sample has all 8 corners inside the volume (no FOV mask needed)
@@ -169,7 +176,7 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   if (pw && threadIdx.x == 0) pw[0] = wall_clock64(), pw[4] = __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4);
 #endif
   constexpr int SZ = kP2SZ, SZ4 = kP2SZ4, NW = kBlock / kWave, TI = kP2TI, TJ = kP2TJ;
-  constexpr int ROWS = GEN ? kP2Rows : TI * TJ, RPW = ROWS / NW, SCR = kWave + 1;
+  constexpr int ROWS = GEN ? kP2Rows : TI * TJ, RPW = ROWS / NW, SCR = GEN ? kWave + 1 : kP2Scr;
   constexpr int HALF = RPW % 8 == 0 ? 8 : (RPW % 6 == 0 ? 6 : 4);
   static_assert(TI * TJ <= kP2Rows && ROWS % NW == 0 && RPW % HALF == 0, "rows per wave");
   extern __shared__ __align__(16) float win[];  // W * H columns x SZ planes
@@ -332,6 +339,35 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   // workgroup meets once and the rows go through the conv in a scratch that ALIASES the window -
   // dead by then: no LDS of its own for the scratch (it was 8.3 KB, 16.6 KB with profiles along x / y),
   // so a fifth workgroup fits a CU where the window is <= 32 KB.
+  // one sample: the trilinear value of p at grid point (i, j, kfv), from the window (masked by the field
+  // of view where the workgroup is not wholly inside)
+  auto sample = [&](auto i, auto j, float kfv) {
+    const RowBase rb = affine_row(G.A, (float)i, (float)j);
+    const float gx = fmaf(c0, kfv, rb.x) + t0, gy = fmaf(c1, kfv, rb.y) + t1, gz = fmaf(c2, kfv, rb.z) + t2;
+    const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+    const float wx = gx - fx, wy = gy - fy, wz = gz - fz;
+    const int zl = (int)(fz - fZ0);
+    const int xy = (int)fmaf(fx, (float)(H * SZ), fy * (float)SZ);
+    const int a0 = xy + zl + tab[zl >> 2], a1 = xy + zl + 1 + tab[(zl + 1) >> 2];
+    float v = 0.f;
+    if (!(P.dbg & 2)) {
+      // the four ds_read2_b32 return (y, y + 1) pairs: the z interpolation runs on the pairs as they
+      // come (v_pk_add_f32 / v_pk_fma_f32, no register shuffles), y and x on scalars
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      const v2f P0 = {win[a0], win[a0 + SZ]}, R0 = {win[a0 + H * SZ], win[a0 + (H + 1) * SZ]};
+      const v2f P1 = {win[a1], win[a1 + SZ]}, R1 = {win[a1 + H * SZ], win[a1 + (H + 1) * SZ]};
+      const v2f wz2 = {wz, wz};
+      const v2f Q0 = __builtin_elementwise_fma(wz2, P1 - P0, P0), Q1 = __builtin_elementwise_fma(wz2, R1 - R0, R0);
+      const float q0 = fmaf(wy, Q0.y - Q0.x, Q0.x), q1 = fmaf(wy, Q1.y - Q1.x, Q1.x);
+      v = fmaf(wx, q1 - q0, q0);
+    }
+    if (!inside) {  // zero bound comes from the zero-filled window; the in-FOV mask is explicit
+      const bool in = gx > -P.tol && gx < bx + P.tol && gy > -P.tol && gy < by + P.tol && gz > -P.tol &&
+                      gz < bz + P.tol;
+      v = in ? v : 0.f;
+    }
+    return v;
+  };
   float hvall[RPW];
 #pragma unroll
   for (int h0 = 0; h0 < RPW; h0 += HALF) {
@@ -342,34 +378,24 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
       const int rr = GEN ? min(row, nrows - 1) : row;  // (rows past the layout replay the last one)
       const int i = min(i0 + (GEN ? (int)rowi[rr] : row / TJ), G.gd.x - 1),
                 j = min(j0 + (GEN ? (int)rowj[rr] : row % TJ), G.gd.y - 1);
-      const RowBase rb = affine_row(G.A, (float)i, (float)j);
-      const float gx = fmaf(c0, kf, rb.x) + t0, gy = fmaf(c1, kf, rb.y) + t1, gz = fmaf(c2, kf, rb.z) + t2;
-      const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
-      const float wx = gx - fx, wy = gy - fy, wz = gz - fz;
-      const int zl = (int)(fz - fZ0);
-      const int xy = (int)fmaf(fx, (float)(H * SZ), fy * (float)SZ);
-      const int a0 = xy + zl + tab[zl >> 2], a1 = xy + zl + 1 + tab[(zl + 1) >> 2];
-      float v = 0.f;
-      if (!(P.dbg & 2)) {
-        // the four ds_read2_b32 return (y, y + 1) pairs: the z interpolation runs on the pairs as they
-        // come (v_pk_add_f32 / v_pk_fma_f32, no register shuffles), y and x on scalars
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        const v2f P0 = {win[a0], win[a0 + SZ]}, R0 = {win[a0 + H * SZ], win[a0 + (H + 1) * SZ]};
-        const v2f P1 = {win[a1], win[a1 + SZ]}, R1 = {win[a1 + H * SZ], win[a1 + (H + 1) * SZ]};
-        const v2f wz2 = {wz, wz};
-        const v2f Q0 = __builtin_elementwise_fma(wz2, P1 - P0, P0), Q1 = __builtin_elementwise_fma(wz2, R1 - R0, R0);
-        const float q0 = fmaf(wy, Q0.y - Q0.x, Q0.x), q1 = fmaf(wy, Q1.y - Q1.x, Q1.x);
-        v = fmaf(wx, q1 - q0, q0);
-      }
-      if (!inside) {  // zero bound comes from the zero-filled window; the in-FOV mask is explicit
-        const bool in = gx > -P.tol && gx < bx + P.tol && gy > -P.tol && gy < by + P.tol && gz > -P.tol &&
-                        gz < bz + P.tol;
-        v = in ? v : 0.f;
-      }
+      const float v = sample(i, j, kf);
       hv[r] = lane < npts ? v : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < HALF; ++r) hvall[h0 + r] = hv[r];
+  }
+  // the chunk's grid points beyond the 64 lanes (extended chunks only): lane = (row of this wave, extra)
+  const int next = GEN ? 0 : max(0, min(G.span, G.gd.z - k0) - kWave);
+  float hx = 0.f;
+  int xrow = 0, xcol = 0;
+  bool xact = false;
+  if (!GEN && next > 0) {
+    const int r = (int)(((float)lane + 0.5f) / (float)next), t = lane - r * next;
+    xact = r < RPW;
+    xrow = wave * RPW + min(r, RPW - 1), xcol = kWave + t;
+    const int i = min(i0 + xrow / TJ, G.gd.x - 1), j = min(j0 + xrow % TJ, G.gd.y - 1);
+    const float v = sample(i, j, (float)(k0 + kWave + t));
+    hx = xact ? v : 0.f;
   }
   float (*scr)[SCR] = reinterpret_cast<float (*)[SCR]>(win);
   if (P.dbg & 4) {
@@ -390,6 +416,7 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
     __syncthreads();  // every wave is done with the window; the scratch rows below are wave-private
 #pragma unroll
     for (int r = 0; r < RPW; ++r) scr[wave * RPW + r][lane] = hvall[r];
+    if (xact) scr[xrow][xcol] = hx;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int it = lane; it < RPW * G.m; it += kWave) {
       const int r = (int)(((float)it + 0.5f) * inv_m), win_i = it - __mul24(r, G.m);  // exact: it < 2^20
@@ -481,6 +508,7 @@ static bool p2_geometry(Dim3i sd, const Affine &A, const Taps &T, const Scaling 
   G.si = T.s[0], G.sj = T.s[1], G.ni = T.n[0], G.nj = T.n[1];
   G.sk = T.s[2];
   G.m = (kWave - T.n[2]) / T.s[2] + 1;  // whole conv windows inside 64 grid points
+  G.span = (G.m - 1) * T.s[2] + T.n[2];
   const bool zonly = T.n[0] == 1 && T.s[0] == 1 && T.n[1] == 1 && T.s[1] == 1;
   // rows of a workgroup: the (oi, oj) with the most x-space rows per sampled grid row whose window
   // fits; window extents = span of the rows over a plane group (z in [Zg - 1, Zg + 4)), + floor, +
@@ -494,7 +522,8 @@ static bool p2_geometry(Dim3i sd, const Affine &A, const Taps &T, const Scaling 
     int hn;
     extents(pi, pj, w, hn);
     // z planes: span of gz over the workgroup + floor + upper corner + alignment of Z0 to 4
-    const double ez = (pi - 1) * fabs((double)A.m[8]) + (pj - 1) * fabs((double)A.m[9]) + 63.0 * fabs(a22) + 0.05;
+    const double ez = (pi - 1) * fabs((double)A.m[8]) + (pj - 1) * fabs((double)A.m[9]) +
+                      (double)(std::max(G.span, (int)kWave) - 1) * fabs(a22) + 0.05;
     if ((int)floor(ez) + 2 + 3 + 1 > kP2SZ) return false;
     if (w > 24 || hn > 16) return false;
     h = hn <= 10 ? 10 : (hn <= 12 ? 12 : 16);
@@ -503,7 +532,19 @@ static bool p2_geometry(Dim3i sd, const Affine &A, const Taps &T, const Scaling 
   };
   if (zonly) {
     G.pi = G.oi = kP2TI, G.pj = G.oj = kP2TJ;
-    if (!fits(G.pi, G.pj, W, H)) return false;
+    // one window more per chunk where that saves a chunk and the taller window still fits
+    static const bool ext_ok = !(getenv("UNIRES_P2_EXT") && atoi(getenv("UNIRES_P2_EXT")) == 0);
+    const int m0 = G.m, span0 = G.span, span1 = m0 * T.s[2] + T.n[2];
+    bool ext = ext_ok && !(T.n[2] == 1 && T.s[2] == 1) && span1 - kWave <= kP2MaxExt &&
+               (xd.z + m0) / (m0 + 1) < (xd.z + m0 - 1) / m0;
+    if (ext) {
+      G.m = m0 + 1, G.span = span1;
+      ext = fits(G.pi, G.pj, W, H);
+    }
+    if (!ext) {
+      G.m = m0, G.span = span0;
+      if (!fits(G.pi, G.pj, W, H)) return false;
+    }
   } else {
     double best = 0.0;
     for (int oi = 1; oi <= 16; ++oi)
@@ -620,7 +661,8 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
   static const int dbg = getenv("UNIRES_P2_DBG") ? atoi(getenv("UNIRES_P2_DBG")) : 0;
   P.dbg = dbg;
   // the window, or the conv scratch that aliases it (64 rows x 65 floats) if that is larger
-  const size_t lds = std::max((size_t)W * H * kP2SZ, (size_t)kP2Rows * (kWave + 1)) * sizeof(float);
+  const size_t scratch = gen ? (size_t)kP2Rows * (kWave + 1) : (size_t)(kP2TI * kP2TJ) * kP2Scr;
+  const size_t lds = std::max((size_t)W * H * kP2SZ, scratch) * sizeof(float);
   const dim3 grid((unsigned)p2_blocks(P.G, xd)), block(kBlock);
   {
     const long long nbi = (long long)grid.x / ((long long)P.G.nbc * P.G.nbj);
