@@ -146,3 +146,29 @@ def test_update_y_reduces_objective():
                          prob['method'], prob['do_proj'], return_info=True)
     for n_it, obj in info:
         assert 1 <= n_it <= 20 and obj[-1] < obj[0]
+
+
+@pytest.mark.parametrize('fwhm', [1.5, 2.0, 3.0, 6.0])
+def test_slice_profiles_are_the_profile_convolved_with_the_linear_basis(fwhm):
+    """Independent of the restatement's own quadrature and of the closed form it uses for the
+    Gaussian (SPM's spm_smoothkern erf / exp expression): every tap of smooth1d equals the integral
+    of profile(t) * tri(x - t) computed by scipy.integrate.quad, after the same normalisation."""
+    import math
+    from scipy.integrate import quad
+    tri = lambda t: max(0.0, 1.0 - abs(t))
+    s2 = (fwhm / math.sqrt(8.0 * math.log(2.0))) ** 2
+    profiles = {0: (lambda t: (1.0 / fwhm) if abs(t) <= fwhm / 2 else 0.0, fwhm / 2),
+                1: (lambda t: tri(t / fwhm) / fwhm, fwhm),
+                2: (lambda t: math.exp(-0.5 * t * t / s2) / math.sqrt(2.0 * math.pi * s2), 12.0 * math.sqrt(s2))}
+    for kind, (prof, reach) in profiles.items():
+        ker = N.smooth1d(kind, fwhm)
+        L = (len(ker) - 1) // 2
+        ref = []
+        for x in range(-L, L + 1):
+            lo, hi = max(-reach, x - 1.0), min(reach, x + 1.0)
+            pts = sorted({p for p in (-fwhm / 2, fwhm / 2, 0.0, float(x), -reach, reach) if lo < p < hi})
+            ref.append(quad(lambda t: prof(t) * tri(x - t), lo, hi, points=pts or None, epsabs=1e-13, epsrel=1e-12)[0]
+                       if hi > lo else 0.0)
+        tot = sum(ref)
+        for a, b in zip(ker, ref):
+            assert abs(a - b / tot) < 2e-9, (kind, fwhm)
