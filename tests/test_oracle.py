@@ -172,3 +172,52 @@ def test_slice_profiles_are_the_profile_convolved_with_the_linear_basis(fwhm):
         tot = sum(ref)
         for a, b in zip(ker, ref):
             assert abs(a - b / tot) < 2e-9, (kind, fwhm)
+
+
+def test_cg_iterates_are_those_of_scipy_cg_and_converge_to_the_solve():
+    """The restated cg against code that shares nothing with it: after k iterations its x equals the
+    k-th iterate of scipy.sparse.linalg.cg (same Krylov recurrences, float64) and after enough of them
+    numpy's direct solve; the preconditioned form agrees with scipy's M argument."""
+    import numpy as np
+    from scipy.sparse.linalg import cg as scipy_cg
+    rng = np.random.default_rng(3)
+    n = 40
+    Q = rng.standard_normal((n, n))
+    A = Q @ Q.T + n * np.eye(n)
+    b = rng.standard_normal(n)
+    d = np.diag(A).copy()
+    At, bt = torch.tensor(A), torch.tensor(b)
+    for use_pre in (False, True):
+        for k in (1, 3, 7):
+            its = []
+            scipy_cg(A, b, x0=np.zeros(n), maxiter=k, rtol=0.0, atol=0.0,
+                     M=np.diag(1.0 / d) if use_pre else None, callback=lambda xk: its.append(xk.copy()))
+            x = N.cg(lambda v: At @ v, bt, torch.zeros(n, dtype=torch.float64), max_iter=k, tolerance=0,
+                     precond=(lambda r: r / torch.tensor(d)) if use_pre else (lambda r: r))
+            assert len(its) == k
+            assert np.abs(x.numpy() - its[-1]).max() < 1e-12
+        x = N.cg(lambda v: At @ v, bt, torch.zeros(n, dtype=torch.float64), max_iter=80, tolerance=0,
+                 precond=(lambda r: r / torch.tensor(d)) if use_pre else (lambda r: r))
+        assert np.abs(x.numpy() - np.linalg.solve(A, b)).max() < 1e-10
+
+
+def test_grid_grad_is_the_derivative_of_grid_sample():
+    """The restated grid_grad (what the rigid Gauss-Newton differentiates through,
+    unires/_update.py:508) against autograd through torch's own trilinear sampler: d pull / d g in voxel
+    coordinates = d grid_sample / d g_normalised * 2 / (n - 1), away from the volume's faces where
+    padding and the FOV mask enter."""
+    torch.manual_seed(4)
+    dim = (9, 11, 13)
+    y = torch.rand((1, 1) + dim, dtype=torch.float64)
+    M = rigid_matrix([0.4, -0.3, 0.6], [0.05, -0.04, 0.03])
+    g = N.affine_grid(M, (6, 7, 8))[None].clone()
+    g = g.clamp(min=0.3)  # keep every sample strictly inside
+    for d, n in enumerate(dim):
+        g[..., d] = g[..., d].clamp(max=n - 1.3)
+    g = g + 1e-3  # off the integer lattice: the derivative of a trilinear sample jumps there
+    g.requires_grad_(True)
+    gn = torch.stack([2 * g[..., 2] / (dim[2] - 1) - 1, 2 * g[..., 1] / (dim[1] - 1) - 1,
+                      2 * g[..., 0] / (dim[0] - 1) - 1], -1)
+    F.grid_sample(y, gn, mode='bilinear', padding_mode='zeros', align_corners=True).sum().backward()
+    ours = N.grid_grad(y, g.detach())[0, 0]
+    assert (ours - g.grad[0]).abs().max() < 1e-10
