@@ -156,6 +156,14 @@ int unires_plan_destroy(unires_plan_t *plan);
 int unires_plan_set_repeat(unires_plan_t *plan, int32_t n, const unires_repeat_t *repeat);
 /* Bytes of device workspace the plan owns. */
 int64_t unires_plan_workspace_bytes(const unires_plan_t *plan);
+/* Which kernels repeat n's operator runs on (no counterpart in the reference, whose _proj_apply
+ * takes any mat_x through a dense grid, _project.py:147-159; here the plan relabels the observation's
+ * voxel axes so that sagittal / coronal / reflected storage takes the same kernels as axial).
+ * info[0..2] = caller's voxel axis behind canonical axis 0..2, info[3] = bit j set where canonical axis
+ * j is reversed, info[4] = 1 if the LDS-window pull serves it, info[5] = 0 if the schedule-driven
+ * splat does not serve it, else 2 + its conv_up axis (1: grid-space source, 2..4: along x / y / z, 5: all), info[6] = 1 if the translation-only one-kernel
+ * matvec serves it, info[7] = 1 if the convolutions run as separable passes. */
+int unires_plan_repeat_info(const unires_plan_t *plan, int32_t n, int32_t info[8]);
 /* Measurement aid (no counterpart in the reference; bench.py's roofline leg).  While on,
  * unires_cg_solve launches its kernels one by one (no hipGraph replay) and brackets every operator
  * application A(p) of the solve with HIP events on the caller's stream. */

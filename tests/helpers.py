@@ -22,6 +22,24 @@ def rigid_matrix(t, r):
     return M
 
 
+def orient_axes(dim, mat, perm, flip):
+    """The same acquisition STORED with its voxel axes permuted / reversed (sagittal or coronal
+    storage, LAS vs RAS): new voxel axis a is old axis perm[a], reversed where flip[a].  Returns the
+    stored dims and affine (mat @ Q, Q mapping stored to old voxel coordinates) - what
+    ``_read_image`` hands the reference as it is (unires/_util.py:134-197)."""
+    Q = torch.zeros((4, 4), dtype=torch.float64)
+    Q[3, 3] = 1.0
+    for a in range(3):
+        Q[perm[a], a] = -1.0 if flip[a] else 1.0
+        if flip[a]:
+            Q[perm[a], 3] = dim[perm[a]] - 1
+    return tuple(int(dim[perm[a]]) for a in range(3)), mat @ Q
+
+
+SIGNED_PERMS = [(p, f) for p in ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))
+                for f in ((0, 0, 0), (0, 0, 1), (0, 1, 0), (0, 1, 1), (1, 0, 0), (1, 0, 1), (1, 1, 0), (1, 1, 1))]
+
+
 def rel_err(a, b):
     a, b = a.double(), b.double()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
@@ -52,13 +70,21 @@ def fov_margin(po, method):
 
 def make_problem(dim_y=(16, 14, 12), n_channels=1, thick=3, seed=0, scl=0.0, regime='sr',
                  n_repeats=1, vx_y=1.0, rot=0.05, trans=0.7, noise_sd=20.0, prof_tp=0,
-                 prof_ip=0, thick_axes=None, aniso=None, iso=False):
+                 prof_ip=0, thick_axes=None, aniso=None, iso=False, orient=None):
     """A synthetic multi-channel y-update problem.
 
     regime 'sr': thick-slice observations (ratio ``thick`` along a per-channel axis),
     'dn': same-resolution observations with a rigid misalignment (pull/push only),
     'id': do_proj False (A = I).
+    ``orient``: per (channel, repeat) index c * n_repeats + n (cycled), a (perm, flip) pair: the
+    observation is stored with its voxel axes permuted / reversed (``orient_axes``).
     """
+    def stored(c, n, dim, mat):
+        if orient is None:
+            return dim, mat
+        perm, flip = orient[(c * n_repeats + n) % len(orient)]
+        return orient_axes(dim, mat, perm, flip)
+
     gen = torch.Generator().manual_seed(seed)
     mat_y = torch.diag(torch.tensor([vx_y, vx_y, vx_y, 1.0], dtype=torch.float64))
     if aniso is not None:
@@ -82,12 +108,14 @@ def make_problem(dim_y=(16, 14, 12), n_channels=1, thick=3, seed=0, scl=0.0, reg
                         sc_ = [float(v) for v in iso] if isinstance(iso, (tuple, list)) else [float(thick)] * 3
                     mx_ = mat_y @ torch.diag(torch.tensor(sc_ + [1.0], dtype=torch.float64))
                     dx_ = tuple(int(math.floor(d / s_)) for d, s_ in zip(dim_y, sc_))
+                    dx_, mx_ = stored(c, n, dx_, mx_)
                     po_ = O.proj_info(dim_y, mat_y, dx_, mx_, rigid=rigid, prof_ip=prof_ip,
                                       prof_tp=prof_tp)
                     if fov_margin(po_, 'super-resolution') > 1e-4:
                         break
                 else:
-                    po_ = O.proj_info(dim_y, mat_y, dim_y, mat_y, rigid=rigid)
+                    dx_, mx_ = stored(c, n, tuple(dim_y), mat_y)
+                    po_ = O.proj_info(dim_y, mat_y, dx_, mx_, rigid=rigid)
                     if fov_margin(po_, 'denoising') > 1e-4:
                         break
             if regime == 'sr':
@@ -99,11 +127,12 @@ def make_problem(dim_y=(16, 14, 12), n_channels=1, thick=3, seed=0, scl=0.0, reg
                 D = torch.diag(torch.tensor(scale + [1.0], dtype=torch.float64))
                 mat_x = mat_y @ D
                 dim_x = tuple(int(math.floor(d / s)) for d, s in zip(dim_y, scale))
+                dim_x, mat_x = stored(c, n, dim_x, mat_x)
                 po = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=prof_ip,
                                  prof_tp=prof_tp, scl=scl)
                 method = 'super-resolution'
             elif regime == 'dn':
-                mat_x, dim_x = mat_y.clone(), tuple(dim_y)
+                dim_x, mat_x = stored(c, n, tuple(dim_y), mat_y.clone())
                 po = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid)
                 method = 'denoising'
             else:

@@ -47,7 +47,13 @@ CASES = {
     'dn_2rep': dict(dim_y=(12, 12, 10), n_channels=1, regime='dn', n_repeats=2),
     'id_1ch': dict(dim_y=(18, 17, 13), n_channels=1, regime='id'),
     'id_2rep': dict(dim_y=(9, 8, 70), n_channels=2, regime='id', n_repeats=2),
-
+    # observations STORED sagittally / coronally / reflected (voxel axes a signed permutation of the world's:
+    # what a NIfTI file hands the reference as it is, _util.py:134-197); tests/test_gpu_orient.py sweeps all 48
+    'sr_orient': dict(dim_y=(18, 16, 14), n_channels=2, thick=3, regime='sr', scl=0.05, n_repeats=2,
+                      orient=[((2, 0, 1), (1, 0, 0)), ((1, 2, 0), (0, 1, 1)), ((0, 1, 2), (1, 0, 0)),
+                              ((2, 1, 0), (0, 0, 1))]),
+    'dn_orient': dict(dim_y=(15, 13, 11), n_channels=2, regime='dn', rot=0.1, trans=1.5,
+                      orient=[((1, 0, 2), (0, 0, 0)), ((2, 0, 1), (1, 1, 1))]),
 }
 
 
@@ -313,7 +319,7 @@ MANY_CHANNELS = {
 }
 
 
-@pytest.mark.parametrize('case', ['sr_3ch_axes', 'dn_2ch', 'id_2rep', 'sr_aniso', 'id_11ch', 'dn_17ch'])
+@pytest.mark.parametrize('case', ['sr_3ch_axes', 'dn_2ch', 'id_2rep', 'sr_aniso', 'id_11ch', 'dn_17ch', 'sr_orient', 'dn_orient'])
 @pytest.mark.parametrize('alpha', [1.0, 1.5])
 def test_zw_update_and_objective_match_oracle(dev, case, alpha):
     """z/w updates and the objective, same inputs as the oracle."""
@@ -442,7 +448,7 @@ def test_aligned_kernel_agrees_with_general_kernels_at_256(dev, tmp_path):
                           rtol=1e-6)
 
 
-@pytest.mark.parametrize('case', ['sr_3ch_axes', 'sr_2rep', 'sr_aligned'])
+@pytest.mark.parametrize('case', ['sr_3ch_axes', 'sr_2rep', 'sr_aligned', 'sr_orient'])
 @pytest.mark.parametrize('n_ls', [0, 4])
 def test_update_scaling_matches_oracle(dev, case, n_ls):
     """SURVEY 8(f) next-3, even/odd slice-scaling Gauss-Newton (unires/_update.py:270-393):
@@ -536,7 +542,7 @@ def _rigid_setup(prob, dev, perturb=0.02):
     return xo, yo, xg, yg, sett, Bo
 
 
-@pytest.mark.parametrize('case', ['sr_3ch_axes', 'dn_2ch'])
+@pytest.mark.parametrize('case', ['sr_3ch_axes', 'dn_2ch', 'sr_orient', 'dn_orient'])
 def test_rigid_match_terms(dev, case):
     """_rigid_match (unires/_update.py:448-538): ll, gradient and Hessian volumes."""
     import unires_amd as U
@@ -563,7 +569,7 @@ def test_rigid_match_terms(dev, case):
         assert rel_err(gr_g.cpu(), gr_o) < 5e-5 and rel_err(H_g.cpu(), H_o) < 5e-5
 
 
-@pytest.mark.parametrize('case', ['sr_3ch_axes', 'dn_2ch', 'sr_2rep'])
+@pytest.mark.parametrize('case', ['sr_3ch_axes', 'dn_2ch', 'sr_2rep', 'sr_orient', 'dn_orient'])
 def test_update_rigid_matches_oracle(dev, case):
     """Unified rigid Gauss-Newton (unires/_update.py:198-266, 541-710): the oracle works in a
     different se(3) basis than the product - the rigid matrices and log-likelihoods agree."""

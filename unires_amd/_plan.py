@@ -101,11 +101,22 @@ class ChannelPlan:
     def workspace_bytes(self):
         return int(self.lib.unires_plan_workspace_bytes(self._h))
 
+    def repeat_info(self, n):
+        """Which kernels repeat n runs on and how its voxel axes were relabelled
+        (``unires_plan_repeat_info``): dict(perm, flip, pull2, splat2_axis, shift, separable)."""
+        info = (C.c_int32 * 8)()
+        check(self.lib.unires_plan_repeat_info(self._h, int(n), info))
+        v = list(info)
+        return dict(perm=tuple(v[:3]), flip=tuple((v[3] >> j) & 1 for j in range(3)), pull2=bool(v[4]),
+                    splat2_axis=None if v[5] == 0 else v[5] - 2, shift=bool(v[6]), separable=bool(v[7]))
+
+    @on_device
     def time_matvecs(self, on=True):
         """Measurement aid: bracket every operator application of the following solves with HIP events
         (the solves then run as plain launches, not as a hipGraph)."""
         check(self.lib.unires_plan_time_matvecs(self._h, 1 if on else 0))
 
+    @on_device
     def matvec_time(self):
         """(launches, total microseconds) recorded since the last call; waits for them."""
         n, us = C.c_int32(0), C.c_double(0.0)

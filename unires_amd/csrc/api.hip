@@ -18,6 +18,7 @@
 #include "fftpre.hpp"
 #include "fused.hpp"
 #include "ops.hpp"
+#include "orient.hpp"
 #include "pull2.hpp"
 #include "shift.hpp"
 #include "splat2.hpp"
@@ -254,6 +255,12 @@ extern "C" int unires_dtd(const float *src, const int32_t dim[3], const float vx
 // plan
 // --------------------------------------------------------------------------
 struct Repeat {
+  // Everything below is in the plan's CANONICAL voxel layout of the observation: x-space axis d runs
+  // mainly along +d of the output (orient.hpp).  `orient` maps it to the caller's layout, `dim_xu`
+  // are the caller's x-space dims; only 'A' outputs and 'At' / RHS inputs are ever re-ordered.
+  Orient orient;
+  bool oriented = false;
+  Dim3i dim_xu;
   Dim3i dim_x, dim_g;
   Affine A;
   Taps T;
@@ -308,6 +315,7 @@ struct unires_plan {
   float *gbuf = nullptr;                                           // max N_g
   float *gbuf2 = nullptr;  // second grid-space scratch, only for many-tap profiles (separable passes)
   float *xbuf = nullptr;                                           // max N_x
+  float *xperm = nullptr;  // max N_x: an x-space volume on its way between the caller's layout and the canonical one
   double *part0 = nullptr, *part1 = nullptr;                       // kMaxPartials each
   CgState *state = nullptr;
   size_t cap_g = 0, cap_x = 0;
@@ -346,6 +354,47 @@ static void drop_cg_graph(unires_plan *pl) {
   pl->cg_exec = nullptr;
 }
 
+// Relabel the observation's voxel axes so that grid axis d runs mainly along +d of the output
+// (orient.hpp).  With u[perm[j]] = flip[j] ? n[perm[j]] - 1 - u'[j] : u'[j] on the grid and on x-space
+// alike: columns of A permuted and negated, the translation moved to the far end of a reversed axis
+// (composed in double from the float32 entries the reference's grid is made of, rounded once); dims,
+// strides and taps permuted; the taps of a reversed axis reversed - x[k] = sum_t ker[t] g[r k + t] with
+// n_g = (n_x - 1) r + K reads x'[k'] = sum_t ker[K - 1 - t] g'[r k' + t] - and the even / odd slice
+// factors swapped where reversal changes the parity of a slice index (n_x even).
+static void canonicalise(Repeat &R) {
+  static const bool off = getenv("UNIRES_NO_CANON") != nullptr;  // (measurement: the r3 behaviour)
+  R.orient = off ? Orient() : orient_of(R.A);
+  R.oriented = !R.orient.identity();
+  if (!R.oriented) return;
+  const Orient &O = R.orient;
+  const int nx[3] = {R.dim_x.x, R.dim_x.y, R.dim_x.z}, ng[3] = {R.dim_g.x, R.dim_g.y, R.dim_g.z};
+  const Affine A = R.A;
+  const Taps T = R.T;
+  int cx[3], cg[3];
+  double t[3] = {A.m[3], A.m[7], A.m[11]};
+  for (int j = 0; j < 3; ++j) {
+    const int a = O.perm[j];
+    cx[j] = nx[a], cg[j] = ng[a];
+    for (int r = 0; r < 3; ++r) {
+      R.A.m[4 * r + j] = O.flip[j] ? -A.m[4 * r + a] : A.m[4 * r + a];
+      if (O.flip[j]) t[r] += (double)(ng[a] - 1) * (double)A.m[4 * r + a];
+    }
+    R.T.n[j] = T.n[a], R.T.s[j] = T.s[a];
+    for (int i = 0; i < UNIRES_MAX_TAPS; ++i)
+      R.T.t[j][i] = i < T.n[a] ? (O.flip[j] ? T.t[a][T.n[a] - 1 - i] : T.t[a][i]) : 0.f;
+  }
+  for (int r = 0; r < 3; ++r) R.A.m[4 * r + 3] = (float)t[r];
+  R.dim_x = Dim3i{cx[0], cx[1], cx[2]};
+  R.dim_g = Dim3i{cg[0], cg[1], cg[2]};
+  if (R.dim_thick >= 0 && R.dim_thick <= 2) {
+    int jt = 0;
+    for (int j = 0; j < 3; ++j)
+      if (O.perm[j] == R.dim_thick) jt = j;
+    if (O.flip[jt] && (nx[R.dim_thick] & 1) == 0) R.scl = -R.scl;
+    R.dim_thick = jt;
+  }
+}
+
 static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat &out) {
   if (!in) return fail(UNIRES_ERR_NULL, "null repeat descriptor");
   if (!(in->tau > 0.f)) return fail(UNIRES_ERR_ARG, "tau must be positive");
@@ -353,12 +402,13 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
   out.sched = SplatSched();
   out.pplan = PullPlan();
   out.shift = ShiftPlan();
+  out.orient = Orient();
   out.ctab_step = 1;
   out.tau = in->tau;
   out.scl = in->scl;
   out.dim_thick = in->dim_thick;
   if (pl->regime == UNIRES_REGIME_IDENTITY) {
-    out.dim_x = pl->dy;
+    out.dim_x = out.dim_xu = pl->dy;
     out.dim_g = pl->dy;
     return UNIRES_OK;
   }
@@ -379,6 +429,8 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
       return fail(UNIRES_ERR_DIM, "denoising regime needs dim_g == dim_x");
     for (int d = 0; d < 3; ++d) out.T.n[d] = out.T.s[d] = 1, out.T.t[d][0] = 1.f;
   }
+  out.dim_xu = out.dim_x;
+  canonicalise(out);
   trim_taps(out.T, out.A, out.dim_g, out.Tf, out.Af, out.dim_gf);
   // many taps (e.g. a Gaussian in-plane profile on top of the slice profile): the fused kernels'
   // direct 3-D sum (prod n_d taps per output, fan-in^3 gathers per grid voxel) loses to one
@@ -605,7 +657,7 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
     return o;
   };
   const size_t o_r = carve(ny * 4), o_p = carve(ny * 4), o_ap = carve(ny * 4), o_ax = carve(ny * 4);
-  const size_t o_g = carve(pl->cap_g * 4), o_x = carve(pl->cap_x * 4);
+  const size_t o_g = carve(pl->cap_g * 4), o_x = carve(pl->cap_x * 4), o_xp = carve(pl->cap_x * 4);
   const size_t o_g2 = carve(need_sep ? pl->cap_g * 4 : 0);
   const size_t o_p0 = carve(kMaxPartials * 8), o_p1 = carve(kMaxPartials * 8);
   const size_t o_st = carve(sizeof(CgState));
@@ -622,6 +674,7 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
   pl->ax = (float *)(pl->ws + o_ax);
   pl->gbuf = (float *)(pl->ws + o_g);
   pl->xbuf = (float *)(pl->ws + o_x);
+  pl->xperm = (float *)(pl->ws + o_xp);
   pl->gbuf2 = need_sep ? (float *)(pl->ws + o_g2) : nullptr;
   pl->part0 = (double *)(pl->ws + o_p0);
   pl->part1 = (double *)(pl->ws + o_p1);
@@ -717,6 +770,20 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
 
 extern "C" int64_t unires_plan_workspace_bytes(const unires_plan_t *plan) {
   return plan ? (int64_t)plan->ws_bytes : 0;
+}
+
+extern "C" int unires_plan_repeat_info(const unires_plan_t *plan, int32_t n, int32_t info[8]) {
+  if (!plan || !info) return fail(UNIRES_ERR_NULL, "null argument");
+  if (n < 0 || n >= (int)plan->reps.size()) return fail(UNIRES_ERR_ARG, "repeat index");
+  const Repeat &R = plan->reps[n];
+  const bool id = plan->regime == UNIRES_REGIME_IDENTITY;
+  for (int j = 0; j < 3; ++j) info[j] = id ? j : R.orient.perm[j];
+  info[3] = id ? 0 : (R.orient.flip[0] | (R.orient.flip[1] << 1) | (R.orient.flip[2] << 2));
+  info[4] = R.pplan.valid ? 1 : 0;
+  info[5] = R.sched.valid ? 2 + R.sched.axis : 0;
+  info[6] = R.shift.valid ? 1 : 0;
+  info[7] = R.sep ? 1 : 0;
+  return UNIRES_OK;
 }
 
 // --------------------------------------------------------------------------
@@ -852,6 +919,10 @@ static void at_accumulate(unires_plan *pl, const Repeat &R, const float *x, floa
     launch_axpy(alpha, x, out, pl->dy.numel(), st);  // caller initialised out
     return;
   }
+  if (R.oriented) {  // the caller's voxel layout -> the plan's
+    launch_to_canonical(R.orient, x, R.dim_xu, pl->xperm, st);
+    x = pl->xperm;
+  }
   PushEpilogue ep;
   ep.accumulate = accumulate ? 1 : 0;
   const bool sr = pl->regime == UNIRES_REGIME_SUPERRES;
@@ -873,6 +944,8 @@ extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, con
     return UNIRES_OK;
   }
   if (op == UNIRES_OP_A) {
+    float *const out_user = out;
+    if (R.oriented) out = plan->xperm;  // canonical layout first, re-ordered into the caller's below
     if (plan->regime == UNIRES_REGIME_DENOISE) {
       if (launch_pull_conv2(R.pplan, in, plan->dy, R.A, R.T, Scaling{1.f, 1.f, -1}, out, R.dim_g, R.dim_g,
                             plan->fov_tol, nullptr, st))
@@ -892,6 +965,7 @@ extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, con
                          nullptr, st);
       }
     }
+    if (R.oriented) launch_from_canonical(R.orient, plan->xperm, out_user, R.dim_xu, st);
   } else if (op == UNIRES_OP_AT) {
     at_accumulate(plan, R, in, out, 1.f, false, st);
   } else {
