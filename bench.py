@@ -38,6 +38,13 @@ WORKLOADS = {
     # the same subject translated by a fraction of a voxel per channel, no rotation (shift.hip)
     'cfg3_256c3_thick6z_shift': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 2, 2), rigid='shift'),
     'cfg3_256c3_thick6xyz': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(0, 1, 2)),
+    # multi-orientation thick-slice scans as files carry them (the reference's motivating case; it takes
+    # mat_x as read, unires/_util.py:134-197): channel 0 axial, RAS order; channel 1 thick along world x,
+    # STORED sagittally (voxel axes = world y, z, x); channel 2 thick along world y, stored coronally with
+    # the first axis reversed (voxel axes = -x, z, y: LAS, det < 0).  orient[c] = (perm, flip): stored
+    # voxel axis a is axis perm[a] of the axis-aligned acquisition, reversed where flip[a]
+    'cfg3_256c3_thick6_orient': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 0, 1),
+                                     orient=(((0, 1, 2), (0, 0, 0)), ((1, 2, 0), (0, 0, 0)), ((0, 2, 1), (1, 0, 0)))),
     'cfg4_384c4_iso2': dict(dim_y=(384, 384, 384), C=4, thick=2, axes=None),
     # the same with the reference's default in-plane profile (Gaussian, struct.py:95; fan-in > 2)
     'cfg4_384c4_iso2_gauss': dict(dim_y=(384, 384, 384), C=4, thick=2, axes=None, prof_ip=2),
@@ -62,6 +69,18 @@ def rigid_matrix(t, r):
     M[:3, :3] = Rz @ Ry @ Rx
     M[:3, 3] = torch.tensor(t, dtype=torch.float64)
     return M
+
+
+def orient_axes(dim, mat, perm, flip):
+    """Dims and affine of the same acquisition stored with voxel axis a = old axis perm[a], reversed
+    where flip[a] (mat @ Q, Q mapping stored to old voxel coordinates)."""
+    Q = torch.zeros((4, 4), dtype=torch.float64)
+    Q[3, 3] = 1.0
+    for a in range(3):
+        Q[perm[a], a] = -1.0 if flip[a] else 1.0
+        if flip[a]:
+            Q[perm[a], 3] = dim[perm[a]] - 1
+    return tuple(int(dim[perm[a]]) for a in range(3)), mat @ Q
 
 
 def phantom(dim, gen, device):
@@ -100,6 +119,8 @@ def build_subject(wl, device, seed):
             scale[wl['axes'][c]] = float(thick)
         mat_x = mat_y @ torch.diag(torch.tensor(scale + [1.0], dtype=torch.float64))
         dim_x = tuple(int(math.floor(d / s)) for d, s in zip(dim_y, scale))
+        if wl.get('orient'):
+            dim_x, mat_x = orient_axes(dim_x, mat_x, *wl['orient'][c])
         u = torch.rand(6, generator=gen) * 2 - 1
         rigid = rigid_matrix((u[:3] * 5.0).tolist(), (u[3:] * 0.1).tolist())
         if wl.get('rigid') == 'identity':  # grid-aligned observations (no motion between scans)

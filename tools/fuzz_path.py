@@ -2,7 +2,7 @@
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import nitorch_restated as N, unires_restated as O
-from tests.helpers import make_problem, oracle_structs, gpu_structs, rel_err, run_oracle_update_y, run_gpu_update_y
+from tests.helpers import SIGNED_PERMS, make_problem, oracle_structs, gpu_structs, rel_err, run_oracle_update_y, run_gpu_update_y
 import unires_amd as U
 dev = 'cuda:0'
 g = torch.Generator().manual_seed(int(os.environ.get('SEED', '0')))
@@ -33,6 +33,9 @@ for it in range(int(os.environ.get('N', '12'))):
         # the in-plane / through-plane slice profiles of the reference's settings (rect, triangle, Gaussian)
         kw['prof_ip'] = int(torch.randint(0, 3, (1,), generator=g))
         kw['prof_tp'] = int(torch.randint(0, 2, (1,), generator=g))
+    if regime != 'id' and int(torch.randint(0, 2, (1,), generator=g)) == 0:
+        # stored orientation: a random signed permutation of the voxel axes per repeat (sagittal / coronal / reflected)
+        kw['orient'] = [SIGNED_PERMS[int(v)] for v in torch.randint(0, 48, (4,), generator=g)]
     try:
         prob = make_problem(**kw)
     except Exception as e:  # degenerate draw (e.g. a thick axis longer than the volume)
