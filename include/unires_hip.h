@@ -8,8 +8,10 @@
  * status (0 = OK) and never throws; unires_last_error() gives the message of
  * the calling thread's last failure.  Kernels are launched on the caller's
  * stream (`stream` is a hipStream_t passed as void*; NULL = default stream).
- * No entry point synchronises, except unires_cg_solve when the caller asks for
- * the realised iteration count / objective trace on the host.
+ * No entry point synchronises a stream, except unires_cg_solve when the caller asks for
+ * the realised iteration count / objective trace on the host.  (A solve that can stop
+ * early - tol > 0 - keeps the calling thread until its last chunk of iterations is
+ * enqueued; it watches a host-mapped progress word, not the stream.)
  *
  * The reference (brudfors/UniRes) has no FFI layer: its seam is Python calls
  * into nitorch + torch.  Each entry point below cites the
@@ -213,10 +215,26 @@ int unires_precond_apply(unires_plan_t *plan, const float *in, float *out, void 
  * tol == 0 runs exactly max_iter iterations with no objective evaluation.
  * If iters_out != NULL the call synchronises the stream and returns the realised
  * iteration count; obj_trace (HOST, max_iter+1 doubles, may be NULL) then
- * receives the objective values obj[0..iters]. */
+ * receives the objective values obj[0..iters].
+ * tol > 0 (the reference's default, struct.py:65-67): the solve is enqueued in chunks of
+ * UNIRES_CG_CHUNK iterations (default 2), one chunk ahead of the device; the kernel that ends an
+ * iteration publishes (done, iterations) to host-mapped memory and the next chunk is enqueued only
+ * while the stopping test has not fired - same kernels, same order, same iterate and trace as
+ * enqueuing all max_iter iterations, without their no-op tail.  max_iter may then exceed 4096
+ * (nitorch's default is 10 numel); obj_trace receives at most 4097 values (a ring beyond that). */
 int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const float *b, float *x,
                     int32_t max_iter, double tol, int32_t stop_mode, int32_t precond_mode,
                     int32_t *iters_out, double *obj_trace, void *stream);
+
+/* The channels' solves of one y-update together (_update.py:122-150 loops over the channels; they do
+ * not couple inside the y-update): n plans, each with its own b, x, rho, lam and stream (all HOST
+ * arrays of n entries).  One host loop feeds the chunks of all of them, so channels on separate
+ * streams keep overlapping on the device.  iters_out: n ints or NULL (non-NULL synchronises every
+ * stream); obj_trace: n x (min(max_iter, 4096) + 1) doubles or NULL. */
+int unires_cg_solve_many(int32_t n, unires_plan_t *const *plans, const float *rho, const float *lam,
+                         const float *const *b, float *const *x, int32_t max_iter, double tol,
+                         int32_t stop_mode, int32_t precond_mode, int32_t *iters_out,
+                         double *obj_trace, void *const *streams);
 
 /* ------------------------------------------------------------------------
  * Next rows of the path: the updates and sums that follow the

@@ -69,6 +69,10 @@ SIGNATURES = {
     'unires_cg_solve': (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.c_double, C.c_int32, C.c_int32,
                                   C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p]),
+    'unires_cg_solve_many': (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_float),
+                                       C.POINTER(C.c_float), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.c_int32, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_void_p)]),
     'unires_zw_update': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int32, c_i32x3,
                                    c_f32x3, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),

@@ -246,9 +246,10 @@ class ChannelPlan:
         self._y(x, 'x')
         s = stop if stop in _lib.STOP else stop[0].lower()
         mode = _lib.STOP[s] if s in _lib.STOP else (0 if s == 'e' else 1)
+        max_iter = int(max_iter)
         if sync:
             it = C.c_int32(0)
-            obj = (C.c_double * (max_iter + 1))()
+            obj = (C.c_double * (min(max_iter, 4096) + 1))()
             check(self.lib.unires_cg_solve(self._h, float(rho), float(lam), _ptr(b), _ptr(x),
                                            int(max_iter), float(tolerance), mode, pm, C.byref(it),
                                            obj, _stream()))
@@ -258,3 +259,34 @@ class ChannelPlan:
                                        int(max_iter), float(tolerance), mode, pm, None, None,
                                        _stream()))
         return None
+
+
+def cg_many(plans, bs, xs, rho, lams, streams, max_iter=20, tolerance=1e-3, stop='max_gain', precond='none',
+            sync=False):
+    """The solves of several channels at once, channel c on ``streams[c]`` (``unires_cg_solve_many``): with
+    a tolerance the library feeds every solve chunk by chunk from one host loop, so the channels keep
+    overlapping on the device.  Returns [(iters, obj), ...] when ``sync``."""
+    if precond not in _lib.PRECOND:
+        raise ValueError('Undefined preconditioner')
+    n = len(plans)
+    lib = plans[0].lib
+    s = stop if stop in _lib.STOP else stop[0].lower()
+    mode = _lib.STOP[s] if s in _lib.STOP else (0 if s == 'e' else 1)
+    for pl, b, x in zip(plans, bs, xs):
+        pl._y(b, 'b')
+        if not x.is_contiguous():
+            raise ValueError('unires_amd: cg updates x in place and needs it contiguous')
+        pl._y(x, 'x')
+    max_iter = int(max_iter)
+    nobj = min(max_iter, 4096) + 1
+    it = (C.c_int32 * n)() if sync else None
+    obj = (C.c_double * (n * nobj))() if sync else None
+    with torch.cuda.device(plans[0].device):
+        check(lib.unires_cg_solve_many(
+            n, (C.c_void_p * n)(*[pl._h.value for pl in plans]), (C.c_float * n)(*[float(rho)] * n),
+            (C.c_float * n)(*[float(v) for v in lams]), (C.c_void_p * n)(*[b.data_ptr() for b in bs]),
+            (C.c_void_p * n)(*[x.data_ptr() for x in xs]), max_iter, float(tolerance), mode,
+            _lib.PRECOND[precond], it, obj, (C.c_void_p * n)(*[st.cuda_stream for st in streams])))
+    if not sync:
+        return None
+    return [(it[c], list(obj[c * nobj:c * nobj + it[c] + 1]) if tolerance else None) for c in range(n)]

@@ -7,6 +7,7 @@ import torch
 from . import _lib
 from ._lib import check, f3, i3
 from ._ops import _ptr, _stream, on_device
+from ._plan import cg_many
 from ._project import _channel_plan, _proj
 from .spatial import voxel_size
 
@@ -92,6 +93,7 @@ def _update_y(x, y, z, w, rho, tmp, sett, info=None):
     ready = torch.cuda.Event()
     ready.record(main)
     streams = _side_streams(y[0].dat.device, C)
+    plans, bs = [], []
     for c in range(C):
         plan = _channel_plan(x[c], y[c], sett.method, sett.do_proj, vx_y)
         lam = float(y[c].lam)
@@ -104,8 +106,12 @@ def _update_y(x, y, z, w, rho, tmp, sett, info=None):
                 plan.rhs([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=b)
             if pre in ('jacobi', 'fft'):
                 plan.precond_build(rho, lam, mode=pre)
-            plan.cg(b, y[c].dat, rho, lam, max_iter=sett.cgs_max_iter, tolerance=sett.cgs_tol,
-                    stop=sett.cgs_stop, sync=False, precond=pre)
+        plans.append(plan)
+        bs.append(b)
+    # the solves of all channels from one call: with a tolerance the library feeds them chunk by chunk
+    # from one host loop (unires_cg_solve_many), each on its channel's stream
+    cg_many(plans, bs, [yc.dat for yc in y], rho, [float(yc.lam) for yc in y], streams,
+            max_iter=sett.cgs_max_iter, tolerance=sett.cgs_tol, stop=sett.cgs_stop, precond=pre)
     for c in range(C):
         main.wait_stream(streams[c])
     return y

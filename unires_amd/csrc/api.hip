@@ -8,6 +8,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sched.h>
+
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -333,6 +336,11 @@ struct unires_plan {
     }
   } cg_key;
   hipGraphExec_t cg_exec = nullptr;
+  // chunked solves: start + chunk graphs, the host-mapped progress word and the solve counter
+  CgKey cg_chunk_key;
+  hipGraphExec_t cg_start_exec = nullptr, cg_chunk_exec = nullptr;
+  unsigned long long *progress = nullptr, *progress_dev = nullptr;
+  unsigned cg_gen = 0;
   float *precM = nullptr;  // Jacobi diagonal (own allocation, made by unires_precond_build)
   FftPre fft;              // FFT-diagonal preconditioner (plans + buffers, made on demand)
   float prec_rho = 0.f, prec_lam = 0.f;
@@ -347,7 +355,16 @@ static void drop_timing(unires_plan *pl) {
   pl->tev.clear();
 }
 
+static void drop_cg_chunk_graphs(unires_plan *pl) {
+  if (!pl->cg_start_exec && !pl->cg_chunk_exec) return;
+  (void)hipDeviceSynchronize();
+  if (pl->cg_start_exec) (void)hipGraphExecDestroy(pl->cg_start_exec);
+  if (pl->cg_chunk_exec) (void)hipGraphExecDestroy(pl->cg_chunk_exec);
+  pl->cg_start_exec = pl->cg_chunk_exec = nullptr;
+}
+
 static void drop_cg_graph(unires_plan *pl) {
+  drop_cg_chunk_graphs(pl);
   if (!pl->cg_exec) return;
   (void)hipDeviceSynchronize();
   (void)hipGraphExecDestroy(pl->cg_exec);
@@ -705,6 +722,9 @@ extern "C" int unires_plan_destroy(unires_plan_t *plan) {
   if (plan->ws) (void)hipFree(plan->ws);
   if (plan->precM) (void)hipFree(plan->precM);
   if (plan->cg_exec) (void)hipGraphExecDestroy(plan->cg_exec);
+  if (plan->cg_start_exec) (void)hipGraphExecDestroy(plan->cg_start_exec);
+  if (plan->cg_chunk_exec) (void)hipGraphExecDestroy(plan->cg_chunk_exec);
+  if (plan->progress) (void)hipHostFree(plan->progress);
   drop_timing(plan);
   fftpre_destroy(plan->fft);
   for (Repeat &R : plan->reps) free_ztabs(R), free_sched(R);
@@ -1175,15 +1195,17 @@ extern "C" int unires_rhs_from_atx(unires_plan_t *plan, const float *atx, const 
 // --------------------------------------------------------------------------
 // CG  (nitorch.core.optim.cg as UniRes calls it)
 // --------------------------------------------------------------------------
-// Enqueues the whole solve (every kernel of nitorch's cg()) on `st`.
-static int cg_enqueue(unires_plan *pl, float rho, float lam, const float *b, float *x, int max_iter,
-                      double tol, int stop_mode, const float *M, bool fft, hipStream_t st) {
+// The solve is enqueued in two parts: the start (r = b - A x, p, r.z, obj[0]) and runs of iterations.
+// `dev_k`: the iteration index is the device state's own counter (a captured chunk of iterations then
+// serves any part of a solve); `hostw`: the scalar kernel that ends an iteration publishes the state's
+// (generation, done, iterations) to this host-mapped word.
+static int cg_enqueue_start(unires_plan *pl, float rho, float lam, const float *b, float *x, double tol,
+                            int stop_mode, const float *M, bool fft, unsigned long long *hostw,
+                            hipStream_t st) {
   const size_t ny = pl->dy.numel();
   const bool check = tol != 0.0;
   CgState *S = pl->state;
-  const int *done = &S->done;
   const int gv = vec_num_blocks(ny);
-
   // r = b - A(x); p = r; rz = r.r; obj[0]
   HIP_TRY(hipMemsetAsync(&S->done, 0, sizeof(int), st));
   matvec(pl, rho, lam, x, pl->ap, nullptr, nullptr, st);
@@ -1195,19 +1217,40 @@ static int cg_enqueue(unires_plan *pl, float rho, float lam, const float *b, flo
     HIP_TRY(hipMemcpyAsync(pl->p, pl->fft.z, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
     launch_dot(pl->r, pl->fft.z, ny, pl->part0, nullptr, st);
   }
-  launch_sc_init(S, pl->part0, pl->part1, gv, stop_mode, check ? 1 : 0, st);
+  launch_sc_init(S, pl->part0, pl->part1, gv, stop_mode, check ? 1 : 0, hostw, st);
+  return UNIRES_OK;
+}
 
+static int cg_enqueue_iters(unires_plan *pl, float rho, float lam, const float *b, float *x, int k_first,
+                            int count, double tol, int stop_mode, const float *M, bool fft, bool dev_k,
+                            unsigned long long *hostw, hipStream_t st) {
+  const size_t ny = pl->dy.numel();
+  const bool check = tol != 0.0;
+  CgState *S = pl->state;
+  const int *done = &S->done;
+  const int gv = vec_num_blocks(ny);
   // UNIRES_CG_FOLD=1: alpha / beta in the prologues of the vector kernels instead of one-block
   // kernels of their own
   static const bool fold_on = getenv("UNIRES_CG_FOLD") && getenv("UNIRES_CG_FOLD")[0] == '1';
   const int gf = vec_num_blocks_fold(ny);
-  for (int k = 1; k <= max_iter; ++k) {
+  for (int k = k_first; k < k_first + count; ++k) {
+    const int kk = dev_k ? -1 : k;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (pl->timing && hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
-      (void)hipEventRecord(ev0, st);
+    if (pl->timing && hipEventCreate(&ev0) == hipSuccess) {
+      if (hipEventCreate(&ev1) == hipSuccess) {
+        (void)hipEventRecord(ev0, st);
+      } else {
+        (void)hipEventDestroy(ev0);
+        ev0 = nullptr;
+      }
+    }
     const int g = matvec(pl, rho, lam, pl->p, pl->ap, pl->part0, done, st);
     if (ev0 && ev1) {
       (void)hipEventRecord(ev1, st);
+      if (pl->tev.size() >= 65536) {  // a caller that never collects: forget the oldest pair
+        (void)hipEventDestroy(pl->tev.front().first), (void)hipEventDestroy(pl->tev.front().second);
+        pl->tev.erase(pl->tev.begin());
+      }
       pl->tev.emplace_back(ev0, ev1);
     }
     const bool recur = check && stop_mode == UNIRES_STOP_MAXGAIN_RECURRED;
@@ -1216,7 +1259,7 @@ static int cg_enqueue(unires_plan *pl, float rho, float lam, const float *b, flo
     if (recur) obj_kind = 2;
     // "x += alpha p" rides with the p update unless sc_beta can stop the solve in between
     const bool lazy_x = obj_kind == 0;
-    if (fold_on && lazy_x && !fft) {
+    if (fold_on && lazy_x && !fft && !dev_k) {
       // no scalar kernels: alpha in the prologue of the r update (its r.z partials go to part1 -
       // part0 is being read by every workgroup), beta in the prologue of the x / p update
       launch_update_r_fold(S, pl->part0, g, k, pl->ap, pl->r, ny, pl->part1, M, st);
@@ -1229,25 +1272,208 @@ static int cg_enqueue(unires_plan *pl, float rho, float lam, const float *b, flo
         if (fftpre_apply(pl->fft, pl->r, pl->fft.z, st)) return fail(UNIRES_ERR_HIP, "hipFFT execution failed");
         launch_dot(pl->r, pl->fft.z, ny, pl->part0, done, st);
       }
-      launch_sc_beta(S, pl->part0, pl->part1, gv, k, obj_kind, tol, st);
+      launch_sc_beta(S, pl->part0, pl->part1, gv, kk, obj_kind, tol, obj_kind ? hostw : nullptr, st);
       launch_update_p(S, fft ? pl->fft.z : pl->r, pl->p, ny, M, lazy_x ? x : nullptr, st);
     }
     if (check && stop_mode == UNIRES_STOP_MAXGAIN) {
       // objective sum x (Ax - 2b) folded into the matvec epilogue: A(x) is never stored
       const int go = matvec(pl, rho, lam, x, pl->ax, pl->part1, done, st, b);
-      launch_sc_obj(S, pl->part1, go, k, tol, st);
+      launch_sc_obj(S, pl->part1, go, kk, tol, hostw, st);
     }
   }
   return UNIRES_OK;
 }
 
-extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const float *b, float *x,
-                               int32_t max_iter, double tol, int32_t stop_mode,
-                               int32_t precond_mode, int32_t *iters_out, double *obj_trace,
-                               void *stream) {
+// Enqueues the whole solve (every kernel of nitorch's cg()) on `st`.
+static int cg_enqueue(unires_plan *pl, float rho, float lam, const float *b, float *x, int max_iter,
+                      double tol, int stop_mode, const float *M, bool fft, hipStream_t st) {
+  const int rc = cg_enqueue_start(pl, rho, lam, b, x, tol, stop_mode, M, fft, nullptr, st);
+  if (rc) return rc;
+  return cg_enqueue_iters(pl, rho, lam, b, x, 1, max_iter, tol, stop_mode, M, fft, false, nullptr, st);
+}
+
+// --------------------------------------------------------------------------
+// Chunked solves (round 4): a solve that can stop early (tolerance > 0: the reference's default,
+// struct.py:65-67 cgs_tol = 1e-3, 'max_gain') is enqueued as the start + chunks of `chunk` iterations,
+// one chunk of look-ahead.  The kernel that ends an iteration publishes (generation, done, iterations)
+// to a host-mapped word; the host enqueues the next chunk when the older of the two in flight has
+// finished and the flag is not up - no stream synchronisation, the device never idles, and at most
+// 2 chunk - 1 iterations run as no-op kernels after convergence (enqueuing all max_iter iterations, as
+// rounds 1-3 did, ran 45 of config 3's 60 iterations as ~10 no-op kernels each).  The realised
+// iteration count, iterate and objective trace are those of the full enqueue: the same kernels in
+// the same order, the stopping test on the device.  Start and chunk are hipGraphs, captured once per
+// (b, x, rho, lam, options) and replayed.
+// --------------------------------------------------------------------------
+struct CgRun {
+  unires_plan *pl = nullptr;
+  float rho = 0.f, lam = 0.f;
+  const float *b = nullptr;
+  float *x = nullptr;
+  int max_iter = 0, stop = 0, chunk = 2;
+  double tol = 0.0;
+  const float *M = nullptr;
+  bool fft = false;
+  hipStream_t st = nullptr;
+  int enqueued = 0;     // iterations enqueued so far
+  unsigned gen = 0;     // generation of this solve
+  bool finished = false;
+  bool use_graph = false;
+};
+
+static int cg_chunk_size() {
+  static const int k = [] {
+    const char *e = getenv("UNIRES_CG_CHUNK");
+    const int v = e ? atoi(e) : 2;
+    return v < 1 ? 1 : (v > 64 ? 64 : v);
+  }();
+  return k;
+}
+
+static int capture_graph(hipStream_t st, hipGraphExec_t *exec, const std::function<int()> &body) {
+  *exec = nullptr;
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;  // capture refused: the caller launches plainly
+  }
+  const int rc = body();
+  hipGraph_t graph = nullptr;
+  const hipError_t ce = hipStreamEndCapture(st, &graph);
+  if (rc) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  if (ce != hipSuccess || !graph) return fail(UNIRES_ERR_HIP, "hipStreamEndCapture failed");
+  const hipError_t ge = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ge != hipSuccess) {
+    *exec = nullptr;
+    return fail(UNIRES_ERR_HIP, "hipGraphInstantiate failed");
+  }
+  return UNIRES_OK;
+}
+
+static int cg_run_enqueue_chunk(CgRun &R) {
+  unires_plan *pl = R.pl;
+  const int n = std::min(R.chunk, R.max_iter - R.enqueued);
+  if (n <= 0) return UNIRES_OK;
+  if (R.use_graph && n == R.chunk && pl->cg_chunk_exec) {
+    HIP_TRY(hipGraphLaunch(pl->cg_chunk_exec, R.st));
+  } else {
+    const int rc = cg_enqueue_iters(pl, R.rho, R.lam, R.b, R.x, R.enqueued + 1, n, R.tol, R.stop, R.M, R.fft,
+                                    true, pl->progress_dev, R.st);
+    if (rc) return rc;
+  }
+  R.enqueued += n;
+  return UNIRES_OK;
+}
+
+static int cg_run_start(CgRun &R) {
+  unires_plan *pl = R.pl;
+  if (!pl->progress) {
+    HIP_TRY(hipHostMalloc((void **)&pl->progress, 64, hipHostMallocMapped));
+    *pl->progress = 0ull;
+    HIP_TRY(hipHostGetDevicePointer((void **)&pl->progress_dev, (void *)pl->progress, 0));
+  }
+  R.gen = ++pl->cg_gen;
+  R.enqueued = 0;
+  R.finished = false;
+  unires_plan::CgKey key;
+  key.b = R.b, key.x = R.x, key.rho = R.rho, key.lam = R.lam, key.max_iter = -2 - R.chunk, key.stop = R.stop;
+  key.pre = R.M ? UNIRES_PRECOND_JACOBI : UNIRES_PRECOND_IDENTITY, key.tol = R.tol;
+  if (R.use_graph && !(pl->cg_start_exec && pl->cg_chunk_exec && pl->cg_chunk_key == key)) {
+    drop_cg_chunk_graphs(pl);
+    int rc = capture_graph(R.st, &pl->cg_start_exec, [&] {
+      return cg_enqueue_start(pl, R.rho, R.lam, R.b, R.x, R.tol, R.stop, R.M, R.fft, pl->progress_dev, R.st);
+    });
+    if (rc > 0) return rc;
+    if (rc == 0)
+      rc = capture_graph(R.st, &pl->cg_chunk_exec, [&] {
+        return cg_enqueue_iters(pl, R.rho, R.lam, R.b, R.x, 1, R.chunk, R.tol, R.stop, R.M, R.fft, true,
+                                pl->progress_dev, R.st);
+      });
+    if (rc > 0) return rc;
+    if (rc < 0 || !pl->cg_start_exec || !pl->cg_chunk_exec) {
+      drop_cg_chunk_graphs(pl);
+      R.use_graph = false;
+    } else {
+      pl->cg_chunk_key = key;
+    }
+  }
+  if (R.use_graph) {
+    HIP_TRY(hipGraphLaunch(pl->cg_start_exec, R.st));
+  } else {
+    const int rc = cg_enqueue_start(pl, R.rho, R.lam, R.b, R.x, R.tol, R.stop, R.M, R.fft, pl->progress_dev, R.st);
+    if (rc) return rc;
+  }
+  // two chunks in flight
+  int rc = cg_run_enqueue_chunk(R);
+  if (!rc) rc = cg_run_enqueue_chunk(R);
+  if (rc) return rc;
+  if (R.enqueued >= R.max_iter) R.finished = true;
+  return UNIRES_OK;
+}
+
+// One look at the progress word (never blocks): enqueues the next chunk when the older chunk in flight is
+// through and the solve has not converged.
+static int cg_run_poll(CgRun &R) {
+  if (R.finished) return UNIRES_OK;
+  const unsigned long long w = __atomic_load_n(R.pl->progress, __ATOMIC_ACQUIRE);
+  if ((unsigned)(w >> 32) != R.gen) return UNIRES_OK;  // this solve's first kernels have not run yet
+  if (w & 0x80000000ull) {
+    R.finished = true;
+    return UNIRES_OK;
+  }
+  const int iters = (int)(w & 0x7fffffffull);
+  while (!R.finished && iters >= R.enqueued - R.chunk) {
+    const int rc = cg_run_enqueue_chunk(R);
+    if (rc) return rc;
+    if (R.enqueued >= R.max_iter) R.finished = true;
+  }
+  return UNIRES_OK;
+}
+
+// Drive a set of runs (each on its own plan and stream) until every one has everything it needs
+// enqueued.  The host spins on the progress words; every so often it asks the streams for errors.
+static int cg_runs_drive(std::vector<CgRun> &runs) {
+  unsigned spins = 0;
+  for (;;) {
+    bool all = true;
+    for (CgRun &R : runs) {
+      if (R.finished) continue;
+      const int rc = cg_run_poll(R);
+      if (rc) return rc;
+      all = all && R.finished;
+    }
+    if (all) return UNIRES_OK;
+    if ((++spins & 0x3ff) == 0) {
+      for (CgRun &R : runs) {
+        if (R.finished) continue;
+        const hipError_t q = hipStreamQuery(R.st);
+        if (q == hipSuccess) {
+          // the stream drained: whatever was enqueued has run and published; a look at the word must
+          // either end the run or enqueue more
+          const int before = R.enqueued;
+          const int rc = cg_run_poll(R);
+          if (rc) return rc;
+          if (!R.finished && R.enqueued == before)
+            return fail(UNIRES_ERR_HIP, "chunked CG: the stream drained without the expected progress");
+        } else if (q != hipErrorNotReady) {
+          g_err = std::string("chunked CG: ") + hipGetErrorString(q);
+          return UNIRES_ERR_HIP;
+        }
+      }
+      sched_yield();
+    }
+  }
+}
+
+static int cg_check_args(unires_plan *plan, float rho, float lam, const float *b, float *x, int32_t max_iter,
+                         double tol, int32_t stop_mode, int32_t precond_mode) {
   if (!plan || !b || !x) return fail(UNIRES_ERR_NULL, "null argument");
   if (b == x) return fail(UNIRES_ERR_ARG, "b and x must not alias");
-  if (max_iter < 0 || max_iter > kMaxCgIter) return fail(UNIRES_ERR_ARG, "max_iter out of range");
+  if (max_iter < 0) return fail(UNIRES_ERR_ARG, "max_iter out of range");
+  if (max_iter > kMaxCgIter && !(tol > 0.0))
+    return fail(UNIRES_ERR_ARG, "max_iter beyond 4096 needs a tolerance (the solve is then enqueued in chunks)");
   if (stop_mode < 0 || stop_mode > 2) return fail(UNIRES_ERR_ARG, "bad stop mode");
   if (precond_mode < UNIRES_PRECOND_IDENTITY || precond_mode > UNIRES_PRECOND_FFT)
     return fail(UNIRES_ERR_UNSUPPORTED, "preconditioner modes: identity (0), Jacobi (1), FFT (2)");
@@ -1255,64 +1481,131 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
       (!plan->prec_ready || plan->prec_mode != precond_mode || plan->prec_rho != rho ||
        plan->prec_lam != lam))
     return fail(UNIRES_ERR_ARG, "call unires_precond_build with this mode, rho and lam first");
+  if (!(tol >= 0.0)) return fail(UNIRES_ERR_ARG, "tolerance must be >= 0");
+  return UNIRES_OK;
+}
+
+static bool cg_graphs_on() {
+  static const bool on = !(getenv("UNIRES_CG_GRAPH") && getenv("UNIRES_CG_GRAPH")[0] == '0');
+  return on;
+}
+
+// chunked enqueue: solves that can stop early, unless switched off (UNIRES_CG_CHUNK=0: the full enqueue)
+static bool cg_chunked(double tol, int max_iter) {
+  static const bool off = getenv("UNIRES_CG_CHUNK") && atoi(getenv("UNIRES_CG_CHUNK")) == 0;
+  return tol != 0.0 && max_iter > 0 && (!off || max_iter > kMaxCgIter);
+}
+
+static CgRun cg_make_run(unires_plan *pl, float rho, float lam, const float *b, float *x, int max_iter,
+                         double tol, int stop_mode, int precond_mode, hipStream_t st) {
+  CgRun R;
+  R.pl = pl, R.rho = rho, R.lam = lam, R.b = b, R.x = x, R.max_iter = max_iter, R.tol = tol, R.stop = stop_mode;
+  R.M = precond_mode == UNIRES_PRECOND_JACOBI ? pl->precM : nullptr;
+  R.fft = precond_mode == UNIRES_PRECOND_FFT;
+  R.st = st;
+  R.chunk = cg_chunk_size();
+  R.use_graph = cg_graphs_on() && !R.fft && !pl->timing;
+  return R;
+}
+
+static int cg_read_back(unires_plan *pl, int max_iter, double tol, int32_t *iters_out, double *obj_trace,
+                        hipStream_t st) {
+  CgState *S = pl->state;
+  int it = 0;
+  HIP_TRY(hipMemcpyAsync(&it, &S->iters, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (obj_trace && tol != 0.0)
+    HIP_TRY(hipMemcpyAsync(obj_trace, S->obj, sizeof(double) * (size_t)(std::min(max_iter, kMaxCgIter) + 1),
+                           hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *iters_out = it;
+  return UNIRES_OK;
+}
+
+extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const float *b, float *x,
+                               int32_t max_iter, double tol, int32_t stop_mode,
+                               int32_t precond_mode, int32_t *iters_out, double *obj_trace,
+                               void *stream) {
+  int rc = cg_check_args(plan, rho, lam, b, x, max_iter, tol, stop_mode, precond_mode);
+  if (rc) return rc;
   const float *M = precond_mode == UNIRES_PRECOND_JACOBI ? plan->precM : nullptr;
   const bool fft = precond_mode == UNIRES_PRECOND_FFT;
-  if (!(tol >= 0.0)) return fail(UNIRES_ERR_ARG, "tolerance must be >= 0");
   hipStream_t st = (hipStream_t)stream;
   unires_plan *pl = plan;
 
+  if (cg_chunked(tol, max_iter)) {
+    std::vector<CgRun> runs(1, cg_make_run(pl, rho, lam, b, x, max_iter, tol, stop_mode, precond_mode, st));
+    if ((rc = cg_run_start(runs[0]))) return rc;
+    if ((rc = cg_runs_drive(runs))) return rc;
+    CHECK_LAUNCH();
+    return iters_out ? cg_read_back(pl, max_iter, tol, iters_out, obj_trace, st) : UNIRES_OK;
+  }
+  ++pl->cg_gen;  // (k_sc_init counts every solve)
+
   // hipGraph replay (UNIRES_CG_GRAPH=0 disables): the ~8 launches per iteration of a solve are
   // captured once and re-launched as one graph while the arguments stay the same
-  static const bool use_graph = !(getenv("UNIRES_CG_GRAPH") && getenv("UNIRES_CG_GRAPH")[0] == '0');
   unires_plan::CgKey key;
   key.b = b, key.x = x, key.rho = rho, key.lam = lam, key.max_iter = max_iter, key.stop = stop_mode;
   key.pre = precond_mode, key.tol = tol;
-  const bool graphable = use_graph && !fft && max_iter > 0 && !pl->timing;  // (events go with plain launches)
+  const bool graphable = cg_graphs_on() && !fft && max_iter > 0 && !pl->timing;  // (events go with plain launches)
   if (graphable && pl->cg_exec && pl->cg_key == key) {
     HIP_TRY(hipGraphLaunch(pl->cg_exec, st));
   } else {
-    bool capturing = false;
-    if (graphable) {
-      if (pl->cg_exec) {
-        drop_cg_graph(pl);
-      }
-      capturing = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
-      if (!capturing) (void)hipGetLastError();
-    }
-    const int rc = cg_enqueue(pl, rho, lam, b, x, max_iter, tol, stop_mode, M, fft, st);
-    if (capturing) {
-      hipGraph_t graph = nullptr;
-      const hipError_t ce = hipStreamEndCapture(st, &graph);
-      if (rc) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return rc;
-      }
-      if (ce != hipSuccess || !graph) return fail(UNIRES_ERR_HIP, "hipStreamEndCapture failed");
-      const hipError_t ge = hipGraphInstantiate(&pl->cg_exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      if (ge != hipSuccess) {
-        pl->cg_exec = nullptr;
-        return fail(UNIRES_ERR_HIP, "hipGraphInstantiate failed");
-      }
+    if (graphable && pl->cg_exec) drop_cg_graph(pl);
+    rc = graphable ? capture_graph(st, &pl->cg_exec, [&] {
+      return cg_enqueue(pl, rho, lam, b, x, max_iter, tol, stop_mode, M, fft, st);
+    }) : -1;
+    if (rc > 0) return rc;
+    if (rc == 0) {
       pl->cg_key = key;
       HIP_TRY(hipGraphLaunch(pl->cg_exec, st));
-    } else if (rc) {
+    } else if ((rc = cg_enqueue(pl, rho, lam, b, x, max_iter, tol, stop_mode, M, fft, st))) {
       return rc;
     }
   }
   CHECK_LAUNCH();
+  return iters_out ? cg_read_back(pl, max_iter, tol, iters_out, obj_trace, st) : UNIRES_OK;
+}
 
-  if (iters_out) {
-    CgState *S = pl->state;
-    const bool check = tol != 0.0;
-    int it = 0;
-    HIP_TRY(hipMemcpyAsync(&it, &S->iters, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (obj_trace && check)
-      HIP_TRY(hipMemcpyAsync(obj_trace, S->obj, sizeof(double) * (size_t)(max_iter + 1),
-                             hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    *iters_out = it;
+// Several channels' solves at once, each on its own plan and stream (unires/_update.py:122-150 loops over
+// the channels; they do not couple inside the y-update): the chunks of all of them are fed from one host
+// loop, so that the channels still overlap on the device where they run on separate streams.
+extern "C" int unires_cg_solve_many(int32_t n, unires_plan_t *const *plans, const float *rho, const float *lam,
+                                    const float *const *b, float *const *x, int32_t max_iter, double tol,
+                                    int32_t stop_mode, int32_t precond_mode, int32_t *iters_out,
+                                    double *obj_trace, void *const *streams) {
+  if (n < 1 || !plans || !rho || !lam || !b || !x || !streams) return fail(UNIRES_ERR_NULL, "null argument");
+  for (int c = 0; c < n; ++c) {
+    const int rc = cg_check_args(plans[c], rho[c], lam[c], b[c], x[c], max_iter, tol, stop_mode, precond_mode);
+    if (rc) return rc;
+    for (int d = 0; d < c; ++d)
+      if (plans[d] == plans[c]) return fail(UNIRES_ERR_ARG, "one plan per solve");
   }
+  if (!cg_chunked(tol, max_iter)) {  // nothing to steer: each solve is enqueued whole
+    for (int c = 0; c < n; ++c) {
+      const int rc = unires_cg_solve(plans[c], rho[c], lam[c], b[c], x[c], max_iter, tol, stop_mode, precond_mode,
+                                     nullptr, nullptr, streams[c]);
+      if (rc) return rc;
+    }
+  } else {
+    std::vector<CgRun> runs;
+    for (int c = 0; c < n; ++c)
+      runs.push_back(cg_make_run(plans[c], rho[c], lam[c], b[c], x[c], max_iter, tol, stop_mode, precond_mode,
+                                 (hipStream_t)streams[c]));
+    for (CgRun &R : runs) {
+      const int rc = cg_run_start(R);
+      if (rc) return rc;
+    }
+    const int rc = cg_runs_drive(runs);
+    if (rc) return rc;
+    CHECK_LAUNCH();
+  }
+  if (iters_out)
+    for (int c = 0; c < n; ++c) {
+      const int rc = cg_read_back(plans[c], max_iter, tol, iters_out + c,
+                                  obj_trace ? obj_trace + (size_t)c * (std::min(max_iter, kMaxCgIter) + 1) : nullptr,
+                                  (hipStream_t)streams[c]);
+      if (rc) return rc;
+    }
   return UNIRES_OK;
 }
 

@@ -382,8 +382,16 @@ __device__ __forceinline__ double sum_partials(const double *part, int g) {
 }
 
 // nitorch get_gain(obj[:k+1], 'decreasing') and the |gain| < tol test
+__device__ __forceinline__ void publish(const CgState *st, unsigned long long *hostw) {
+  if (hostw)
+    __hip_atomic_store(hostw, cg_progress_word(st->gen, st->done, st->iters), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ void record_obj(CgState *st, int k, double obj, double tol) {
-  st->obj[k] = obj;
+  constexpr int kRing = kMaxCgIter + 1;
+  const double prev = k > 0 ? st->obj[(k - 1) % kRing] : 0.0;
+  st->obj[k % kRing] = obj;
   if (k == 0) {
     st->obj_max = obj;
     st->obj_min = obj;
@@ -391,13 +399,13 @@ __device__ __forceinline__ void record_obj(CgState *st, int k, double obj, doubl
   }
   st->obj_max = fmax(st->obj_max, obj);
   st->obj_min = fmin(st->obj_min, obj);
-  const double gain = (st->obj[k - 1] - obj) / (st->obj_max - st->obj_min);
+  const double gain = (prev - obj) / (st->obj_max - st->obj_min);
   if (fabs(gain) < tol) st->done = 1;  // NaN compares false, like torch
 }
 
 __global__ void __launch_bounds__(kBlock)
     k_sc_init(CgState *st, const double *part_rr, const double *part_obj, int g, int mode,
-              int check) {
+              int check, unsigned long long *hostw) {
   const double rr = sum_partials(part_rr, g);
   double ob = 0.0;
   if (check && mode != UNIRES_STOP_RESIDUAL) ob = sum_partials(part_obj, g);
@@ -409,7 +417,9 @@ __global__ void __launch_bounds__(kBlock)
     st->iters = 0;
     st->alpha = 0.0;
     st->beta = 0.0;
+    st->gen += 1u;
     if (check) record_obj(st, 0, mode == UNIRES_STOP_RESIDUAL ? sqrt(rr) : 0.5 * ob, 0.0);
+    publish(st, hostw);
   }
 }
 
@@ -425,8 +435,9 @@ __global__ void __launch_bounds__(kBlock) k_sc_alpha(CgState *st, const double *
 // obj_kind: 0 none, 1 sqrt(rz) ('e'), 2 recurred (-0.5 * sum x(b+r))
 __global__ void __launch_bounds__(kBlock)
     k_sc_beta(CgState *st, const double *part_rr, const double *part_obj, int g, int k,
-              int obj_kind, double tol) {
+              int obj_kind, double tol, unsigned long long *hostw) {
   if (st->done) return;
+  if (k < 0) k = st->iters + 1;
   const double rr = sum_partials(part_rr, g);
   double ob = 0.0;
   if (obj_kind == 2) ob = sum_partials(part_obj, g);
@@ -438,14 +449,19 @@ __global__ void __launch_bounds__(kBlock)
     st->iters = k;
     if (obj_kind == 1) record_obj(st, k, sqrt(rr), tol);
     if (obj_kind == 2) record_obj(st, k, -0.5 * ob, tol);
+    publish(st, hostw);
   }
 }
 
 __global__ void __launch_bounds__(kBlock)
-    k_sc_obj(CgState *st, const double *part_obj, int g, int k, double tol) {
+    k_sc_obj(CgState *st, const double *part_obj, int g, int k, double tol, unsigned long long *hostw) {
   if (st->done) return;
+  if (k < 0) k = st->iters;
   const double ob = sum_partials(part_obj, g);
-  if (threadIdx.x == 0) record_obj(st, k, 0.5 * ob, tol);
+  if (threadIdx.x == 0) {
+    record_obj(st, k, 0.5 * ob, tol);
+    publish(st, hostw);
+  }
 }
 
 __global__ void __launch_bounds__(kBlock) k_sum_to(const double *part, int g, double *out) {
@@ -527,20 +543,21 @@ void launch_axpy(float a, const float *x, float *y, size_t n, hipStream_t st) {
                      dim3(kBlock), 0, st, a, x, y, n);
 }
 void launch_sc_init(CgState *s, const double *part_rr, const double *part_obj, int g, int mode,
-                    int check, hipStream_t st) {
+                    int check, unsigned long long *hostw, hipStream_t st) {
   hipLaunchKernelGGL(k_sc_init, dim3(1), dim3(kBlock), 0, st, s, part_rr, part_obj, g, mode,
-                     check);
+                     check, hostw);
 }
 void launch_sc_alpha(CgState *s, const double *part, int g, hipStream_t st) {
   hipLaunchKernelGGL(k_sc_alpha, dim3(1), dim3(kBlock), 0, st, s, part, g);
 }
 void launch_sc_beta(CgState *s, const double *part_rr, const double *part_obj, int g, int k,
-                    int obj_kind, double tol, hipStream_t st) {
+                    int obj_kind, double tol, unsigned long long *hostw, hipStream_t st) {
   hipLaunchKernelGGL(k_sc_beta, dim3(1), dim3(kBlock), 0, st, s, part_rr, part_obj, g, k,
-                     obj_kind, tol);
+                     obj_kind, tol, hostw);
 }
-void launch_sc_obj(CgState *s, const double *part, int g, int k, double tol, hipStream_t st) {
-  hipLaunchKernelGGL(k_sc_obj, dim3(1), dim3(kBlock), 0, st, s, part, g, k, tol);
+void launch_sc_obj(CgState *s, const double *part, int g, int k, double tol, unsigned long long *hostw,
+                   hipStream_t st) {
+  hipLaunchKernelGGL(k_sc_obj, dim3(1), dim3(kBlock), 0, st, s, part, g, k, tol, hostw);
 }
 void launch_sum_to(const double *part, int g, double *out, hipStream_t st) {
   hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(kBlock), 0, st, part, g, out);

@@ -9,10 +9,17 @@ constexpr int kMaxCgIter = 4096;
 struct CgState {  // lives in device memory, owned by the plan
   double rz, pAp, alpha, beta, obj_max, obj_min;
   int done, iters;
+  unsigned gen, pad_;  // solves started on this plan (k_sc_init counts); tags the published progress word
   double rzpp[2];  // r.z of iterations k (slot k & 1) and k - 1: the folded kernels read one slot while
                    // workgroup 0 of the same launch writes the other
-  double obj[kMaxCgIter + 1];
+  double obj[kMaxCgIter + 1];  // objective trace; iteration k at slot k % (kMaxCgIter + 1)
 };
+
+// Progress word of a solve, published by its scalar kernels to host-mapped memory (chunked solves,
+// api.hip): generation << 32 | done << 31 | iterations completed.
+__host__ __device__ inline unsigned long long cg_progress_word(unsigned gen, int done, int iters) {
+  return ((unsigned long long)gen << 32) | (done ? 0x80000000ull : 0ull) | (unsigned)(iters & 0x7fffffff);
+}
 
 int vec_num_blocks(size_t n);  // grid (= number of partials) of the vector kernels
 void launch_residual_init(const float *b, const float *ax, const float *x, float *r, float *p,
@@ -32,12 +39,16 @@ void launch_scale_shift(float a, float c, float *y, size_t n, hipStream_t st);
 void launch_fill(float v, float *y, size_t n, hipStream_t st);
 void launch_div(const float *a, const float *m, float *y, size_t n, hipStream_t st);  // y = a / m
 void launch_axpy(float a, const float *x, float *y, size_t n, hipStream_t st);
+// hostw (nullable): host-mapped progress word, written (system scope) when an iteration's last scalar
+// kernel has run.  k < 0 in sc_beta / sc_obj: the iteration index is the state's own counter (iters + 1 /
+// iters), so that a captured chunk of iterations can be replayed for any part of a solve.
 void launch_sc_init(CgState *s, const double *part_rr, const double *part_obj, int g, int mode,
-                    int check, hipStream_t st);
+                    int check, unsigned long long *hostw, hipStream_t st);
 void launch_sc_alpha(CgState *s, const double *part, int g, hipStream_t st);
 void launch_sc_beta(CgState *s, const double *part_rr, const double *part_obj, int g, int k,
-                    int obj_kind, double tol, hipStream_t st);
-void launch_sc_obj(CgState *s, const double *part, int g, int k, double tol, hipStream_t st);
+                    int obj_kind, double tol, unsigned long long *hostw, hipStream_t st);
+void launch_sc_obj(CgState *s, const double *part, int g, int k, double tol, unsigned long long *hostw,
+                   hipStream_t st);
 void launch_sum_to(const double *part, int g, double *out, hipStream_t st);
 // Folded forms (no scalar kernels between the matvec and the vector updates): EVERY workgroup
 // re-reduces the producer's partial sums in a fixed order in its prologue - visibility comes from

@@ -38,7 +38,9 @@ def cg(A, b, x=None, precond=None, max_iter=None, tolerance=1e-5, verbose=False,
     if sum_dtype != torch.float64:
         raise NotImplementedError('dot products accumulate in float64')
     if max_iter is None:
-        max_iter = 4096
+        # nitorch: 10 numel.  With a tolerance the solve is enqueued chunk by chunk and takes any budget;
+        # without one every iteration would really run, and one captured solve holds 4 096 of them
+        max_iter = 10 * b.numel() if tolerance else 4096
     if x is None:
         x = torch.zeros_like(b)
     elif not inplace:
