@@ -168,7 +168,8 @@ int64_t unires_plan_workspace_bytes(const unires_plan_t *plan);
 int unires_plan_repeat_info(const unires_plan_t *plan, int32_t n, int32_t info[8]);
 /* Measurement aid (no counterpart in the reference; bench.py's roofline leg).  While on,
  * unires_cg_solve launches its kernels one by one (no hipGraph replay) and brackets every operator
- * application A(p) of the solve with HIP events on the caller's stream. */
+ * application A(p) of the solve with HIP events on the caller's stream.  Meaningful with tol == 0
+ * only: launches enqueued after a solve has converged return at entry and are still counted. */
 int unires_plan_time_matvecs(unires_plan_t *plan, int32_t on);
 /* Waits for the recorded events; returns how many applications were recorded since the last call and
  * the sum of their durations (microseconds), and forgets them. */

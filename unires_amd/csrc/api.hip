@@ -11,6 +11,8 @@
 #include <sched.h>
 
 #include <functional>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -1650,10 +1652,30 @@ extern "C" int unires_nll_prior(const float *const *y_ptrs, const float *lam, in
   if (!vx_ok(vx)) return fail(UNIRES_ERR_ARG, "voxel size must be positive");
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(double), st));
-  float *acc = nullptr;  // more than 8 channels: the running sum of squares needs a volume of scratch
-  if (n_channels > 8) HIP_TRY(hipMallocAsync((void **)&acc, mk(dim).numel() * sizeof(float), st));
+  // more than 8 channels: the running sum of squares needs a volume of scratch.  It is kept (one per
+  // device, grown on demand, used in stream order by the chained launches) instead of allocated and freed
+  // per call: no allocation inside a stream capture, nothing to leak on an error path
+  float *acc = nullptr;
+  if (n_channels > 8) {
+    static std::mutex mu;
+    static std::map<int, std::pair<float *, size_t>> scratch;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const size_t need = mk(dim).numel() * sizeof(float);
+    std::lock_guard<std::mutex> lock(mu);
+    auto &slot = scratch[dev];
+    if (slot.second < need) {
+      if (slot.first) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(slot.first);
+        slot = {nullptr, 0};
+      }
+      HIP_TRY(hipMalloc((void **)&slot.first, need));
+      slot.second = need;
+    }
+    acc = slot.first;
+  }
   launch_jtv_scale(y_ptrs, lam, n_channels, nullptr, nullptr, mk(dim), vx, 1.f, 1.f, acc, out_dev, 1, st);
-  if (acc) HIP_TRY(hipFreeAsync(acc, st));
   CHECK_LAUNCH();
   return UNIRES_OK;
 }

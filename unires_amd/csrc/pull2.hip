@@ -179,6 +179,8 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   constexpr int ROWS = GEN ? kP2Rows : TI * TJ, RPW = ROWS / NW, SCR = GEN ? kWave + 1 : kP2Scr;
   constexpr int HALF = RPW % 8 == 0 ? 8 : (RPW % 6 == 0 ? 6 : 4);
   static_assert(TI * TJ <= kP2Rows && ROWS % NW == 0 && RPW % HALF == 0, "rows per wave");
+  // the extended chunk's extra grid points of a wave's rows are sampled in ONE pass, lane = (row, extra)
+  static_assert(GEN || RPW * kP2MaxExt <= kWave, "extras of a wave's rows must fit one pass of 64 lanes");
   extern __shared__ __align__(16) float win[];  // W * H columns x SZ planes
   __shared__ int tab[SZ4 + 2];                  // per plane group: -(ox * H + oy) * SZ, in floats
   __shared__ int2 org[SZ4];
