@@ -19,9 +19,11 @@
 // z operator is the 3 x 3 blend B of nine neighbouring lines (eight of them L2 hits: every line is
 // somebody's centre), and the z operator reads its taps per x-space voxel from a table.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -44,6 +46,12 @@ struct ShiftArgs {
   const float4 *e;         // [nz] {bits(kb), e0, e1, e2}
   float tau, a0, sx, sy, sz;  // sx.. = c / vx^2 of the stencil term
   int padl, padr, wave_floats;
+  int xr;  // x-marching form: planes per run
+  const float4 *e4;  // lane-window rows: [nz] weights on xs[kmin[lane] .. + 3]
+  const int *kmin;   // [64]
+  int lw;            // 1: lane-window form of the z operator (xdz <= 64, four-entry windows)
+  int dbg;           // measurement only (UNIRES_SHIFT_DBG): 1 no z operator, 2 no stores, 8 plain stores
+  unsigned long long *prof;  // -DUNIRES_SHIFT_PROF builds: per wave {steps, total, load wait, z operator, stencil + store} clocks
 };
 
 typedef float sf4 __attribute__((ext_vector_type(4)));
@@ -53,6 +61,19 @@ __device__ __forceinline__ float s4_lower(float v) {  // lane l gets lane l - 1'
 }
 __device__ __forceinline__ float s4_upper(float v) {  // lane l gets lane l + 1's value (lane 63: 0)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+// One x-space voxel of the z operator: sum_t f[t] B[t], taps four at a time with their eight LDS reads in
+// flight together (rows of the table beyond nf are zero; the reads they pair with stay inside the wave's
+// buffer: pl is followed by the x-space line).  Same products in the same order as a tap-by-tap loop.
+__device__ __forceinline__ float zline_taps(const float *bin, const float *fk, int xdz, int nf) {
+  float acc = 0.f;
+  for (int t0 = 0; t0 < nf; t0 += 4) {
+    const float f0 = fk[t0 * xdz], f1 = fk[(t0 + 1) * xdz], f2 = fk[(t0 + 2) * xdz], f3 = fk[(t0 + 3) * xdz];
+    const float b0 = bin[t0], b1 = bin[t0 + 1], b2 = bin[t0 + 2], b3 = bin[t0 + 3];
+    acc = fmaf(f3, b3, fmaf(f2, b2, fmaf(f1, b1, fmaf(f0, b0, acc))));
+  }
+  return acc;
 }
 
 // nz % 4 == 0, nz <= 256: one 16-byte vector per lane and line
@@ -66,7 +87,12 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift(ShiftArgs A, const int *__
   const int nz = dd.z;
   float *fl = smem;                                            // f: xdz x kShiftMaxTaps, shared by the workgroup
   float *buf = smem + A.xdz * kShiftMaxTaps + w * A.wave_floats;  // (wave_floats, padl: multiples of 4)
-  for (int i = threadIdx.y * kWave + lane; i < A.xdz * kShiftMaxTaps; i += kBlock) fl[i] = A.f[i];
+  // the taps of x-space voxel k in LDS as fl[t * xdz + k]: lane = k reads consecutive words (the [k][t] layout
+  // of the host table put sixteen lanes on one bank)
+  for (int i = threadIdx.y * kWave + lane; i < A.xdz * kShiftMaxTaps; i += kBlock) {
+    const int k = i / kShiftMaxTaps, t = i - k * kShiftMaxTaps;
+    fl[t * A.xdz + k] = A.f[i];
+  }
   float *pl = buf + A.padl;               // the blended line with zero aprons
   float *xs = pl + nz + A.padr;           // x-space line + two zero pads
   for (int i = lane; i < A.wave_floats; i += kWave) buf[i] = 0.f;
@@ -121,11 +147,7 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift(ShiftArgs A, const int *__
     for (int k0 = 0; k0 < A.xdz; k0 += kWave) {
       const int k = k0 + (int)lane;
       if (k < A.xdz) {
-        const float *bin = pl + (k * A.s + A.oz);  // aprons: no bounds checks on the taps
-        const float *fk = fl + k * kShiftMaxTaps;
-        float acc = 0.f;
-        for (int t = 0; t < A.nf; ++t) acc = fmaf(fk[t], bin[t], acc);
-        xs[k] = acc;
+        xs[k] = zline_taps(pl + (k * A.s + A.oz), fl + k, A.xdz, A.nf);  // aprons: no bounds checks on the taps
       }
     }
     asm volatile("" ::: "memory");
@@ -180,7 +202,12 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift2(ShiftArgs A, const int *_
   const int nz = dd.z;
   float *fl = smem;
   float *buf = smem + A.xdz * kShiftMaxTaps + w * 2 * A.wave_floats;
-  for (int i = threadIdx.y * kWave + lane; i < A.xdz * kShiftMaxTaps; i += kBlock) fl[i] = A.f[i];
+  // the taps of x-space voxel k in LDS as fl[t * xdz + k]: lane = k reads consecutive words (the [k][t] layout
+  // of the host table put sixteen lanes on one bank)
+  for (int i = threadIdx.y * kWave + lane; i < A.xdz * kShiftMaxTaps; i += kBlock) {
+    const int k = i / kShiftMaxTaps, t = i - k * kShiftMaxTaps;
+    fl[t * A.xdz + k] = A.f[i];
+  }
   float *pl[2] = {buf + A.padl, buf + A.wave_floats + A.padl};
   float *xs[2] = {pl[0] + nz + A.padr, pl[1] + nz + A.padr};
   for (int i = lane; i < 2 * A.wave_floats; i += kWave) buf[i] = 0.f;
@@ -240,11 +267,7 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift2(ShiftArgs A, const int *_
       for (int k0 = 0; k0 < A.xdz; k0 += kWave) {
         const int k = k0 + (int)lane;
         if (k < A.xdz) {
-          const float *bin = pl[l] + (k * A.s + A.oz);
-          const float *fk = fl + k * kShiftMaxTaps;
-          float acc = 0.f;
-          for (int t = 0; t < A.nf; ++t) acc = fmaf(fk[t], bin[t], acc);
-          xs[l][k] = acc;
+          xs[l][k] = zline_taps(pl[l] + (k * A.s + A.oz), fl + k, A.xdz, A.nf);  // aprons: no bounds checks on the taps
         }
       }
     asm volatile("" ::: "memory");
@@ -294,6 +317,255 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift2(ShiftArgs A, const int *_
   }
 }
 
+// x-marching form (round 4).  A wave owns a PAIR of y-adjacent lines over a run of `xr` x planes and walks
+// along x: the 3 x 3 blend factorises, B(x) = cx- R(x-1) + cx0 R(x) + cx+ R(x+1) with R(x) = the y blend of
+// plane x, so a plane's four lines (the pair and its two y neighbours) are loaded ONCE, reduced to two
+// rows R and kept in registers with the pair's centres for the next two planes - four vector loads per
+// plane for two output lines (+ two planes of run-in per run) where k_ata_shift2 issues twelve per pair,
+// every one of them a different L2 line of another wave's centre.  The next plane's loads are in flight
+// while a plane is computed; the z operator and the stencil are k_ata_shift2's.
+// NL = lines per wave (1 or 2): with one line a wave's plane state halves (4 waves per SIMD instead of 2); with
+// two, a plane costs four loads for two lines instead of three for one.
+//
+// The instruction stream is what bounds this kernel (a step's loads have long arrived when it looks for them;
+// -DUNIRES_SHIFT_PROF timeline), so the step is written for few instructions: four plane slots
+// that change ROLES (previous / current / next / in flight) instead of registers being copied, the walk
+// unrolled by four; everything in 4-vectors, which the compiler packs into v_pk_* instructions; the
+// volume's faces on a path of their own, so that the interior carries no selects; pointers bumped, not
+// recomputed; the lane's conv_up rows transposed (one vector per window entry).
+template <int NL, bool DOT, bool OBJ>
+__global__ void __launch_bounds__(kBlock) k_ata_shift_m(ShiftArgs A, const int *__restrict__ done) {
+  if (done && *done) return;
+  extern __shared__ __align__(16) float smem[];
+  const unsigned lane = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const Dim3i dd = A.dd;
+  const int nz = dd.z;
+  float *fl = smem;
+  float *cxl = smem + A.xdz * kShiftMaxTaps;  // rows of the x blend (a vector load per step would be waited for
+                                              // with vmcnt(0): the next plane's loads, just issued, with it)
+  float4 *el = reinterpret_cast<float4 *>(cxl + 4 * dd.x);  // conv_up rows per output z
+  float *buf = cxl + 4 * dd.x + 4 * nz + w * NL * A.wave_floats;
+  // the taps of x-space voxel k in LDS as fl[t * xdz + k]: lane = k reads consecutive words (the [k][t] layout
+  // of the host table put sixteen lanes on one bank)
+  for (int i = threadIdx.y * kWave + lane; i < A.xdz * kShiftMaxTaps; i += kBlock) {
+    const int k = i / kShiftMaxTaps, t = i - k * kShiftMaxTaps;
+    fl[t * A.xdz + k] = A.f[i];
+  }
+  for (int i = threadIdx.y * kWave + lane; i < 4 * dd.x; i += kBlock) cxl[i] = A.cx[i];
+  for (int i = threadIdx.y * kWave + lane; i < nz; i += kBlock) el[i] = A.lw ? A.e4[i] : A.e[i];
+  float *pl[NL], *xs[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) pl[l] = buf + l * A.wave_floats + A.padl, xs[l] = pl[l] + nz + A.padr;
+  for (int i = lane; i < NL * A.wave_floats; i += kWave) buf[i] = 0.f;
+  __syncthreads();
+  const int z0 = 4 * (int)lane;
+  const bool in = z0 < nz;
+  const float4 *elz = el + (in ? z0 : 0);
+  // lane-window form: the taps of "its" x-space voxel (k = lane) are lane constants, and so are the start of
+  // the x-space window its four outputs read and their rows on it - transposed: tw[j] = the weights of window
+  // entry j in the lane's four outputs
+  float fr[kShiftMaxTaps];
+#pragma unroll
+  for (int t = 0; t < kShiftMaxTaps; ++t) fr[t] = A.lw && (int)lane < A.xdz ? A.f[lane * kShiftMaxTaps + t] : 0.f;
+  const int kmin = A.lw ? A.kmin[lane] : 0;
+  const int bin_off = ((int)lane < A.xdz ? (int)lane : 0) * A.s + A.oz;
+  sf4 tw[4];
+  {
+    const float4 t0 = elz[0], t1 = elz[1], t2 = elz[2], t3 = elz[3];
+    tw[0] = sf4{t0.x, t1.x, t2.x, t3.x}, tw[1] = sf4{t0.y, t1.y, t2.y, t3.y};
+    tw[2] = sf4{t0.z, t1.z, t2.z, t3.z}, tw[3] = sf4{t0.w, t1.w, t2.w, t3.w};
+  }
+  const float *__restrict__ p = A.p;
+  float *__restrict__ q = A.q;
+  const int hyn = dd.y / NL, nxr = (dd.x + A.xr - 1) / A.xr, ntasks = hyn * nxr;
+  const size_t sxl = (size_t)dd.y * nz;
+  const long long syl = nz;
+  double dot = 0.0;
+  const int lb = xcd_chunked_block(blockIdx.x, gridDim.x);
+  const int task_step = gridDim.x * kShiftLines;
+  const int zc = in ? z0 : 0;
+  const sf4 zero = {0.f, 0.f, 0.f, 0.f};
+  const bool lane0 = lane == 0;
+  struct Plane {
+    sf4 v[NL + 2];  // lines vy0 - 1 .. vy0 + NL
+    sf4 r[NL];      // their y blends
+  };
+#ifdef UNIRES_SHIFT_PROF
+  unsigned long long pt_steps = 0, pt_total = 0, pt_wait = 0, pt_z = 0, pt_out = 0;
+  const unsigned long long pt_begin = __builtin_readcyclecounter();
+#define PT_NOW(var) const unsigned long long var = __builtin_readcyclecounter()
+#define PT_PIN(x) asm volatile("" ::"v"(x))
+#else
+#define PT_NOW(var)
+#define PT_PIN(x)
+#endif
+  for (int task = lb * kShiftLines + w; task < ntasks; task += task_step) {
+    const int xr = task / hyn, vy0 = NL * (task - xr * hyn);
+    const int xa = xr * A.xr, xb = min(xa + A.xr, dd.x);
+    const bool ly = vy0 > 0, hy = vy0 + NL < dd.y;
+    // rows of y: vy0 - 1 .. vy0 + NL (missing ones read line vy0; their coefficients are 0)
+    long long oy[NL + 2];
+    oy[0] = ly ? -syl : 0;
+#pragma unroll
+    for (int b = 0; b < NL; ++b) oy[1 + b] = b * syl;
+    oy[NL + 1] = hy ? NL * syl : 0;
+    float4 cyv[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) cyv[l] = *reinterpret_cast<const float4 *>(A.cy + 4 * (vy0 + l));
+    const float *pcol = p + (size_t)vy0 * nz + zc;
+    // the lines of plane vx (a plane outside the volume reads the nearest one; its coefficient is 0)
+    auto load_plane = [&](int vx, Plane &P) {
+      const float *pp = pcol + (size_t)min(max(vx, 0), dd.x - 1) * sxl;
+#pragma unroll
+      for (int b = 0; b < NL + 2; ++b) P.v[b] = *reinterpret_cast<const sf4 *>(pp + oy[b]);
+    };
+    auto rows_of = [&](Plane &P) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l) P.r[l] = cyv[l].x * P.v[l] + cyv[l].y * P.v[l + 1] + cyv[l].z * P.v[l + 2];
+    };
+    // one output plane: prev / cur / next hold planes vx - 1, vx, vx + 1 (next's rows not yet formed), fly
+    // receives plane vx + 2
+    auto step = [&](const Plane &prev, const Plane &cur, Plane &next, Plane &fly, int vx) {
+      const size_t base = ((size_t)vx * dd.y + vy0) * nz;
+      load_plane(vx + 2 < xb + 1 ? vx + 2 : vx + 1, fly);  // in flight over this step
+      sf4 rb[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) rb[l] = OBJ ? *reinterpret_cast<const sf4 *>(A.objb + base + l * syl + zc) : zero;
+      const float4 cxv = *reinterpret_cast<const float4 *>(cxl + 4 * vx);
+      PT_NOW(pt0);
+      rows_of(next);
+      PT_PIN(next.r[0].x);
+      PT_PIN(next.r[NL - 1].w);
+      PT_NOW(pt1);
+      sf4 rc[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        sf4 B = cxv.x * prev.r[l] + cxv.y * cur.r[l] + cxv.z * next.r[l];
+        rc[l] = cur.v[1 + l];
+        if (!in) rc[l] = B = zero;
+        if (in) *reinterpret_cast<sf4 *>(pl[l] + z0) = B;
+      }
+      asm volatile("" ::: "memory");
+      if (A.dbg & 1) {
+      } else if (A.lw) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          const float *bin = pl[l] + bin_off;
+          float acc = 0.f;
+#pragma unroll
+          for (int t0 = 0; t0 < kShiftMaxTaps; t0 += 4)
+            if (t0 < A.nf) {
+              const float b0 = bin[t0], b1 = bin[t0 + 1], b2 = bin[t0 + 2], b3 = bin[t0 + 3];
+              acc = fmaf(fr[t0 + 3], b3, fmaf(fr[t0 + 2], b2, fmaf(fr[t0 + 1], b1, fmaf(fr[t0], b0, acc))));
+            }
+          if ((int)lane < A.xdz) xs[l][lane] = acc;
+        }
+      } else {
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+          for (int k0 = 0; k0 < A.xdz; k0 += kWave) {
+            const int k = k0 + (int)lane;
+            if (k < A.xdz)
+              xs[l][k] = zline_taps(pl[l] + (k * A.s + A.oz), fl + k, A.xdz, A.nf);  // aprons: no bounds checks on the taps
+          }
+      }
+      asm volatile("" ::: "memory");
+#ifdef UNIRES_SHIFT_PROF
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      PT_NOW(pt2);
+      const bool hx = vx + 1 < dd.x, lx = vx > 0;
+      sf4 out[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        const sf4 c = rc[l];
+        // conv_up
+        sf4 h;
+        if (A.lw && !(A.dbg & 1)) {  // the lane's x-space window, read once for its four outputs
+          const float *xo = xs[l] + kmin;
+          h = xo[0] * tw[0] + xo[1] * tw[1] + xo[2] * tw[2] + xo[3] * tw[3];
+        } else {
+          float h4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float4 te = elz[e];
+            const float *xo = xs[l] + __float_as_int(te.x);
+            h4[e] = te.y * xo[0] + te.z * xo[1] + te.w * xo[2];
+          }
+          h = sf4{h4[0], h4[1], h4[2], h4[3]};
+        }
+        // z neighbours across lanes; the line's first voxel has no backward term (zlo := c), its last no
+        // forward neighbour (a zero comes in from beyond lane 63 / the zero vector of the lanes past nz)
+        float zlo = s4_lower(c.w);
+        const float zhi = s4_upper(c.x);
+        zlo = lane0 ? c.x : zlo;
+        const sf4 zm = {zlo, c.x, c.y, c.z}, zp = {c.y, c.z, c.w, zhi};
+        const sf4 xp = next.v[1 + l], xm = prev.v[1 + l], yp = cur.v[2 + l], ym = cur.v[l];
+        const bool lyl = l == 0 ? ly : true, hyl = l == NL - 1 ? hy : true;
+        sf4 dx, dy;
+        if (hx && lx && lyl && hyl) {  // interior of the volume in x and y (wave-uniform)
+          dx = (c - xm) - (xp - c), dy = (c - ym) - (yp - c);
+        } else {
+          const sf4 xf = (hx ? xp : zero) - c, xbk = lx ? c - xm : zero;
+          const sf4 yf = (hyl ? yp : zero) - c, ybk = lyl ? c - ym : zero;
+          dx = xbk - xf, dy = ybk - yf;
+        }
+        const sf4 dz = (c - zm) - (zp - c);
+        out[l] = A.tau * h + A.a0 * c + (A.sx * dx + A.sy * dy + A.sz * dz);
+      }
+      asm volatile("" ::: "memory");
+      if (in) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          if (OBJ) {
+            dot += (double)obj_term(out[l].x, rb[l].x, rc[l].x) + (double)obj_term(out[l].y, rb[l].y, rc[l].y) +
+                   (double)obj_term(out[l].z, rb[l].z, rc[l].z) + (double)obj_term(out[l].w, rb[l].w, rc[l].w);
+          } else {
+            if (A.dbg & 8)
+              *reinterpret_cast<sf4 *>(q + base + l * syl + z0) = out[l];
+            else if (!(A.dbg & 2))
+              __builtin_nontemporal_store(out[l], reinterpret_cast<sf4 *>(q + base + l * syl + z0));
+            if (DOT)
+              dot += ((double)__fmul_rn(rc[l].x, out[l].x) + (double)__fmul_rn(rc[l].y, out[l].y)) +
+                     ((double)__fmul_rn(rc[l].z, out[l].z) + (double)__fmul_rn(rc[l].w, out[l].w));
+          }
+        }
+      }
+#ifdef UNIRES_SHIFT_PROF
+      {
+        PT_NOW(pt3);
+        pt_steps += 1, pt_wait += pt1 - pt0, pt_z += pt2 - pt1, pt_out += pt3 - pt2;
+      }
+#endif
+    };
+    Plane P0, P1, P2, P3;
+    load_plane(xa - 1, P0);
+    load_plane(xa, P1);
+    load_plane(xa + 1, P2);
+    rows_of(P0);
+    rows_of(P1);
+    for (int vx = xa; vx < xb; vx += 4) {  // the slots change roles: no register moves
+      step(P0, P1, P2, P3, vx);
+      if (vx + 1 < xb) step(P1, P2, P3, P0, vx + 1);
+      if (vx + 2 < xb) step(P2, P3, P0, P1, vx + 2);
+      if (vx + 3 < xb) step(P3, P0, P1, P2, vx + 3);
+      else break;
+    }
+  }
+#ifdef UNIRES_SHIFT_PROF
+  pt_total = __builtin_readcyclecounter() - pt_begin;
+  if (A.prof && lane == 0) {
+    unsigned long long *o = A.prof + ((size_t)blockIdx.x * kShiftLines + w) * 8;
+    o[0] = pt_steps, o[1] = pt_total, o[2] = pt_wait, o[3] = pt_z, o[4] = pt_out, o[5] = pt_begin;
+  }
+#endif
+  if (DOT) {
+    const double tot = block_sum(dot);
+    if (threadIdx.x == 0 && threadIdx.y == 0) A.partials[blockIdx.x] = tot;
+  }
+}
+
 // --------------------------------------------------------------------------
 // host: the three factors of AtA
 // --------------------------------------------------------------------------
@@ -302,8 +574,27 @@ void shift_free(ShiftPlan &S) {
   S = ShiftPlan();
 }
 
+// x-marching form: planes per run - as long as the chip still gets ~UNIRES_SHIFT_TASKS wave tasks (0: form off)
+static int shift_nl(Dim3i dd) {  // lines per wave of the marching form
+  static const int nl = getenv("UNIRES_SHIFT_NL") ? atoi(getenv("UNIRES_SHIFT_NL")) : 2;
+  return nl == 2 && dd.y % 2 == 0 ? 2 : 1;
+}
+
+static int shift_xr(Dim3i dd) {
+  static const int march = getenv("UNIRES_SHIFT_MARCH") ? atoi(getenv("UNIRES_SHIFT_MARCH")) : -1;  // 0: off, n: xr = n
+  // tasks = the waves the chip holds at once: 2 per SIMD with two lines per wave (233 registers), 3 with one
+  static const int tasks_env = getenv("UNIRES_SHIFT_TASKS") ? atoi(getenv("UNIRES_SHIFT_TASKS")) : 0;
+  if (march == 0 || dd.x > 1024) return 0;  // (the x-blend table sits in LDS)
+  const int tasks = tasks_env > 0 ? tasks_env : (shift_nl(dd) == 2 ? 2048 : 3072);
+  const long long pairs = dd.y / shift_nl(dd);
+  long long xr = march > 0 ? march : ((long long)dd.x * pairs + tasks - 1) / tasks;
+  return (int)std::max<long long>(4, std::min<long long>(xr, dd.x));
+}
+
 int shift_blocks(Dim3i dd) {
-  const long long nb = ((long long)dd.x * dd.y + kShiftLines - 1) / kShiftLines;
+  long long nb = ((long long)dd.x * dd.y + kShiftLines - 1) / kShiftLines;
+  if (const int xr = shift_xr(dd))  // every workgroup of the marching form has tasks (its XCD chunks are of tasks)
+    nb = ((long long)(dd.y / shift_nl(dd)) * ((dd.x + xr - 1) / xr) + kShiftLines - 1) / kShiftLines;
   return (int)(nb < 4096 ? nb : 4096);
 }
 
@@ -414,15 +705,44 @@ int shift_build(ShiftPlan &S, Dim3i dd, Dim3i gd, Dim3i xd, const Taps &T, const
     memcpy(&e[(size_t)z * 4], &first, 4);
     for (int m = 0; m < 3; ++m) e[(size_t)z * 4 + 1 + m] = first + m < xd.z ? (float)row[first + m] : 0.f;
   }
+  // lane-window form of the same rows (x-marching kernel): a lane's four outputs z0 .. z0 + 3 read ONE window
+  // xs[kmin .. kmin + 3] of the x-space line - their rows as weights on those four entries; lw = 0 where the
+  // four rows of some lane span more than four entries (strides below 4: the per-voxel triples serve)
+  std::vector<float> e4((size_t)dd.z * 4, 0.f);
+  std::vector<int> kmin((size_t)kWave, 0);
+  bool lane_window = xd.z <= kWave;
+  for (int L = 0; L < kWave && lane_window; ++L) {
+    int lo = 1 << 30, hi = -1;
+    for (int z = 4 * L; z < std::min(4 * L + 4, dd.z); ++z) {
+      int first;
+      memcpy(&first, &e[(size_t)z * 4], 4);
+      int used = 0;
+      for (int m = 0; m < 3; ++m)
+        if (e[(size_t)z * 4 + 1 + m] != 0.f) used = m + 1;
+      if (used == 0) continue;
+      lo = std::min(lo, first), hi = std::max(hi, first + used - 1);
+    }
+    if (hi < 0) lo = hi = 0;
+    if (hi - lo > 3) lane_window = false;
+    kmin[L] = lo;
+    for (int z = 4 * L; z < std::min(4 * L + 4, dd.z) && lane_window; ++z) {
+      int first;
+      memcpy(&first, &e[(size_t)z * 4], 4);
+      for (int m = 0; m < 3; ++m) {
+        const float wv = e[(size_t)z * 4 + 1 + m];
+        if (wv != 0.f) e4[(size_t)z * 4 + (first + m - lo)] = wv;
+      }
+    }
+  }
   // aprons of the blended line: x-space voxel kk reads B[s kk + oz, s kk + oz + nf)
   const int lo = oz, hi = (xd.z - 1) * s + oz + nf - 1;
   int padl = lo < 0 ? -lo : 0, padr = hi >= dd.z ? hi - dd.z + 1 : 0;
   padl = (padl + 3) & ~3;
   if (padl > 256 || padr > 256) return 1;
-  const int wave_floats = (padl + dd.z + padr + xd.z + 2 + 3) & ~3;
+  const int wave_floats = (padl + dd.z + padr + xd.z + 4 + 3) & ~3;  // (+ 4: a lane window may start at the last voxel)
   if (((size_t)xd.z * kShiftMaxTaps + (size_t)kShiftLines * wave_floats) * sizeof(float) > 60 * 1024) return 1;
-  const size_t n_cx = cx.size(), n_cy = cy.size(), n_f = f.size(), n_e = e.size();
-  const size_t total = n_cx + n_cy + n_f + n_e;
+  const size_t n_cx = cx.size(), n_cy = cy.size(), n_f = f.size(), n_e = e.size(), n_e4 = e4.size(), n_km = kmin.size();
+  const size_t total = n_cx + n_cy + n_f + n_e + n_e4 + n_km;
   if (total > S.cap) {
     if (S.dev) (void)hipFree(S.dev);
     S.dev = nullptr;
@@ -435,8 +755,15 @@ int shift_build(ShiftPlan &S, Dim3i dd, Dim3i gd, Dim3i xd, const Taps &T, const
   all.insert(all.end(), cx.begin(), cx.end());
   all.insert(all.end(), cy.begin(), cy.end());
   all.insert(all.end(), f.begin(), f.end());
+  all.insert(all.end(), e4.begin(), e4.end());
+  for (int v : kmin) {
+    float fv;
+    memcpy(&fv, &v, 4);
+    all.push_back(fv);
+  }
   if (hipMemcpy(S.dev, all.data(), total * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return 1;
   S.o_e = 0, S.o_cx = n_e, S.o_cy = n_e + n_cx, S.o_f = n_e + n_cx + n_cy;
+  S.o_e4 = S.o_f + n_f, S.o_kmin = S.o_e4 + n_e4, S.lane_window = lane_window;
   S.nf = nf, S.s = s, S.oz = oz, S.padl = padl, S.padr = padr, S.wave_floats = wave_floats;
   S.dd = dd, S.xdz = xd.z;
   memcpy(S.key, A.m, sizeof(A.m));
@@ -459,10 +786,65 @@ int launch_ata_shift(const ShiftPlan &S, const float *p, float *q, Dim3i dd, con
   G.cx = S.dev + S.o_cx, G.cy = S.dev + S.o_cy, G.f = S.dev + S.o_f;
   G.tau = tau, G.a0 = a0, G.sx = cx, G.sy = cy, G.sz = cz;
   G.padl = S.padl, G.padr = S.padr, G.wave_floats = S.wave_floats;
+  G.e4 = reinterpret_cast<const float4 *>(S.dev + S.o_e4), G.kmin = reinterpret_cast<const int *>(S.dev + S.o_kmin);
+  static const bool no_lw = getenv("UNIRES_SHIFT_LW") && getenv("UNIRES_SHIFT_LW")[0] == '0';
+  G.lw = S.lane_window && !no_lw ? 1 : 0;
+  static const int dbg = getenv("UNIRES_SHIFT_DBG") ? atoi(getenv("UNIRES_SHIFT_DBG")) : 0;
+  G.dbg = dbg;
   const size_t lds = ((size_t)S.xdz * kShiftMaxTaps + (size_t)kShiftLines * S.wave_floats) * sizeof(float);
   const dim3 grid(shift_blocks(dd)), block(kWave, kShiftLines);
   static const bool no_x2 = getenv("UNIRES_SHIFT_X2") && getenv("UNIRES_SHIFT_X2")[0] == '0';
+  G.xr = shift_xr(dd);
   const size_t lds2 = ((size_t)S.xdz * kShiftMaxTaps + (size_t)2 * kShiftLines * S.wave_floats) * sizeof(float);
+  const int nl = shift_nl(dd);
+  const size_t lds_m = ((size_t)S.xdz * kShiftMaxTaps + (size_t)nl * kShiftLines * S.wave_floats + (size_t)4 * (dd.x + dd.z)) *
+                       sizeof(float);
+  G.prof = nullptr;
+#ifdef UNIRES_SHIFT_PROF
+  static unsigned long long *prof_dev = nullptr;
+  if (!prof_dev) (void)hipMalloc((void **)&prof_dev, (size_t)4096 * kShiftLines * 8 * sizeof(unsigned long long));
+  (void)hipMemsetAsync(prof_dev, 0, (size_t)4096 * kShiftLines * 8 * sizeof(unsigned long long), st);
+  G.prof = prof_dev;
+#endif
+  static const size_t pad_lds = getenv("UNIRES_SHIFT_PADLDS") ? (size_t)atoi(getenv("UNIRES_SHIFT_PADLDS")) : 0;  // (measurement: fewer workgroups per CU)
+  if (G.xr > 0 && lds_m <= 64 * 1024) {
+#define SHIFT_M_LAUNCH(NLV)                                                                       \
+  do {                                                                                            \
+    if (objb)                                                                                     \
+      hipLaunchKernelGGL((k_ata_shift_m<NLV, true, true>), grid, block, lds_m + pad_lds, st, G, done);      \
+    else if (partials)                                                                            \
+      hipLaunchKernelGGL((k_ata_shift_m<NLV, true, false>), grid, block, lds_m + pad_lds, st, G, done);     \
+    else                                                                                          \
+      hipLaunchKernelGGL((k_ata_shift_m<NLV, false, false>), grid, block, lds_m + pad_lds, st, G, done);    \
+  } while (0)
+    if (nl == 2)
+      SHIFT_M_LAUNCH(2);
+    else
+      SHIFT_M_LAUNCH(1);
+#undef SHIFT_M_LAUNCH
+#ifdef UNIRES_SHIFT_PROF
+    {
+      static int shots = 0;
+      if (++shots == 12) {  // one warmed-up launch: mean clocks per step and wave
+        (void)hipStreamSynchronize(st);
+        const size_t nw = (size_t)grid.x * kShiftLines;
+        std::vector<unsigned long long> h(nw * 8);
+        (void)hipMemcpy(h.data(), prof_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double steps = 0, tot = 0, wt = 0, zt = 0, ot = 0;
+        unsigned long long b0 = ~0ull, b1 = 0, e1 = 0;
+        for (size_t i = 0; i < nw; ++i) {
+          if (!h[i * 8]) continue;
+          steps += (double)h[i * 8], tot += (double)h[i * 8 + 1], wt += (double)h[i * 8 + 2], zt += (double)h[i * 8 + 3], ot += (double)h[i * 8 + 4];
+          b0 = std::min(b0, h[i * 8 + 5]), b1 = std::max(b1, h[i * 8 + 5]), e1 = std::max(e1, h[i * 8 + 5] + h[i * 8 + 1]);
+        }
+        fprintf(stderr, "[shift_m] %zu waves, %.0f steps; clocks per step: total %.0f = load wait %.0f + z operator %.0f + stencil / store %.0f "
+                        "+ rest %.0f; waves start within %llu clocks, kernel spans %llu clocks\n",
+                nw, steps, tot / steps, wt / steps, zt / steps, ot / steps, (tot - wt - zt - ot) / steps, b1 - b0, e1 - b0);
+      }
+    }
+#endif
+    return 0;
+  }
   if (!no_x2 && dd.y % 2 == 0 && lds2 <= 64 * 1024) {
     if (objb)
       hipLaunchKernelGGL((k_ata_shift2<true, true>), grid, block, lds2, st, G, done);

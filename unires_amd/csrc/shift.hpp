@@ -8,7 +8,8 @@ namespace unires {
 struct ShiftPlan {
   float *dev = nullptr;
   size_t cap = 0;  // floats allocated
-  size_t o_e = 0, o_cx = 0, o_cy = 0, o_f = 0;
+  size_t o_e = 0, o_cx = 0, o_cy = 0, o_f = 0, o_e4 = 0, o_kmin = 0;
+  bool lane_window = false;  // the lane-window tables (e4, kmin) describe the operator
   int nf = 0, s = 1, oz = 0, padl = 0, padr = 0, wave_floats = 0, xdz = 0;
   Dim3i dd{0, 0, 0};
   float key[12] = {0};  // the affine it was built for
