@@ -1029,6 +1029,11 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
     const Repeat &R = pl->reps[0];
     const float ivx = 1.f / (pl->vx[0] * pl->vx[0]), ivy = 1.f / (pl->vx[1] * pl->vx[1]),
                 ivz = 1.f / (pl->vx[2] * pl->vx[2]);
+    // (UNIRES_SHIFT_INT=1: integer shifts too go through the x-marching kernel of shift.hip)
+    static const bool shift_first = getenv("UNIRES_SHIFT_INT") && getenv("UNIRES_SHIFT_INT")[0] == '1';
+    if (shift_first &&
+        !launch_ata_shift(R.shift, p, q, pl->dy, R.Af, R.tau, 0.f, c * ivx, c * ivy, c * ivz, part, objb, done, st))
+      return part ? shift_blocks(pl->dy) : 0;
     if (!launch_ata_aligned(p, q, pl->dy, R.dim_gf, R.dim_x, R.Tf,
                             make_scaling(2.f * R.scl, R.dim_thick), R.Af, R.tau, 0.f, c * ivx,
                             c * ivy, c * ivz, part, objb, done, st))
