@@ -49,6 +49,8 @@ WORKLOADS = {
     # the same with the reference's default in-plane profile (Gaussian, struct.py:95; fan-in > 2)
     'cfg4_384c4_iso2_gauss': dict(dim_y=(384, 384, 384), C=4, thick=2, axes=None, prof_ip=2),
     'small_96c3_thick3': dict(dim_y=(96, 96, 96), C=3, thick=3, axes=(2, 2, 2)),
+    # launch-bound: the device finishes every kernel before the host has enqueued the next (tools/host_time.py)
+    'tiny_32c3_thick2': dict(dim_y=(32, 32, 32), C=3, thick=2, axes=(2, 2, 2)),
     # the shape of the reference's multi-channel demo (demos/demo_multi_channel.ipynb:109-113):
     # 181x217x181, three contrasts, 4 mm slices along x, y and z
     'demo_181c3_thick4xyz': dict(dim_y=(181, 217, 181), C=3, thick=4, axes=(0, 1, 2)),

@@ -9,6 +9,8 @@
 // (alpha == 1 path; over-relaxation is a per-voxel blend with z_old and is built too).
 #include <string.h>
 
+#include <algorithm>
+
 #include "admm.hpp"
 
 namespace unires {
@@ -36,52 +38,56 @@ __device__ __forceinline__ void grad_at(const float *__restrict__ y, size_t idx,
 }
 
 // s = shrinkage factor of the joint TV norm (written to `scale`); optional partial of
-// sum(n) (the -ln p(y) term of the objective when called with w = 0, rho = 1)
+// sum(n) (the -ln p(y) term of the objective when called with w = 0, rho = 1).
+// A workgroup owns one 64 x 4 patch of (z, y) and walks along x in steps of gridDim.z planes: no index
+// divisions (r3's flat tile loop paid two 64-bit divisions per tile: 1.6 - 2.9 TB/s); NC channels compiled
+// in (0: any number up to 8), so that the 7 loads per channel and voxel of all channels are in flight
+// together; the sum over channels keeps its order and float32 arithmetic.
+template <int NC>
 __global__ void __launch_bounds__(kBlock)
     k_jtv_scale(ChanPtrs C, const float *__restrict__ w, const float *__restrict__ z_old, Dim3i d,
                 float ivx, float ivy, float ivz, float rho, float alpha, float *__restrict__ scale,
                 double *__restrict__ partials /* single accumulator */, int norm_only) {
-  const int tz = (d.z + kWave - 1) / kWave, ty = (d.y + 3) / 4;
-  const long long ntiles = (long long)tz * ty * d.x;
   const size_t n = d.numel();
   const float irho = 1.f / rho;
   double tot = 0.0;
-  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int kc = (int)(t % tz);
-    const long long t2 = t / tz;
-    const int jq = (int)(t2 % ty), i = (int)(t2 / ty);
-    const int k = kc * kWave + threadIdx.x, j = jq * 4 + threadIdx.y;
-    if (k >= d.z || j >= d.y) continue;
-    const size_t idx = ((size_t)i * d.y + j) * d.z + k;
-    // (more than 8 channels: the sum over channels continues, in the same order and the same float32
-    // arithmetic, from the value the previous launch left in `scale`)
-    float acc = C.first ? 0.f : scale[idx];
-    for (int c = 0; c < C.n; ++c) {
-      float gx, gy, gz;
-      grad_at(C.y[c], idx, i, j, k, d, C.lam[c] * ivx, C.lam[c] * ivy, C.lam[c] * ivz, gx, gy, gz);
-      const size_t o = (size_t)(C.c0 + c) * 3 * n + idx;
-      if (alpha != 1.f) {  // Dy = alpha*Dy + (1-alpha)*z_old   (_update.py:169-170)
-        gx = alpha * gx + (1.f - alpha) * z_old[o];
-        gy = alpha * gy + (1.f - alpha) * z_old[o + n];
-        gz = alpha * gz + (1.f - alpha) * z_old[o + 2 * n];
+  const int k = blockIdx.x * kWave + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+  const bool inside = k < d.z && j < d.y;
+  const int nc = NC ? NC : C.n;
+  if (inside)
+    for (int i = blockIdx.z; i < d.x; i += gridDim.z) {
+      const size_t idx = ((size_t)i * d.y + j) * d.z + k;
+      // (more than 8 channels: the sum over channels continues, in the same order and the same float32
+      // arithmetic, from the value the previous launch left in `scale`)
+      float acc = C.first ? 0.f : scale[idx];
+#pragma unroll
+      for (int c = 0; c < (NC ? NC : 8); ++c) {
+        if (c >= nc) break;
+        float gx, gy, gz;
+        grad_at(C.y[c], idx, i, j, k, d, C.lam[c] * ivx, C.lam[c] * ivy, C.lam[c] * ivz, gx, gy, gz);
+        const size_t o = (size_t)(C.c0 + c) * 3 * n + idx;
+        if (alpha != 1.f) {  // Dy = alpha*Dy + (1-alpha)*z_old   (_update.py:169-170)
+          gx = alpha * gx + (1.f - alpha) * z_old[o];
+          gy = alpha * gy + (1.f - alpha) * z_old[o + n];
+          gz = alpha * gz + (1.f - alpha) * z_old[o + 2 * n];
+        }
+        if (!norm_only) {
+          gx += w[o] * irho, gy += w[o + n] * irho, gz += w[o + 2 * n] * irho;
+        }
+        acc += gx * gx + gy * gy + gz * gz;
       }
-      if (!norm_only) {
-        gx += w[o] * irho, gy += w[o + n] * irho, gz += w[o + 2 * n] * irho;
+      if (!C.last) {
+        scale[idx] = acc;
+        continue;
       }
-      acc += gx * gx + gy * gy + gz * gz;
+      const float nrm = sqrtf(acc);
+      if (norm_only) {
+        tot += (double)nrm;
+      } else {
+        scale[idx] = fmaxf(nrm - irho, 0.f) / (nrm + 1e-7f);
+      }
     }
-    if (!C.last) {
-      scale[idx] = acc;
-      continue;
-    }
-    const float nrm = sqrtf(acc);
-    if (norm_only) {
-      tot += (double)nrm;
-    } else {
-      scale[idx] = fmaxf(nrm - irho, 0.f) / (nrm + 1e-7f);
-    }
-  }
-  if (partials && C.last) {  // one float64 atomic per workgroup (<= 2048 per launch, once per ADMM iteration)
+  if (partials && C.last) {  // one float64 atomic per workgroup (<= 4096 per launch, once per ADMM iteration)
     const double s = block_sum(tot);
     if (threadIdx.x == 0 && threadIdx.y == 0) atomicAdd(partials, s);
   }
@@ -253,14 +259,28 @@ int launch_jtv_scale(const float *const *y, const float *lam, int nc, const floa
   // C); the kernel takes 8 channel pointers by value, so more channels run as a chain of launches
   // that carry the running sum of squares in `scale`.
   if (nc > 8 && !scale) return -1;
-  const int g = tile_blocks(d);
+  // (z, y) patches x as many x slots as keep the launch at ~4096 workgroups
+  const int tz = (d.z + kWave - 1) / kWave, ty = (d.y + 3) / 4;
+  int gx = (int)std::min<long long>(d.x, std::max<long long>(1, 4096 / ((long long)tz * ty)));
+  if ((long long)tz * ty * gx > 65535ll * 16) gx = 1;
+  const dim3 grid(tz, ty, gx);
+  const int g = tz * ty * gx;
   for (int c0 = 0; c0 < nc; c0 += 8) {
     ChanPtrs C;
     C.n = nc - c0 < 8 ? nc - c0 : 8;
     C.c0 = c0, C.first = c0 == 0, C.last = c0 + 8 >= nc;
     for (int c = 0; c < 8; ++c) C.y[c] = y[c0 + (c < C.n ? c : 0)], C.lam[c] = lam[c0 + (c < C.n ? c : 0)];
-    hipLaunchKernelGGL(k_jtv_scale, dim3(g), vblock(), 0, st, C, w, z_old, d, 1.f / vx[0],
-                       1.f / vx[1], 1.f / vx[2], rho, alpha, scale, partials, norm_only);
+#define JTV_LAUNCH(NCV)                                                                               \
+  hipLaunchKernelGGL(k_jtv_scale<NCV>, grid, vblock(), 0, st, C, w, z_old, d, 1.f / vx[0], 1.f / vx[1], \
+                     1.f / vx[2], rho, alpha, scale, partials, norm_only)
+    switch (C.n) {
+      case 1: JTV_LAUNCH(1); break;
+      case 2: JTV_LAUNCH(2); break;
+      case 3: JTV_LAUNCH(3); break;
+      case 4: JTV_LAUNCH(4); break;
+      default: JTV_LAUNCH(0); break;
+    }
+#undef JTV_LAUNCH
   }
   return g;
 }

@@ -8,7 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <sched.h>
+#include <time.h>
 
 #include <functional>
 #include <map>
@@ -1452,7 +1452,13 @@ static int cg_runs_drive(std::vector<CgRun> &runs) {
       all = all && R.finished;
     }
     if (all) return UNIRES_OK;
-    if ((++spins & 0x3ff) == 0) {
+    // a chunk is hundreds of microseconds of device work and one more is queued behind it: after a short spin
+    // the thread sleeps between looks (eight ranks on one host must not each burn a core on the wait)
+    if (++spins > 256) {
+      const struct timespec nap = {0, 20000};
+      (void)nanosleep(&nap, nullptr);
+    }
+    if ((spins & 0x3ff) == 0 || (spins > 256 && (spins & 0xf) == 0)) {
       for (CgRun &R : runs) {
         if (R.finished) continue;
         const hipError_t q = hipStreamQuery(R.st);
@@ -1469,7 +1475,6 @@ static int cg_runs_drive(std::vector<CgRun> &runs) {
           return UNIRES_ERR_HIP;
         }
       }
-      sched_yield();
     }
   }
 }
