@@ -50,6 +50,7 @@ struct ShiftArgs {
   const float4 *e4;  // lane-window rows: [nz] weights on xs[kmin[lane] .. + 3]
   const int *kmin;   // [64]
   int lw;            // 1: lane-window form of the z operator (xdz <= 64, four-entry windows)
+  int defer;         // 1: a step's stores are issued behind the next step's loads
   int dbg;           // measurement only (UNIRES_SHIFT_DBG): 1 no z operator, 2 no stores, 8 plain stores
   unsigned long long *prof;  // -DUNIRES_SHIFT_PROF builds: per wave {steps, total, load wait, z operator, stencil + store} clocks
 };
@@ -426,9 +427,27 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift_m(ShiftArgs A, const int *
     };
     // one output plane: prev / cur / next hold planes vx - 1, vx, vx + 1 (next's rows not yet formed), fly
     // receives plane vx + 2
+    // (UNIRES_SHIFT_DEFER=1, measured and left off: the stores of a step issued at the START of the next one,
+    // right behind its loads, as in the copy loop of tools/mb_stream.hip that walks the same planes in 25 us -
+    // 39.3 us against 37.1)
+    sf4 pend[NL];
+    float *pend_q = nullptr;
+    auto flush = [&]() {
+      if (pend_q && in) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          if (A.dbg & 8)
+            *reinterpret_cast<sf4 *>(pend_q + l * syl) = pend[l];
+          else if (!(A.dbg & 2))
+            __builtin_nontemporal_store(pend[l], reinterpret_cast<sf4 *>(pend_q + l * syl));
+        }
+      }
+      pend_q = nullptr;
+    };
     auto step = [&](const Plane &prev, const Plane &cur, Plane &next, Plane &fly, int vx) {
       const size_t base = ((size_t)vx * dd.y + vy0) * nz;
       load_plane(vx + 2 < xb + 1 ? vx + 2 : vx + 1, fly);  // in flight over this step
+      flush();
       sf4 rb[NL];
 #pragma unroll
       for (int l = 0; l < NL; ++l) rb[l] = OBJ ? *reinterpret_cast<const sf4 *>(A.objb + base + l * syl + zc) : zero;
@@ -522,10 +541,14 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift_m(ShiftArgs A, const int *
             dot += (double)obj_term(out[l].x, rb[l].x, rc[l].x) + (double)obj_term(out[l].y, rb[l].y, rc[l].y) +
                    (double)obj_term(out[l].z, rb[l].z, rc[l].z) + (double)obj_term(out[l].w, rb[l].w, rc[l].w);
           } else {
-            if (A.dbg & 8)
+            if (A.defer) {
+              pend[l] = out[l];
+              pend_q = q + base + z0;
+            } else if (A.dbg & 8) {
               *reinterpret_cast<sf4 *>(q + base + l * syl + z0) = out[l];
-            else if (!(A.dbg & 2))
+            } else if (!(A.dbg & 2)) {
               __builtin_nontemporal_store(out[l], reinterpret_cast<sf4 *>(q + base + l * syl + z0));
+            }
             if (DOT)
               dot += ((double)__fmul_rn(rc[l].x, out[l].x) + (double)__fmul_rn(rc[l].y, out[l].y)) +
                      ((double)__fmul_rn(rc[l].z, out[l].z) + (double)__fmul_rn(rc[l].w, out[l].w));
@@ -552,6 +575,7 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift_m(ShiftArgs A, const int *
       if (vx + 3 < xb) step(P3, P0, P1, P2, vx + 3);
       else break;
     }
+    flush();
   }
 #ifdef UNIRES_SHIFT_PROF
   pt_total = __builtin_readcyclecounter() - pt_begin;
@@ -797,6 +821,8 @@ int launch_ata_shift(const ShiftPlan &S, const float *p, float *q, Dim3i dd, con
   G.lw = S.lane_window && !no_lw ? 1 : 0;
   static const int dbg = getenv("UNIRES_SHIFT_DBG") ? atoi(getenv("UNIRES_SHIFT_DBG")) : 0;
   G.dbg = dbg;
+  static const bool defer = getenv("UNIRES_SHIFT_DEFER") && getenv("UNIRES_SHIFT_DEFER")[0] == '1';
+  G.defer = defer ? 1 : 0;
   const size_t lds = ((size_t)S.xdz * kShiftMaxTaps + (size_t)kShiftLines * S.wave_floats) * sizeof(float);
   const dim3 grid(shift_blocks(dd)), block(kWave, kShiftLines);
   static const bool no_x2 = getenv("UNIRES_SHIFT_X2") && getenv("UNIRES_SHIFT_X2")[0] == '0';
