@@ -42,6 +42,13 @@ CASES = {
                      trans=1.7, scl=0.1),
     'sr_shift_big': dict(dim_y=(13, 11, 40), n_channels=1, thick=4, regime='sr', thick_axes=[2], rot=0.0,
                          trans=6.3),
+    # 256-voxel lines: the fast form of the x-marching kernel (every lane inside the line, lane-window z operator),
+    # two lines per wave / one (odd ny); the same kernel serves integer shifts (rigid = I) there
+    'sr_shift_z256': dict(dim_y=(12, 10, 256), n_channels=2, thick=6, regime='sr', thick_axes=[2, 2], rot=0.0,
+                          trans=2.3, scl=0.1),
+    'sr_shift_z256_odd': dict(dim_y=(9, 11, 256), n_channels=1, thick=4, regime='sr', thick_axes=[2], rot=0.0, trans=1.1),
+    'sr_aligned_z256': dict(dim_y=(10, 12, 256), n_channels=1, thick=6, regime='sr', thick_axes=[2], rot=0.0, trans=0.0,
+                            scl=0.05),
     'dn_shift': dict(dim_y=(15, 13, 12), n_channels=2, regime='dn', rot=0.0, trans=2.4),
     'dn_2ch': dict(dim_y=(15, 13, 11), n_channels=2, regime='dn', rot=0.1, trans=1.5),
     'dn_2rep': dict(dim_y=(12, 12, 10), n_channels=1, regime='dn', n_repeats=2),

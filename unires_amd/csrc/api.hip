@@ -1029,9 +1029,9 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
     const Repeat &R = pl->reps[0];
     const float ivx = 1.f / (pl->vx[0] * pl->vx[0]), ivy = 1.f / (pl->vx[1] * pl->vx[1]),
                 ivz = 1.f / (pl->vx[2] * pl->vx[2]);
-    // (UNIRES_SHIFT_INT=1: integer shifts too go through the x-marching kernel of shift.hip)
-    static const bool shift_first = getenv("UNIRES_SHIFT_INT") && getenv("UNIRES_SHIFT_INT")[0] == '1';
-    if (shift_first &&
+    // where the x-marching kernel's fast form applies it serves integer shifts too (31.5 us against
+    // k_ata_aligned4x2's 36 - 37 at 256^3)
+    if (shift_fast(R.shift, pl->dy) &&
         !launch_ata_shift(R.shift, p, q, pl->dy, R.Af, R.tau, 0.f, c * ivx, c * ivy, c * ivz, part, objb, done, st))
       return part ? shift_blocks(pl->dy) : 0;
     if (!launch_ata_aligned(p, q, pl->dy, R.dim_gf, R.dim_x, R.Tf,

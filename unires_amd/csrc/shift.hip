@@ -334,7 +334,10 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift2(ShiftArgs A, const int *_
 // unrolled by four; everything in 4-vectors, which the compiler packs into v_pk_* instructions; the
 // volume's faces on a path of their own, so that the interior carries no selects; pointers bumped, not
 // recomputed; the lane's conv_up rows transposed (one vector per window entry).
-template <int NL, bool DOT, bool OBJ>
+// FAST: the common case compiled without its run-time alternatives - lane-window z operator, every lane inside
+// the line (nz = 256), no measurement switches: the step then carries a handful of branches instead of ~40
+// (exec-mask juggling and wait counts around them were a third of its instructions).
+template <int NL, bool DOT, bool OBJ, bool FAST>
 __global__ void __launch_bounds__(kBlock) k_ata_shift_m(ShiftArgs A, const int *__restrict__ done) {
   if (done && *done) return;
   extern __shared__ __align__(16) float smem[];
@@ -354,22 +357,25 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift_m(ShiftArgs A, const int *
     fl[t * A.xdz + k] = A.f[i];
   }
   for (int i = threadIdx.y * kWave + lane; i < 4 * dd.x; i += kBlock) cxl[i] = A.cx[i];
-  for (int i = threadIdx.y * kWave + lane; i < nz; i += kBlock) el[i] = A.lw ? A.e4[i] : A.e[i];
+  for (int i = threadIdx.y * kWave + lane; i < nz; i += kBlock) el[i] = (FAST || A.lw) ? A.e4[i] : A.e[i];
   float *pl[NL], *xs[NL];
 #pragma unroll
   for (int l = 0; l < NL; ++l) pl[l] = buf + l * A.wave_floats + A.padl, xs[l] = pl[l] + nz + A.padr;
   for (int i = lane; i < NL * A.wave_floats; i += kWave) buf[i] = 0.f;
   __syncthreads();
   const int z0 = 4 * (int)lane;
-  const bool in = z0 < nz;
+  const bool in = FAST ? true : z0 < nz;
   const float4 *elz = el + (in ? z0 : 0);
+  const bool lw = FAST ? true : A.lw != 0;
+  const int dbg = FAST ? 0 : A.dbg;
+  const bool defer = FAST ? false : A.defer != 0;
   // lane-window form: the taps of "its" x-space voxel (k = lane) are lane constants, and so are the start of
   // the x-space window its four outputs read and their rows on it - transposed: tw[j] = the weights of window
   // entry j in the lane's four outputs
   float fr[kShiftMaxTaps];
 #pragma unroll
-  for (int t = 0; t < kShiftMaxTaps; ++t) fr[t] = A.lw && (int)lane < A.xdz ? A.f[lane * kShiftMaxTaps + t] : 0.f;
-  const int kmin = A.lw ? A.kmin[lane] : 0;
+  for (int t = 0; t < kShiftMaxTaps; ++t) fr[t] = (FAST || A.lw) && (int)lane < A.xdz ? A.f[lane * kShiftMaxTaps + t] : 0.f;
+  const int kmin = (FAST || A.lw) ? A.kmin[lane] : 0;
   const int bin_off = ((int)lane < A.xdz ? (int)lane : 0) * A.s + A.oz;
   sf4 tw[4];
   {
@@ -436,9 +442,9 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift_m(ShiftArgs A, const int *
       if (pend_q && in) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-          if (A.dbg & 8)
+          if (dbg & 8)
             *reinterpret_cast<sf4 *>(pend_q + l * syl) = pend[l];
-          else if (!(A.dbg & 2))
+          else if (!(dbg & 2))
             __builtin_nontemporal_store(pend[l], reinterpret_cast<sf4 *>(pend_q + l * syl));
         }
       }
@@ -466,8 +472,8 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift_m(ShiftArgs A, const int *
         if (in) *reinterpret_cast<sf4 *>(pl[l] + z0) = B;
       }
       asm volatile("" ::: "memory");
-      if (A.dbg & 1) {
-      } else if (A.lw) {
+      if (dbg & 1) {
+      } else if (lw) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
           const float *bin = pl[l] + bin_off;
@@ -501,7 +507,7 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift_m(ShiftArgs A, const int *
         const sf4 c = rc[l];
         // conv_up
         sf4 h;
-        if (A.lw && !(A.dbg & 1)) {  // the lane's x-space window, read once for its four outputs
+        if (lw && !(dbg & 1)) {  // the lane's x-space window, read once for its four outputs
           const float *xo = xs[l] + kmin;
           h = xo[0] * tw[0] + xo[1] * tw[1] + xo[2] * tw[2] + xo[3] * tw[3];
         } else {
@@ -541,12 +547,12 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift_m(ShiftArgs A, const int *
             dot += (double)obj_term(out[l].x, rb[l].x, rc[l].x) + (double)obj_term(out[l].y, rb[l].y, rc[l].y) +
                    (double)obj_term(out[l].z, rb[l].z, rc[l].z) + (double)obj_term(out[l].w, rb[l].w, rc[l].w);
           } else {
-            if (A.defer) {
+            if (defer) {
               pend[l] = out[l];
               pend_q = q + base + z0;
-            } else if (A.dbg & 8) {
+            } else if (dbg & 8) {
               *reinterpret_cast<sf4 *>(q + base + l * syl + z0) = out[l];
-            } else if (!(A.dbg & 2)) {
+            } else if (!(dbg & 2)) {
               __builtin_nontemporal_store(out[l], reinterpret_cast<sf4 *>(q + base + l * syl + z0));
             }
             if (DOT)
@@ -620,6 +626,15 @@ static int shift_xr(Dim3i dd) {
   return (int)xr;
 }
 
+// true: the x-marching kernel's fast form serves this operator (lane-window z operator, 256-voxel lines)
+bool shift_fast(const ShiftPlan &S, Dim3i dd) {
+  static const bool no_fast = getenv("UNIRES_SHIFT_FAST") && getenv("UNIRES_SHIFT_FAST")[0] == '0';
+  static const bool no_lw = getenv("UNIRES_SHIFT_LW") && getenv("UNIRES_SHIFT_LW")[0] == '0';
+  const size_t lds_m = ((size_t)S.xdz * kShiftMaxTaps + (size_t)shift_nl(dd) * kShiftLines * S.wave_floats + (size_t)4 * (dd.x + dd.z)) *
+                       sizeof(float);
+  return S.valid && !no_fast && !no_lw && S.lane_window && dd.z == 4 * kWave && shift_xr(dd) > 0 && lds_m <= 64 * 1024;
+}
+
 int shift_blocks(Dim3i dd) {
   long long nb = ((long long)dd.x * dd.y + kShiftLines - 1) / kShiftLines;
   if (const int xr = shift_xr(dd))  // every workgroup of the marching form has tasks (its XCD chunks are of tasks)
@@ -661,8 +676,10 @@ int shift_build(ShiftPlan &S, Dim3i dd, Dim3i gd, Dim3i xd, const Taps &T, const
   const float t[3] = {A.m[3], A.m[7], A.m[11]};
   for (int d = 0; d < 3; ++d)
     if (!(fabsf(t[d]) < 1e5f)) return 1;
-  static const bool take_int = getenv("UNIRES_SHIFT_INT") && getenv("UNIRES_SHIFT_INT")[0] == '1';
-  if (!take_int && t[0] == floorf(t[0]) && t[1] == floorf(t[1]) && t[2] == floorf(t[2])) return 1;  // aligned.hip's case
+  // (integer shifts are aligned.hip's case; since r4 the tables are built for them too: where the x-marching
+  // kernel's fast form applies it beats k_ata_aligned4x2, 31.5 vs 36 - 37 us at 256^3.  UNIRES_SHIFT_INT=0: not)
+  static const bool no_int = getenv("UNIRES_SHIFT_INT") && getenv("UNIRES_SHIFT_INT")[0] == '0';
+  if (no_int && t[0] == floorf(t[0]) && t[1] == floorf(t[1]) && t[2] == floorf(t[2])) return 1;
   for (int d = 0; d < 2; ++d)
     if (T.n[d] != 1 || T.s[d] != 1 || T.t[d][0] != 1.f) return 1;
   if (S2.dim >= 0 && S2.dim != 2) return 1;
@@ -840,19 +857,24 @@ int launch_ata_shift(const ShiftPlan &S, const float *p, float *q, Dim3i dd, con
 #endif
   static const size_t pad_lds = getenv("UNIRES_SHIFT_PADLDS") ? (size_t)atoi(getenv("UNIRES_SHIFT_PADLDS")) : 0;  // (measurement: fewer workgroups per CU)
   if (G.xr > 0 && lds_m <= 64 * 1024) {
-#define SHIFT_M_LAUNCH(NLV)                                                                       \
-  do {                                                                                            \
-    if (objb)                                                                                     \
-      hipLaunchKernelGGL((k_ata_shift_m<NLV, true, true>), grid, block, lds_m + pad_lds, st, G, done);      \
-    else if (partials)                                                                            \
-      hipLaunchKernelGGL((k_ata_shift_m<NLV, true, false>), grid, block, lds_m + pad_lds, st, G, done);     \
-    else                                                                                          \
-      hipLaunchKernelGGL((k_ata_shift_m<NLV, false, false>), grid, block, lds_m + pad_lds, st, G, done);    \
+#define SHIFT_M_LAUNCH(NLV, FASTV)                                                                             \
+  do {                                                                                                         \
+    if (objb)                                                                                                  \
+      hipLaunchKernelGGL((k_ata_shift_m<NLV, true, true, FASTV>), grid, block, lds_m + pad_lds, st, G, done);   \
+    else if (partials)                                                                                         \
+      hipLaunchKernelGGL((k_ata_shift_m<NLV, true, false, FASTV>), grid, block, lds_m + pad_lds, st, G, done);  \
+    else                                                                                                       \
+      hipLaunchKernelGGL((k_ata_shift_m<NLV, false, false, FASTV>), grid, block, lds_m + pad_lds, st, G, done); \
   } while (0)
-    if (nl == 2)
-      SHIFT_M_LAUNCH(2);
+    const bool fast = shift_fast(S, dd) && G.lw && G.dbg == 0 && G.defer == 0;
+    if (nl == 2 && fast)
+      SHIFT_M_LAUNCH(2, true);
+    else if (nl == 2)
+      SHIFT_M_LAUNCH(2, false);
+    else if (fast)
+      SHIFT_M_LAUNCH(1, true);
     else
-      SHIFT_M_LAUNCH(1);
+      SHIFT_M_LAUNCH(1, false);
 #undef SHIFT_M_LAUNCH
 #ifdef UNIRES_SHIFT_PROF
     {

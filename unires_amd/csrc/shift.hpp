@@ -23,6 +23,7 @@ int shift_build(ShiftPlan &S, Dim3i dd, Dim3i gd, Dim3i xd, const Taps &T, const
                 float tol);
 void shift_free(ShiftPlan &S);
 int shift_blocks(Dim3i dd);  // partial sums written per launch
+bool shift_fast(const ShiftPlan &S, Dim3i dd);  // the x-marching kernel's fast form applies (it then also beats aligned.hip's kernel)
 // q = tau AtA p + a0 p + c DtD p (+ partials of sum p*q, or of the objective sum (q - 2 objb) p without
 // storing q).  Non-zero return: no valid plan for this operator / unaligned volumes; nothing launched.
 int launch_ata_shift(const ShiftPlan &S, const float *p, float *q, Dim3i dd, const Affine &A, float tau, float a0,
