@@ -213,10 +213,11 @@ def test_abi_status_codes(dev, lib):
 
 
 @pytest.mark.parametrize('dim', [(5, 7, 9), (6, 5, 4), (3, 4, 13), (9, 8, 70), (33, 29, 31), (40, 37, 64),
-                                 (24, 50, 181)])
+                                 (24, 50, 181), (7, 16, 16), (12, 23, 19), (4, 17, 61), (21, 64, 4)])
 @pytest.mark.parametrize('shift', [0, 1, 3])
 def test_identity_regime_stencil_any_shape_and_alignment(dev, dim, shift):
-    """Regime A = I (unires/_project.py:76-77 + _DtD :300-317) through the flat 16-byte kernel:
+    """Regime A = I (unires/_project.py:76-77 + _DtD :300-317) through the flat 16-byte kernels (the x-marching one
+    where a plane holds at least 64 vectors and the volume four planes, the chunked one otherwise):
     line lengths that are not multiples of 4, volumes of one chunk and of several, and p / q that
     start 4 or 12 bytes off a 16-byte boundary (the kernel aligns its vectors to q).  Also the fused
     dot product and the never-stored objective form."""

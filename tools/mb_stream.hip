@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} }while(0)
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 constexpr int NX = 256, NY = 256, NZ = 256;
 constexpr size_t N = (size_t)NX * NY * NZ;
 
@@ -47,6 +48,54 @@ __global__ void __launch_bounds__(256) k_march(const float *__restrict__ p, floa
       for (int b = 0; b < NL + 2; ++b) cur[b] = nxt[b];
       pc += sx, qc += sx;
     }
+  }
+}
+
+// flat marching over a volume whose planes are NOT a multiple of 16 bytes (181 x 217 x 181: plane = 39277
+// floats): a lane owns four consecutive in-plane voxels and walks along x with stride `plane`; every 16-byte
+// access except in plane 0 is 4-byte aligned only.  YN: + the y neighbours at +-nz.  (What k_dtd_flat would do
+// if it marched; k_flat5 below is what it does now: five 16-byte loads at 0, +-nz, +-plane per vector.)
+template <bool YN>
+__global__ void __launch_bounds__(256) k_flat_march(const float *__restrict__ p, float *__restrict__ q, unsigned nx, unsigned plane,
+                                                    unsigned nz, int xr) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned nvp = plane / 4, ncw = (nvp + 63) / 64, nxr = (nx + xr - 1) / xr, ntasks = ncw * nxr;
+  const size_t n = (size_t)nx * plane;
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (unsigned)(n * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(q, 0, (unsigned)(n * 4), 0x00020000);
+  for (unsigned task = blockIdx.x * 4 + w; task < ntasks; task += gridDim.x * 4) {
+    const unsigned r = task / ncw, cw = task - r * ncw;
+    const unsigned v = cw * 64 + lane;
+    if (v >= nvp) continue;
+    const unsigned xa = r * xr, xb = min(xa + (unsigned)xr, nx);
+    unsigned off = 4u * (xa * plane + 4u * v);
+    f4 cur = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0));
+    f4 ym = cur, yp = cur;
+    for (unsigned vx = xa; vx < xb; ++vx) {
+      f4 nxt = cur;
+      if (vx + 1 < xb) nxt = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rp, off + 4u * plane, 0, 0));
+      if (YN) {
+        ym = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rp, off - 4u * nz, 0, 0));
+        yp = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rp, off + 4u * nz, 0, 0));
+      }
+      f4 o = cur;
+      if (YN) o = 2.f * cur - ym - yp;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), rq, off, 0, 2);
+      cur = nxt;
+      off += 4u * plane;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_flat5(const float *__restrict__ p, float *__restrict__ q, unsigned n, unsigned plane, unsigned nz) {
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, n * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(q, 0, n * 4u, 0x00020000);
+  const unsigned n4 = n / 4, stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const unsigned off = 16u * i;
+    auto ld = [&](unsigned o) { return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rp, o, 0, 0)); };
+    const f4 c = ld(off), a = ld(off - 4u * nz), b = ld(off + 4u * nz), d = ld(off - 4u * plane), g = ld(off + 4u * plane);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, 4.f * c - a - b - d - g), rq, off, 0, 2);
   }
 }
 
@@ -152,11 +201,37 @@ template <int NL, bool YN> void run_march(const char *nm, float **bufs, int nb, 
   printf("  %-44s runs of %3d planes, %5d wave tasks %s: %6.1f us  %.2f TB/s (134 MB)\n", nm, xr, tasks, nt ? "nt" : "  ", us, 2.0 * N * 4 / us / 1e6);
 }
 
+void run_flat(float **bufs, int nb) {
+  const unsigned nx = 181, ny = 217, nz = 181, plane = ny * nz, n = nx * plane;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int reps = 40;
+  auto time = [&](const char *nm, auto launch) {
+    for (int i = 0; i < 4; ++i) launch(bufs[(2 * i) % nb], bufs[(2 * i + 1) % nb]);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) launch(bufs[(2 * i) % nb], bufs[(2 * i + 1) % nb]);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / reps;
+    printf("  181 x 217 x 181: %-60s %6.1f us  %.2f TB/s (56.9 MB)\n", nm, us, 2.0 * n * 4 / us / 1e6);
+  };
+  time("flat float4 copy (aligned)", [&](float *a, float *b) { hipLaunchKernelGGL((k<4>), dim3(2048), dim3(256), 0, 0, a, b, 1); });
+  time("five 16-byte loads per vector (k_dtd_flat's pattern)", [&](float *a, float *b) { hipLaunchKernelGGL(k_flat5, dim3(2048), dim3(256), 0, 0, a, b, n, plane, nz); });
+  for (int xr : {6, 9, 12, 16}) {
+    const unsigned tasks = ((plane / 4 + 63) / 64) * ((nx + xr - 1) / xr);
+    char nm[128];
+    snprintf(nm, sizeof(nm), "marching, unaligned, runs of %d planes (%u tasks): copy", xr, tasks);
+    time(nm, [&](float *a, float *b) { hipLaunchKernelGGL((k_flat_march<false>), dim3((tasks + 3) / 4), dim3(256), 0, 0, a, b, nx, plane, nz, xr); });
+    snprintf(nm, sizeof(nm), "marching, unaligned, runs of %d planes (%u tasks): + y neighbours", xr, tasks);
+    time(nm, [&](float *a, float *b) { hipLaunchKernelGGL((k_flat_march<true>), dim3((tasks + 3) / 4), dim3(256), 0, 0, a, b, nx, plane, nz, xr); });
+  }
+}
+
 int main() {
   const int nb = 6;  // 6 x 67 MB = 403 MB > Infinity Cache
   float *bufs[nb];
   for (int i = 0; i < nb; ++i) { CK(hipMalloc(&bufs[i], N * 4)); CK(hipMemset(bufs[i], 0, N * 4)); }
-  for (int xr : {8, 16, 17, 32, 33, 64}) {
+  run_flat(bufs, nb);
+  for (int xr : {16, 17}) {
     run_march<1, false>("marching copy, 1 line per wave", bufs, nb, xr, 1);
     run_march<2, false>("marching copy, 2 lines per wave", bufs, nb, xr, 1);
     run_march<2, true>("marching, 2 lines + y neighbours (4 loads)", bufs, nb, xr, 1);

@@ -21,6 +21,8 @@
 // backward term on the first plane), like dtd_at() of the other kernels.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "stencil.hpp"
 
 namespace unires {
@@ -229,6 +231,130 @@ __global__ void __launch_bounds__(kBlock) k_dtd_flat(FlatArgs A, const int *__re
   }
 }
 
+// x-marching form (round 4).  The five 16-byte loads per vector of k_dtd_flat are cache hits but still pass the
+// L2 -> L1 path (tools/mb_stream.hip: 16.9 us for that pattern at 181 x 217 x 181 where a copy takes 8.9).  Here a
+// lane owns four consecutive voxels of a PLANE and walks along x: the x neighbours are the previous / next
+// plane's own vectors, kept in registers (four plane slots that change roles, the walk unrolled by four); a plane
+// costs three 16-byte loads (centre, y - 1, y + 1) and one edge dword, issued two planes ahead.  Planes are
+// not multiples of 16 bytes in general (217 x 181 floats), so every access but plane 0's is 4-byte aligned
+// only - measured: no penalty.  The 0 .. 3 voxels a plane has beyond its whole vectors go through dtd_at().
+struct FlatMArgs {
+  FlatArgs F;
+  unsigned nx, nvp, ncw, xr, nxr;  // planes; whole vectors per plane; 64-vector chunks per plane; planes per run; runs
+};
+
+template <bool DOT, bool OBJ>
+__global__ void __launch_bounds__(kBlock) k_dtd_flat_m(FlatMArgs M, const int *__restrict__ done) {
+  if (done && *done) return;
+  const FlatArgs &A = M.F;
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), w = tid >> 6;
+  const unsigned n = A.n, nz = A.nz, nynz = A.nynz;
+  const __amdgpu_buffer_rsrc_t rp = make_rsrc(A.p, (size_t)n * 4);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(OBJ ? A.objb : A.p, (size_t)n * 4);
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(A.q, (size_t)n * 4);
+  double dot = 0.0;
+  const unsigned ntasks = M.ncw * M.nxr;
+  struct Plane {
+    f4 cc, ym, yp, ob;
+    float edge;
+  };
+  const int lb = xcd_chunked_block(blockIdx.x, gridDim.x);
+  for (unsigned task = (unsigned)lb * (kBlock / kWave) + w; task < ntasks; task += gridDim.x * (kBlock / kWave)) {
+    const unsigned r = task / M.ncw, cw = task - r * M.ncw;
+    const unsigned v = cw * kWave + lane;
+    const bool valid = v < M.nvp;
+    const unsigned o = 4u * v;  // in-plane offset of the lane's first voxel
+    const unsigned j0 = div_small(o, nz, A.inv_nz), k0 = o - __umul24(j0, nz);
+    const unsigned xa = r * M.xr, xb = min(xa + M.xr, M.nx);
+    const unsigned eoff = lane == (unsigned)kWave - 1u ? 16u : 0xfffffffcu;  // the voxel above lane 63's last / below lane 0's first
+    // does any of the wave's voxels lie on a y face?  (a vector spans at most two lines: j0 and j0 + 1)
+    const bool yface = j0 == 0u || j0 + 2u >= A.ny;
+    const bool y_inside = __builtin_amdgcn_ballot_w64(yface) == 0ull;
+    const unsigned pstep = 4u * nynz;
+    auto load_plane = [&](unsigned bo, bool first, Plane &P) {  // (planes -1 and nx: offsets outside the array read zeros)
+      P.cc = ld4_fast(rp, bo), P.ym = ld4_fast(rp, bo - 4u * nz), P.yp = ld4_fast(rp, bo + 4u * nz);
+      // (plane 0: the y - 1 vector of the lane whose four voxels straddle the end of line 0 starts below the
+      // array; the hardware adds the components' offsets without 32-bit wrap-around, so its in-range half would
+      // read as zeros too)
+      if (first && o < nz) P.ym = ld4_safe(rp, (int)o - (int)nz, (int)n);
+      P.ob = OBJ ? ld4_fast(rb, bo) : f4{0.f, 0.f, 0.f, 0.f};
+      P.edge = buf_load(rp, bo + eoff, 0);
+    };
+    unsigned bo = 4u * (xa * nynz + o);  // byte offset of the lane's vector in the plane being computed
+    auto step = [&](const Plane &prev, const Plane &cur, const Plane &next, Plane &fly, unsigned vx) {
+      // in flight over two steps; beyond the run only the centre of its first plane is wanted (as x + 1)
+      if (vx + 2u < xb)
+        load_plane(bo + 2u * pstep, false, fly);
+      else if (vx + 2u == xb)
+        fly.cc = ld4_fast(rp, bo + 2u * pstep);
+      FlatVec L;
+      L.cc = cur.cc, L.xm = prev.cc, L.xp = next.cc, L.ym = cur.ym, L.yp = cur.yp, L.ob = cur.ob, L.edge = cur.edge;
+      // the common case - no voxel of the wave on an x or y face - carries the z tests only
+      if (y_inside && vx > 0u && vx + 1u < M.nx)
+        flat_vec<false, DOT, OBJ>(A, L, lane, bo >> 2, k0, j0, valid, rq, dot);
+      else
+        flat_vec<true, DOT, OBJ>(A, L, lane, bo >> 2, k0, j0, valid, rq, dot);
+      bo += pstep;
+    };
+    Plane P0, P1, P2, P3;
+    P0.cc = f4{0.f, 0.f, 0.f, 0.f};
+    if (xa > 0u) P0.cc = ld4_fast(rp, bo - pstep);
+    load_plane(bo, xa == 0u, P1);
+    if (xa + 1u < xb)
+      load_plane(bo + pstep, false, P2);
+    else
+      P2.cc = ld4_fast(rp, bo + pstep);
+    for (unsigned vx = xa; vx < xb; vx += 4u) {  // the slots change roles: no register moves
+      step(P0, P1, P2, P3, vx);
+      if (vx + 1u < xb) step(P1, P2, P3, P0, vx + 1u);
+      if (vx + 2u < xb) step(P2, P3, P0, P1, vx + 2u);
+      if (vx + 3u < xb) step(P3, P0, P1, P2, vx + 3u);
+      else break;
+    }
+  }
+  // the voxels a plane has beyond its whole vectors, and nothing else is left
+  if (blockIdx.x == 0) {
+    const unsigned tl = nynz - 4u * M.nvp, ntail = M.nx * tl;
+    const Dim3i dd{(int)M.nx, (int)A.ny, (int)nz};
+    for (unsigned i = tid; i < ntail; i += kBlock) {
+      const unsigned x = i / tl, idx = x * nynz + 4u * M.nvp + (i - x * tl);
+      const unsigned line = idx / nz, k = idx - line * nz, j = line - x * A.ny;
+      float pc;
+      const float st = dtd_at(A.p, idx, (int)x, (int)j, (int)k, dd, A.cx, A.cy, A.cz, pc);
+      matvec_emit(A.q, idx, A.a0 * pc + st, pc, OBJ ? A.objb : nullptr, DOT, dot);
+    }
+  }
+  if (DOT || OBJ) {
+    const double tot = block_sum(dot);
+    if (tid == 0) A.partials[blockIdx.x] = tot;
+  }
+}
+
+// marching form: geometry of the launch; false: the flat kernel serves the volume
+static bool flat_m_geometry(Dim3i dd, FlatMArgs &M) {
+  // Measured and left OFF (UNIRES_FLAT_MARCH=-1: on with automatic runs, n: planes per run): at 181 x 217 x 181
+  // the walk takes 13.5 - 14.9 us against k_dtd_flat's 13.0 - a 57 MB pass lasts ~10 us at copy rate, so a wave has
+  // time for a handful of dependent steps only, and with runs that short the run-in planes eat what the marching
+  // saves in loads (4 + 9 / xr per vector instead of 6); with long runs (1024 tasks: 20 us) it is latency-bound.
+  static const int mode = getenv("UNIRES_FLAT_MARCH") ? atoi(getenv("UNIRES_FLAT_MARCH")) : 0;
+  if (mode == 0) return false;
+  const unsigned long long nynz = (unsigned long long)dd.y * dd.z;
+  if (nynz < 4u * kWave || dd.x < 4 || nynz >= (1u << 24)) return false;
+  M.nx = (unsigned)dd.x, M.nvp = (unsigned)(nynz / 4u), M.ncw = (M.nvp + kWave - 1u) / kWave;
+  static const int tasks = getenv("UNIRES_FLAT_TASKS") ? atoi(getenv("UNIRES_FLAT_TASKS")) : 2048;
+  unsigned long long xr = mode > 0 ? (unsigned long long)mode : ((unsigned long long)M.nx * M.ncw + tasks - 1) / tasks;
+  xr = std::max<unsigned long long>(4, std::min<unsigned long long>(xr, M.nx));
+  // (runs a multiple of 1 MB apart keep the concurrently walked planes on the same DRAM banks)
+  if (mode <= 0 && xr < M.nx && (xr * nynz * 4u) % (1u << 20) == 0) ++xr;
+  M.xr = (unsigned)xr, M.nxr = (M.nx + M.xr - 1u) / M.xr;
+  return true;
+}
+
+static int flat_m_blocks(const FlatMArgs &M) {
+  const unsigned long long nb = ((unsigned long long)M.ncw * M.nxr + (kBlock / kWave) - 1) / (kBlock / kWave);
+  return (int)std::min<unsigned long long>(nb, 4096);
+}
+
 static int flat_grid(unsigned nchunk) {
   // every workgroup the same number of chunks (a grid capped at 4096 gave 356 of an XCD's 512
   // workgroups two chunks and the others one); UNIRES_FLAT_BLOCKS overrides the cap (<= kMaxPartials)
@@ -239,6 +365,8 @@ static int flat_grid(unsigned nchunk) {
 }
 
 int dtd_flat_blocks(Dim3i dd) {
+  FlatMArgs M;
+  if (flat_m_geometry(dd, M)) return flat_m_blocks(M);
   const size_t n = dd.numel();
   return flat_grid((unsigned)((n / 4 * 4 + kFlatChunk - 1) / kFlatChunk));
 }
@@ -257,6 +385,18 @@ int launch_dtd_flat(const float *p, float *q, Dim3i dd, float a0, float cx, floa
   A.nvec = (A.n - A.head) / 4u;
   A.nchunk = (A.nvec * 4u + kFlatChunk - 1u) / (unsigned)kFlatChunk;
   A.a0 = a0, A.cx = cx, A.cy = cy, A.cz = cz;
+  FlatMArgs M;
+  if (flat_m_geometry(dd, M)) {
+    M.F = A;
+    const dim3 grid(flat_m_blocks(M)), block(kBlock);
+    if (objb)
+      hipLaunchKernelGGL((k_dtd_flat_m<true, true>), grid, block, 0, st, M, done);
+    else if (partials)
+      hipLaunchKernelGGL((k_dtd_flat_m<true, false>), grid, block, 0, st, M, done);
+    else
+      hipLaunchKernelGGL((k_dtd_flat_m<false, false>), grid, block, 0, st, M, done);
+    return 0;
+  }
   const unsigned G = (unsigned)dtd_flat_blocks(dd);
   A.nx = G >= 8u ? 8u : 1u, A.per_xcd = G / A.nx, A.rem = G % A.nx;
   for (unsigned x = 0, before = 0; x <= A.nx; ++x) {
