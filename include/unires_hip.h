@@ -166,6 +166,11 @@ int64_t unires_plan_workspace_bytes(const unires_plan_t *plan);
  * splat does not serve it, else 2 + its conv_up axis (1: grid-space source, 2..4: along x / y / z, 5: all), info[6] = 1 if the translation-only one-kernel
  * matvec serves it, info[7] = 1 if the convolutions run as separable passes. */
 int unires_plan_repeat_info(const unires_plan_t *plan, int32_t n, int32_t info[8]);
+/* The relabelling a plan applies to an operator with grid -> output affine M (host arithmetic only, no device
+ * call): perm[j] = caller's voxel axis behind canonical axis j, flip[j] = 1 where it is reversed, chosen so that
+ * the permuted, sign-flipped linear part of M is as close to a positive diagonal as a signed permutation gets
+ * (identity for every axis-aligned, right-handed geometry: the descriptor is then used as it is). */
+int unires_orient_of(const float M[12], int32_t perm[3], int32_t flip[3]);
 /* Measurement aid (no counterpart in the reference; bench.py's roofline leg).  While on,
  * unires_cg_solve launches its kernels one by one (no hipGraph replay) and brackets every operator
  * application A(p) of the solve with HIP events on the caller's stream.  Meaningful with tol == 0

@@ -229,3 +229,41 @@ def test_spatial_facade_recovers_the_affine_of_a_dense_grid():
     from unires_amd._util import _bids_name
     assert _bids_name('/a/b/sub-01_T1w.nii') == '/a/b/sub-01_space-unires_T1w.nii'
     assert _bids_name('img.nii.gz') == 'space-unires_img.nii.gz'
+
+
+def test_orientation_relabelling_of_every_signed_permutation(lib):
+    """unires_orient_of (host arithmetic of the plan's canonicalisation, csrc/orient.hip): for an observation
+    stored with its voxel axes permuted / reversed (tests.helpers.orient_axes: what a sagittal / coronal / LAS
+    file hands the reference, unires/_util.py:134-197) composed with a small rigid, the relabelling returned
+    brings the linear part of M = mat_y \\ rigid mat_yx back to a positive dominant diagonal - and it is the
+    identity for axis-aligned, right-handed storage, so that those operators are used exactly as given."""
+    from tests.helpers import SIGNED_PERMS, orient_axes
+    from unires_amd import _lib
+    dim_y = (16, 14, 12)
+    mat_y = torch.eye(4, dtype=torch.float64)
+    rigid = rigid_matrix([0.7, -0.4, 0.3], [0.06, -0.05, 0.08])
+    for thick_axis in range(3):
+        sc = [1.0, 1.0, 1.0, 1.0]
+        sc[thick_axis] = 3.0
+        mat_x0 = mat_y @ torch.diag(torch.tensor(sc, dtype=torch.float64))
+        dim_x0 = tuple(int(d // s) for d, s in zip(dim_y, sc))
+        for perm, flip in SIGNED_PERMS:
+            dim_x, mat_x = orient_axes(dim_x0, mat_x0, perm, flip)
+            po = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid)
+            M, _ = O.proj_matrix(po, 'super-resolution')
+            m12 = _lib.c_f32x12(*[float(v) for v in M[:3, :].reshape(-1).tolist()])
+            p_out, f_out = _lib.c_i32x3(), _lib.c_i32x3()
+            assert lib.unires_orient_of(m12, p_out, f_out) == 0
+            p_out, f_out = list(p_out), list(f_out)
+            assert sorted(p_out) == [0, 1, 2]
+            lin = M[:3, :3]
+            canon = torch.stack([lin[:, p_out[j]] * (-1.0 if f_out[j] else 1.0) for j in range(3)], dim=1)
+            for j in range(3):
+                col = canon[:, j]
+                assert col[j] > 0 and abs(col[j]) == col.abs().max(), (perm, flip, p_out, f_out)
+            if perm == (0, 1, 2) and flip == (0, 0, 0):
+                assert p_out == [0, 1, 2] and f_out == [0, 0, 0]
+            else:  # stored axis a is acquisition axis perm[a]: canonical axis perm[a] is the caller's axis a
+                assert all(p_out[perm[a]] == a and f_out[perm[a]] == flip[a] for a in range(3))
+    bad = _lib.c_f32x12(*([float('nan')] * 12))
+    assert lib.unires_orient_of(bad, _lib.c_i32x3(), _lib.c_i32x3()) != 0

@@ -794,6 +794,17 @@ extern "C" int64_t unires_plan_workspace_bytes(const unires_plan_t *plan) {
   return plan ? (int64_t)plan->ws_bytes : 0;
 }
 
+extern "C" int unires_orient_of(const float M[12], int32_t perm[3], int32_t flip[3]) {
+  if (!M || !perm || !flip) return fail(UNIRES_ERR_NULL, "null argument");
+  Affine A;
+  memcpy(A.m, M, sizeof(A.m));
+  for (int i = 0; i < 12; ++i)
+    if (!isfinite(A.m[i])) return fail(UNIRES_ERR_ARG, "non-finite affine");
+  const Orient O = orient_of(A);
+  for (int j = 0; j < 3; ++j) perm[j] = O.perm[j], flip[j] = O.flip[j];
+  return UNIRES_OK;
+}
+
 extern "C" int unires_plan_repeat_info(const unires_plan_t *plan, int32_t n, int32_t info[8]) {
   if (!plan || !info) return fail(UNIRES_ERR_NULL, "null argument");
   if (n < 0 || n >= (int)plan->reps.size()) return fail(UNIRES_ERR_ARG, "repeat index");
