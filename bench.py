@@ -292,6 +292,8 @@ def oracle_channel(wl, dim_y, seed=0, channel=None):
         mat_y = torch.diag(torch.tensor([0.5, 0.5, 0.5, 1.0], dtype=torch.float64))
     mat_x = mat_y @ torch.diag(torch.tensor(scale + [1.0], dtype=torch.float64))
     dim_x = tuple(int(math.floor(d / s)) for d, s in zip(dim_y, scale))
+    if wl.get('orient') and channel is not None:  # the channel's stored voxel order (sagittal / coronal / reflected)
+        dim_x, mat_x = orient_axes(dim_x, mat_x, *wl['orient'][channel])
     u = torch.rand(6, generator=gen) * 2 - 1
     rigid = rigid_matrix((u[:3] * 5.0).tolist(), (u[3:] * 0.1).tolist())
     po = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=wl.get('prof_ip', 0), prof_tp=0)

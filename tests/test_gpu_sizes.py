@@ -78,6 +78,54 @@ def test_midsize_other_profiles_match_oracle(dev, wlname, dim_y, channel):
     _check(dev, wlname, dim_y, seed=4, rhs=False, channel=channel)
 
 
+@pytest.mark.parametrize('channel', [1, 2])
+def test_midsize_stored_orientations_match_oracle(dev, channel):
+    """The multi-orientation bench subject at mid size: thick slices along world x stored sagittally (voxel axes
+    y, z, x) and along world y stored coronally with the first axis reversed (LAS: det < 0) - matvec and RHS (whose
+    observation goes through the plan's re-ordering kernel) against the oracle's dense grid."""
+    _check(dev, 'cfg3_256c3_thick6_orient', (96, 90, 102), seed=5, rhs=True, channel=channel)
+
+
+def test_full_size_stored_orientations_properties(dev):
+    """256^3, sagittal- and coronal-LAS-stored thick-slice observations: the plan relabels the axes and serves both
+    with the LDS-window pull and the schedule-driven splat; adjointness through the caller's layout (the reference's
+    own harness, _project.py:27-51), symmetry and positivity of the assembled operator."""
+    import unires_amd as U
+    from unires_amd._project import _channel_plan
+    from tests.helpers import rigid_matrix
+    dim_y = (256, 256, 256)
+    eye = torch.eye(4, dtype=torch.float64)
+    g = torch.Generator().manual_seed(0)
+    for ch, thick_axis in ((1, 0), (2, 1)):
+        sc = [1.0, 1.0, 1.0, 1.0]
+        sc[thick_axis] = 6.0
+        dim_x0 = tuple(256 // int(v) for v in sc[:3])
+        dim_x, mat_x = bench.orient_axes(dim_x0, eye @ torch.diag(torch.tensor(sc, dtype=torch.float64)),
+                                         *bench.WORKLOADS['cfg3_256c3_thick6_orient']['orient'][ch])
+        po = U._proj_info(dim_y, eye, dim_x, mat_x, rigid=rigid_matrix([2.0, -3.0, 1.0], [0.05, -0.08, 0.03]), device=dev)
+        assert int(po.dim_thick) == 2 and tuple(po.ratio) == (1, 1, 6)  # the slice axis is the LAST stored axis in both
+        x = [U._input(torch.rand(dim_x, generator=g).to(dev), mat_x, 1.8e-4, po)]
+        y = U._output(torch.zeros(dim_y, device=dev), eye, 0.006)
+        plan = _channel_plan(x, y, 'super-resolution', True)
+        info = plan.repeat_info(0)
+        assert info['pull2'] and info['splat2_axis'] == thick_axis, info
+        # adjointness in the CALLER's layout: <A p, v> = <p, At v>
+        p = torch.rand(dim_y, generator=g).to(dev)
+        v = torch.rand(dim_x, generator=g).to(dev)
+        Ap, Atv = plan.proj_apply(0, 'A', p), plan.proj_apply(0, 'At', v)
+        assert tuple(Ap.shape) == tuple(dim_x)
+        s1 = torch.sum(Ap * v, dtype=torch.float64).item()
+        s2 = torch.sum(p * Atv, dtype=torch.float64).item()
+        assert abs(s1 - s2) < 1e-5 * abs(s1)
+        # AtA = At(A) through the two re-orderings, symmetry, positivity
+        AtAp = plan.proj_apply(0, 'AtA', p)
+        assert rel_err(plan.proj_apply(0, 'At', Ap).cpu(), AtAp.cpu()) < 2e-5
+        q = torch.rand(dim_y, generator=g).to(dev)
+        Mp, Mq = plan.matvec(p, 0.9, 0.006), plan.matvec(q, 0.9, 0.006)
+        t1, t2 = torch.sum(Mp * q, dtype=torch.float64).item(), torch.sum(p * Mq, dtype=torch.float64).item()
+        assert abs(t1 - t2) < 1e-5 * abs(t1) and torch.sum(Mp * p, dtype=torch.float64).item() > 0
+
+
 def test_full_size_config4_properties(dev):
     """BASELINE configs[3] at full size (384^3 from 192^3, ratio 2,2,2: profile along all three
     axes).  No oracle at this size (a dense 387^3 x 3 grid per application): the size-independent
