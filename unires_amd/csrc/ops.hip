@@ -7,6 +7,8 @@
 #include "common.hpp"
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "ops.hpp"
 
 namespace unires {
@@ -603,6 +605,60 @@ void launch_conv_down_sep(const float *g, Dim3i gd, const Taps &T, const Scaling
 }
 
 // g = conv_up(S xs): passes x, y, z; returns the buffer (a or b) that holds the grid volume.
+// conv_up along z for STRIDE 2 (isotropic 2 x down-sampling: BASELINE config 4, Gaussian profile = 11 taps,
+// fan-in 6) without the LDS stage (round 4).  out[2m] = sum_i ker[2i] s[m - i], out[2m + 1] = sum_i ker[2i + 1] s[m - i]:
+// a lane loads TWO source voxels (8 bytes), takes the five older ones from its lower neighbours by wave shifts and
+// writes FOUR outputs as one 16-byte store; three lanes of halo per pass of 64.  ~8 instructions per output where
+// the staged form has ~25 (a dozen LDS reads among them) - and these passes are bound by what a wave issues.
+__device__ __forceinline__ float dpp_shr1(float v) {  // lane l gets lane l - 1's value (lane 0: 0)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+
+struct UpZ2Taps {
+  float ke[6], ko[6];
+};
+
+__global__ void __launch_bounds__(kBlock)
+    k_conv1d_up_z2(const float *__restrict__ src, Dim3i sd, UpZ2Taps K, float se, float so, float *__restrict__ dst,
+                   Dim3i dd) {
+  const int lane = threadIdx.x, w = threadIdx.y;
+  const long long nrows = (long long)dd.x * dd.y;
+  const int nm = (dd.z + 1) / 2, npair = (nm + 1) / 2;
+  constexpr int H = 3, U = kWave - H;  // halo lanes, useful lanes per pass
+  for (long long row = (long long)blockIdx.x * (kBlock / kWave) + w; row < nrows; row += (long long)gridDim.x * (kBlock / kWave)) {
+    const float *srow = src + row * sd.z;
+    float *drow = dst + row * dd.z;
+    for (int jb = 0; jb < npair; jb += U) {
+      const int j = jb - H + lane, c = 2 * j;
+      float s0 = 0.f, s1 = 0.f;
+      if (c >= 0 && c + 1 < sd.z) {
+        const float2 v = ld2_u(srow + c);
+        s0 = v.x * se, s1 = v.y * so;
+      } else if (c >= 0 && c < sd.z) {
+        s0 = srow[c] * se;
+      }
+      const float b0 = dpp_shr1(s0), b1 = dpp_shr1(s1);  // s[2j - 2], s[2j - 1]
+      const float c0 = dpp_shr1(b0), c1 = dpp_shr1(b1);  // s[2j - 4], s[2j - 3]
+      const float d1 = dpp_shr1(c1);                      // s[2j - 5]
+      // m = 2j reads s[2j - i], m = 2j + 1 reads s[2j + 1 - i], i = 0 .. 5
+      const float o0 = K.ke[0] * s0 + K.ke[1] * b1 + K.ke[2] * b0 + K.ke[3] * c1 + K.ke[4] * c0 + K.ke[5] * d1;
+      const float o1 = K.ko[0] * s0 + K.ko[1] * b1 + K.ko[2] * b0 + K.ko[3] * c1 + K.ko[4] * c0 + K.ko[5] * d1;
+      const float o2 = K.ke[0] * s1 + K.ke[1] * s0 + K.ke[2] * b1 + K.ke[3] * b0 + K.ke[4] * c1 + K.ke[5] * c0;
+      const float o3 = K.ko[0] * s1 + K.ko[1] * s0 + K.ko[2] * b1 + K.ko[3] * b0 + K.ko[4] * c1 + K.ko[5] * c0;
+      const int u = 4 * j;
+      if (lane >= H && j < npair) {
+        if (u + 3 < dd.z) {
+          __builtin_memcpy(drow + u, &(const float4 &)make_float4(o0, o1, o2, o3), sizeof(float4));
+        } else {
+          if (u < dd.z) drow[u] = o0;
+          if (u + 1 < dd.z) drow[u + 1] = o1;
+          if (u + 2 < dd.z) drow[u + 2] = o2;
+        }
+      }
+    }
+  }
+}
+
 float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scaling &S, Dim3i gd,
                           float *a, float *b, hipStream_t st) {
   const float *cur = xs;
@@ -642,7 +698,14 @@ float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scalin
     Taps1 K;
     for (int t = 0; t < UNIRES_MAX_TAPS; ++t) K.t[t] = T.t[ax][t];
     const bool sc = S.dim == ax;
-    if (ax == 2)
+    static const bool no_z2 = getenv("UNIRES_UPZ2") && atoi(getenv("UNIRES_UPZ2")) == 0;
+    if (ax == 2 && !no_z2 && T.s[2] == 2 && T.n[2] <= 12 && cd.z >= 2) {
+      UpZ2Taps Z;
+      for (int i = 0; i < 6; ++i) Z.ke[i] = 2 * i < T.n[2] ? T.t[2][2 * i] : 0.f, Z.ko[i] = 2 * i + 1 < T.n[2] ? T.t[2][2 * i + 1] : 0.f;
+      const long long rows = (long long)od.x * od.y;
+      const unsigned blocks = (unsigned)std::min<long long>((rows + 3) / 4, 16384);
+      hipLaunchKernelGGL(k_conv1d_up_z2, dim3(blocks), vol_block(), 0, st, cur, cd, Z, sc ? S.e : 1.f, sc ? S.o : 1.f, out, od);
+    } else if (ax == 2)
       hipLaunchKernelGGL(k_conv1d_up_z, conv1d_grid(od), vol_block(), 0, st, cur, cd, K, T.n[2], T.s[2],
                          sc ? S.e : 1.f, sc ? S.o : 1.f, out, od);
     else if (conv1d_v4_ok(cur, out, cd, od))
