@@ -561,6 +561,117 @@ static inline bool axis_is_dirac(const Taps &T, int a) {
 
 // xs = S conv_down(g): passes z, y, x through two scratch volumes (a and b, each >= numel(gd));
 // the last pass writes dst.  `g` may be `a`.
+// x / y passes of a stride-2 separable conv with many taps (the Gaussian profile of BASELINE config 4: 11 taps,
+// fan-in 6), MARCHING along the pass axis (round 4).  k_conv1d_down_v4 / k_conv1d_up_v4 gather: eleven (five to
+// six) 16-byte loads per output, cache hits that still pass the L2 -> L1 path, with their address arithmetic.  Here
+// a thread keeps a sliding window of the pass axis in registers and walks a run of outputs: two new inputs per
+// output (down), one new input per TWO outputs (up).  sa / sm: strides (in float4) of the thread's fixed axis and
+// of the marching axis.
+struct March2 {
+  int na, z4;                // threads: na x z4
+  long long sa_s, sm_s;      // source strides
+  long long sa_d, sm_d;      // destination strides
+  int n_in, n_out, run;      // extents along the pass axis, outputs (down) / input steps (up) per run
+  float se, so;              // even / odd slice factors along the pass axis (1, 1: none)
+  float k[12];               // taps (down) - or ke[6], ko[6] (up)
+};
+
+template <int NT>
+__global__ void __launch_bounds__(kBlock) k_conv1d_down2_m(const float4 *__restrict__ src, float4 *__restrict__ dst, March2 M,
+                                                          const int *__restrict__ done) {
+  if (done && *done) return;
+  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.y * kWave + threadIdx.x;
+  const int a = (int)(tid / M.z4), kz = (int)(tid - (long long)a * M.z4);
+  if (a >= M.na) return;
+  const int oa = blockIdx.y * M.run, ob = min(oa + M.run, M.n_out);
+  if (oa >= ob) return;
+  const float4 *p = src + (long long)a * M.sa_s + kz + (long long)(2 * oa) * M.sm_s;
+  float4 *q = dst + (long long)a * M.sa_d + kz + (long long)oa * M.sm_d;
+  float4 w[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) w[t] = p[(long long)t * M.sm_s];  // (2 (n_out - 1) + NT - 1 = n_in - 1: inside)
+  p += (long long)NT * M.sm_s;
+  for (int o = oa; o < ob; ++o) {
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
+    if (o + 1 < ob) n0 = p[0], n1 = p[M.sm_s];  // the next output's two new inputs, in flight over this one
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc = fma4(M.k[t], w[t], acc);
+    const float sc = (o & 1) ? M.so : M.se;
+    *q = make_float4(acc.x * sc, acc.y * sc, acc.z * sc, acc.w * sc);
+#pragma unroll
+    for (int t = 0; t + 2 < NT; ++t) w[t] = w[t + 2];
+    w[NT - 2] = n0, w[NT - 1] = n1;
+    p += 2 * M.sm_s, q += M.sm_d;
+  }
+}
+
+// up: out[2m] = sum_i ke[i] S(m - i) in[m - i], out[2m + 1] = sum_i ko[i] S(m - i) in[m - i]; window w[i] = in[m - i].
+// Same products (tap x slice factor, then x input) accumulated in the same order (ascending source index) as
+// k_conv1d_up_v4's gather: bit-identical results.
+template <int F>
+__global__ void __launch_bounds__(kBlock) k_conv1d_up2_m(const float4 *__restrict__ src, float4 *__restrict__ dst, March2 M) {
+  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.y * kWave + threadIdx.x;
+  const int a = (int)(tid / M.z4), kz = (int)(tid - (long long)a * M.z4);
+  if (a >= M.na) return;
+  const int nm = (M.n_out + 1) / 2;
+  const int ma = blockIdx.y * M.run, mb = min(ma + M.run, nm);  // (runs are even: ma is)
+  if (ma >= mb) return;
+  const float4 *p = src + (long long)a * M.sa_s + kz;
+  float4 *q = dst + (long long)a * M.sa_d + kz + (long long)(2 * ma) * M.sm_d;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto in_at = [&](int c) { return c < 0 || c >= M.n_in ? zero : p[(long long)c * M.sm_s]; };
+  // taps x slice factor of source m - i, for even and for odd m
+  float te[2][F], to[2][F];
+#pragma unroll
+  for (int i = 0; i < F; ++i)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const float sc = ((par ^ i) & 1) ? M.so : M.se;
+      te[par][i] = M.k[i] * sc, to[par][i] = M.k[6 + i] * sc;
+    }
+  float4 w[F];
+#pragma unroll
+  for (int i = 0; i < F; ++i) w[i] = in_at(ma - i);
+  auto step = [&](int m, const float (&ke)[F], const float (&ko)[F]) {
+    const float4 nx = m + 1 < mb ? in_at(m + 1) : zero;  // in flight over this step
+    float4 e = zero, o = zero;
+#pragma unroll
+    for (int i = F - 1; i >= 0; --i) e = fma4(ke[i], w[i], e), o = fma4(ko[i], w[i], o);
+    q[0] = e;
+    if (2 * m + 1 < M.n_out) q[M.sm_d] = o;
+#pragma unroll
+    for (int i = F - 1; i > 0; --i) w[i] = w[i - 1];
+    w[0] = nx;
+    q += 2 * M.sm_d;
+  };
+  for (int m = ma; m < mb; m += 2) {
+    step(m, te[0], to[0]);
+    if (m + 1 < mb) step(m + 1, te[1], to[1]);
+  }
+}
+
+static bool march2_ok(const Taps &T, int ax) {
+  static const bool off = getenv("UNIRES_CONV_MARCH") && atoi(getenv("UNIRES_CONV_MARCH")) == 0;
+  return !off && ax != 2 && T.s[ax] == 2 && (T.n[ax] == 11 || T.n[ax] == 5 || T.n[ax] == 3);  // (Gaussian, triangle, trimmed rect at ratio 2)
+}
+
+// geometry shared by the two marching passes along `ax` (0 or 1) between volumes sd -> dd (float4 along z)
+static March2 march2_args(Dim3i sd, Dim3i dd, int ax, int n_in, int n_out, int steps, float se, float so) {
+  March2 M;
+  M.z4 = dd.z / 4;
+  M.na = ax == 0 ? dd.y : dd.x;  // (the fixed axis has the same extent in sd and dd)
+  M.sa_s = ax == 0 ? (long long)M.z4 : (long long)sd.y * M.z4, M.sm_s = ax == 0 ? (long long)sd.y * M.z4 : (long long)M.z4;
+  M.sa_d = ax == 0 ? (long long)M.z4 : (long long)dd.y * M.z4, M.sm_d = ax == 0 ? (long long)dd.y * M.z4 : (long long)M.z4;
+  M.n_in = n_in, M.n_out = n_out, M.se = se, M.so = so;
+  // runs: enough threads for the chip (~4096 waves), at least 8 steps each
+  const long long lanes = (long long)M.na * M.z4;
+  long long runs = std::max<long long>(1, (4096ll * kWave + lanes - 1) / lanes);
+  M.run = (int)std::max<long long>(8, (steps + runs - 1) / runs);
+  M.run += M.run & 1;  // (even: the up pass alternates two tap sets with the parity of its step)
+  return M;
+}
+
 void launch_conv_down_sep(const float *g, Dim3i gd, const Taps &T, const Scaling &S, float *dst,
                           Dim3i xd, float *a, float *b, const int *done, hipStream_t st) {
   const float *cur = g;
@@ -590,7 +701,18 @@ void launch_conv_down_sep(const float *g, Dim3i gd, const Taps &T, const Scaling
     Taps1 K;
     for (int t = 0; t < UNIRES_MAX_TAPS; ++t) K.t[t] = T.t[ax][t];
     const bool sc = S.dim == ax;
-    if (ax == 2 && T.s[2] <= 8)
+    if (march2_ok(T, ax) && conv1d_v4_ok(cur, out, cd, od)) {
+      const int n_in = axis_len(cd, ax), n_out = axis_len(od, ax);
+      March2 M = march2_args(cd, od, ax, n_in, n_out, n_out, sc ? S.e : 1.f, sc ? S.o : 1.f);
+      for (int t = 0; t < 12; ++t) M.k[t] = t < T.n[ax] ? T.t[ax][t] : 0.f;
+      const dim3 grid((unsigned)(((long long)M.na * M.z4 + kBlock - 1) / kBlock), (unsigned)((n_out + M.run - 1) / M.run));
+      if (T.n[ax] == 11)
+        hipLaunchKernelGGL((k_conv1d_down2_m<11>), grid, vol_block(), 0, st, (const float4 *)cur, (float4 *)out, M, done);
+      else if (T.n[ax] == 5)
+        hipLaunchKernelGGL((k_conv1d_down2_m<5>), grid, vol_block(), 0, st, (const float4 *)cur, (float4 *)out, M, done);
+      else
+        hipLaunchKernelGGL((k_conv1d_down2_m<3>), grid, vol_block(), 0, st, (const float4 *)cur, (float4 *)out, M, done);
+    } else if (ax == 2 && T.s[2] <= 8)
       hipLaunchKernelGGL(k_conv1d_down_z, conv1d_grid(od), vol_block(), 0, st, cur, cd, K, T.n[2], T.s[2],
                          sc ? S.e : 1.f, sc ? S.o : 1.f, out, od, done);
     else if (ax != 2 && conv1d_v4_ok(cur, out, cd, od))
@@ -618,20 +740,55 @@ struct UpZ2Taps {
   float ke[6], ko[6];
 };
 
+// FY: the stride-2 conv_up along y fused in front (the source row of output row (x, u_y) is formed on the fly from
+// the <= 6 x-space rows that feed it: six 8-byte loads per lane, cache hits, instead of a pass that writes and
+// re-reads the (X, gy, sz) intermediate - 119 MB each way at BASELINE config 4).
+struct UpY2 {
+  float ke[6], ko[6];  // y taps at even / odd offsets
+  float se, so;        // even / odd slice factors along y
+  int ny_src;          // source rows
+};
+
+template <bool FY>
 __global__ void __launch_bounds__(kBlock)
     k_conv1d_up_z2(const float *__restrict__ src, Dim3i sd, UpZ2Taps K, float se, float so, float *__restrict__ dst,
-                   Dim3i dd) {
+                   Dim3i dd, UpY2 Y) {
   const int lane = threadIdx.x, w = threadIdx.y;
   const long long nrows = (long long)dd.x * dd.y;
   const int nm = (dd.z + 1) / 2, npair = (nm + 1) / 2;
   constexpr int H = 3, U = kWave - H;  // halo lanes, useful lanes per pass
   for (long long row = (long long)blockIdx.x * (kBlock / kWave) + w; row < nrows; row += (long long)gridDim.x * (kBlock / kWave)) {
     const float *srow = src + row * sd.z;
+    // FY: output row (x, uy) = sum_i ty[i] S(my - i) source row (x, my - i), my = uy / 2, taps by the parity of uy
+    float ty[6];
+    const float *yrow[6];
+    if (FY) {
+      const int x = (int)(row / dd.y), uy = (int)(row - (long long)x * dd.y), my = uy >> 1;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int c = my - i;
+        const bool ok = c >= 0 && c < Y.ny_src;
+        ty[i] = ok ? ((uy & 1) ? Y.ko[i] : Y.ke[i]) * ((c & 1) ? Y.so : Y.se) : 0.f;
+        yrow[i] = src + ((long long)x * Y.ny_src + (ok ? c : 0)) * sd.z;
+      }
+    }
     float *drow = dst + row * dd.z;
     for (int jb = 0; jb < npair; jb += U) {
       const int j = jb - H + lane, c = 2 * j;
       float s0 = 0.f, s1 = 0.f;
-      if (c >= 0 && c + 1 < sd.z) {
+      if (FY) {
+        if (c >= 0 && c + 1 < sd.z) {
+          float2 v[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) v[i] = ld2_u(yrow[i] + c);
+#pragma unroll
+          for (int i = 5; i >= 0; --i) s0 = fmaf(ty[i], v[i].x, s0), s1 = fmaf(ty[i], v[i].y, s1);  // (ascending source row)
+        } else if (c >= 0 && c < sd.z) {
+#pragma unroll
+          for (int i = 5; i >= 0; --i) s0 = fmaf(ty[i], yrow[i][c], s0);
+        }
+        s0 *= se, s1 *= so;
+      } else if (c >= 0 && c + 1 < sd.z) {
         const float2 v = ld2_u(srow + c);
         s0 = v.x * se, s1 = v.y * so;
       } else if (c >= 0 && c < sd.z) {
@@ -699,12 +856,48 @@ float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scalin
     for (int t = 0; t < UNIRES_MAX_TAPS; ++t) K.t[t] = T.t[ax][t];
     const bool sc = S.dim == ax;
     static const bool no_z2 = getenv("UNIRES_UPZ2") && atoi(getenv("UNIRES_UPZ2")) == 0;
-    if (ax == 2 && !no_z2 && T.s[2] == 2 && T.n[2] <= 12 && cd.z >= 2) {
+    // (measured and left off, UNIRES_UPYZ=1: the y pass fused into the z kernel - 104 us for the pair's 31 + 67:
+    // six 8-byte row loads per lane and pass cost more than the 119 MB intermediate they spare)
+    static const bool no_yz = !(getenv("UNIRES_UPYZ") && atoi(getenv("UNIRES_UPYZ")) == 1);
+    const bool z2 = !no_z2 && T.s[2] == 2 && T.n[2] <= 12 && cd.z >= 2 && active(2);
+    if (ax == 1 && z2 && !no_yz && T.s[1] == 2 && T.n[1] <= 12) {
+      // y and z passes in one kernel: no (X, gy, sz) intermediate
+      const Dim3i oz = Dim3i{cd.x, gd.y, gd.z};
+      UpZ2Taps Z;
+      UpY2 Y;
+      for (int i = 0; i < 6; ++i) {
+        Z.ke[i] = 2 * i < T.n[2] ? T.t[2][2 * i] : 0.f, Z.ko[i] = 2 * i + 1 < T.n[2] ? T.t[2][2 * i + 1] : 0.f;
+        Y.ke[i] = 2 * i < T.n[1] ? T.t[1][2 * i] : 0.f, Y.ko[i] = 2 * i + 1 < T.n[1] ? T.t[1][2 * i + 1] : 0.f;
+      }
+      Y.se = S.dim == 1 ? S.e : 1.f, Y.so = S.dim == 1 ? S.o : 1.f, Y.ny_src = cd.y;
+      const long long rows = (long long)oz.x * oz.y;
+      const unsigned blocks = (unsigned)std::min<long long>((rows + 3) / 4, 16384);
+      hipLaunchKernelGGL((k_conv1d_up_z2<true>), dim3(blocks), vol_block(), 0, st, cur, cd, Z, S.dim == 2 ? S.e : 1.f,
+                         S.dim == 2 ? S.o : 1.f, out, oz, Y);
+      cur = out, cd = oz;
+      ax = 2;  // (z is done too)
+      continue;
+    }
+    if (ax == 2 && z2) {
       UpZ2Taps Z;
       for (int i = 0; i < 6; ++i) Z.ke[i] = 2 * i < T.n[2] ? T.t[2][2 * i] : 0.f, Z.ko[i] = 2 * i + 1 < T.n[2] ? T.t[2][2 * i + 1] : 0.f;
       const long long rows = (long long)od.x * od.y;
       const unsigned blocks = (unsigned)std::min<long long>((rows + 3) / 4, 16384);
-      hipLaunchKernelGGL(k_conv1d_up_z2, dim3(blocks), vol_block(), 0, st, cur, cd, Z, sc ? S.e : 1.f, sc ? S.o : 1.f, out, od);
+      hipLaunchKernelGGL((k_conv1d_up_z2<false>), dim3(blocks), vol_block(), 0, st, cur, cd, Z, sc ? S.e : 1.f, sc ? S.o : 1.f, out,
+                         od, UpY2());
+    } else if (march2_ok(T, ax) && conv1d_v4_ok(cur, out, cd, od)) {
+      const int n_in = axis_len(cd, ax), n_out = axis_len(od, ax);
+      March2 M = march2_args(cd, od, ax, n_in, n_out, (n_out + 1) / 2, sc ? S.e : 1.f, sc ? S.o : 1.f);
+      for (int i = 0; i < 6; ++i)
+        M.k[i] = 2 * i < T.n[ax] ? T.t[ax][2 * i] : 0.f, M.k[6 + i] = 2 * i + 1 < T.n[ax] ? T.t[ax][2 * i + 1] : 0.f;
+      const int nm = (n_out + 1) / 2;
+      const dim3 grid((unsigned)(((long long)M.na * M.z4 + kBlock - 1) / kBlock), (unsigned)((nm + M.run - 1) / M.run));
+      if (T.n[ax] == 11)
+        hipLaunchKernelGGL((k_conv1d_up2_m<6>), grid, vol_block(), 0, st, (const float4 *)cur, (float4 *)out, M);
+      else if (T.n[ax] == 5)
+        hipLaunchKernelGGL((k_conv1d_up2_m<3>), grid, vol_block(), 0, st, (const float4 *)cur, (float4 *)out, M);
+      else
+        hipLaunchKernelGGL((k_conv1d_up2_m<2>), grid, vol_block(), 0, st, (const float4 *)cur, (float4 *)out, M);
     } else if (ax == 2)
       hipLaunchKernelGGL(k_conv1d_up_z, conv1d_grid(od), vol_block(), 0, st, cur, cd, K, T.n[2], T.s[2],
                          sc ? S.e : 1.f, sc ? S.o : 1.f, out, od);
