@@ -861,6 +861,33 @@ static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, co
   }
   // S(2 scl) once between conv and conv^T  (unires/_project.py:175-177)
   const Scaling S2 = make_scaling(2.f * R.scl, R.dim_thick);
+  if (R.hybf && !R.hyb && R.sep && pl->gbuf2 && R.pplan.valid && !(R.sched.valid && R.sched.axis >= 0) &&
+      R.Tf.s[0] == 2 && !(R.Tf.n[0] == 1)) {
+    // forward-only hybrid (many-tap profiles, e.g. the default Gaussian at ratio 2): the x pair conv_down_x /
+    // conv_up_x of A^T A runs as ONE pass whose half-length intermediate stays in registers; the push source
+    // is then the volume that is x-complete already (x taps = Dirac for what follows)
+    Taps Ty = R.Txy;
+    Ty.n[0] = Ty.s[0] = 1, Ty.t[0][0] = 1.f;
+    const Dim3i dxy = Dim3i{R.dim_h.x, R.dim_x.y, R.dim_x.z};
+    const Scaling Sx = S2.dim == 0 ? S2 : Scaling{1.f, 1.f, -1}, Srest = S2.dim == 0 ? Scaling{1.f, 1.f, -1} : S2;
+    const bool y_active = !(Ty.n[1] == 1 && Ty.s[1] == 1 && Ty.t[1][0] == 1.f) || Srest.dim == 1;
+    // (probe: the fused pass takes the same taps / alignment whatever its source pointer)
+    if (y_active && !launch_pull_conv2(R.pplan, in, pl->dy, R.Af, R.Tz, scaling_z(Srest), pl->gbuf, R.dim_h, R.dim_gf,
+                                       pl->fov_tol, done, st)) {
+      launch_conv_down_sep(pl->gbuf, R.dim_h, Ty, scaling_xy(Srest), pl->gbuf2, dxy, pl->gbuf, pl->gbuf2, done, st);
+      if (!launch_conv_downup2(pl->gbuf2, dxy, R.Tf, Sx, 0, R.dim_x.x, pl->gbuf, done, st)) {
+        PushSrc src = push_src(R, pl->gbuf, true, 0.f);
+        src.xd = dxy;
+        src.T.n[0] = src.T.s[0] = 1, src.T.t[0][0] = 1.f;
+        return src;
+      }
+      // not available for these taps: finish the x pass the usual way
+      Taps Tx = R.Txy;
+      Tx.n[1] = Tx.s[1] = 1, Tx.t[1][0] = 1.f;
+      launch_conv_down_sep(pl->gbuf2, dxy, Tx, Sx, pl->xbuf, R.dim_x, pl->gbuf, pl->gbuf, done, st);
+      return push_src(R, pl->xbuf, true, 0.f);
+    }
+  }
   if (hybrid_forward(pl, R, in, S2, pl->xbuf, done, st)) return push_src(R, pl->xbuf, true, 0.f);
   if (R.sep && pl->gbuf2) {
     launch_pull(in, pl->dy, R.Af, pl->gbuf, R.dim_gf, pl->fov_tol, done, st);

@@ -651,6 +651,65 @@ __global__ void __launch_bounds__(kBlock) k_conv1d_up2_m(const float4 *__restric
   }
 }
 
+// down then up along the same axis in ONE marching pass (A^T A of a stride-2 axis: the x pair of BASELINE
+// config 4 with the default Gaussian in-plane profile): mid[j] = S(j) sum_t k[t] in[2 j + t] lives in
+// registers only - out[2m + par] = sum_i k_up[2 i + par] mid[m - i] - so the (n / 2)-long intermediate is
+// neither written nor read back (2 x 28 MB of 172 MB at config 4).  The products and their order are those of
+// k_conv1d_down2_m followed by k_conv1d_up2_m with unit slice factors: bit-identical results.
+template <int NT, int F>
+__global__ void __launch_bounds__(kBlock) k_conv1d_downup2_m(const float4 *__restrict__ src, float4 *__restrict__ dst,
+                                                            March2 M, int n_mid, const int *__restrict__ done) {
+  if (done && *done) return;
+  const long long tid = (long long)blockIdx.x * kBlock + threadIdx.y * kWave + threadIdx.x;
+  const int a = (int)(tid / M.z4), kz = (int)(tid - (long long)a * M.z4);
+  if (a >= M.na) return;
+  const int nm = (M.n_out + 1) / 2;
+  const int ma = blockIdx.y * M.run, mb = min(ma + M.run, nm);
+  if (ma >= mb) return;
+  const float4 *p = src + (long long)a * M.sa_s + kz;
+  float4 *q = dst + (long long)a * M.sa_d + kz + (long long)(2 * ma) * M.sm_d;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float ke[F], ko[F];
+#pragma unroll
+  for (int i = 0; i < F; ++i) ke[i] = 2 * i < NT ? M.k[2 * i] : 0.f, ko[i] = 2 * i + 1 < NT ? M.k[2 * i + 1] : 0.f;
+  auto mid_of = [&](const float4 (&w)[NT], int j) {
+    float4 acc = zero;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc = fma4(M.k[t], w[t], acc);
+    const float sc = (j & 1) ? M.so : M.se;
+    return make_float4(acc.x * sc, acc.y * sc, acc.z * sc, acc.w * sc);
+  };
+  // md[i] = mid[m - i] after step m; w[t] = in[2 m + t] at its start.  F - 1 warm-up steps (no stores) fill md.
+  float4 md[F], w[NT];
+#pragma unroll
+  for (int i = 0; i < F; ++i) md[i] = zero;
+  const int m0 = max(ma - (F - 1), 0);
+  const bool any = m0 < n_mid;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) w[t] = any ? p[(long long)(2 * m0 + t) * M.sm_s] : zero;
+  p += (long long)(2 * (m0 + 1) + NT - 2) * M.sm_s;  // the first of the two inputs that mid[m0 + 1] adds
+  for (int m = m0; m < mb; ++m) {
+    float4 n0 = zero, n1 = zero;
+    if (m + 1 < n_mid && m + 1 < mb) n0 = p[0], n1 = p[M.sm_s];  // in flight over this step
+    const float4 nx = m < n_mid ? mid_of(w, m) : zero;
+#pragma unroll
+    for (int i = F - 1; i > 0; --i) md[i] = md[i - 1];
+    md[0] = nx;
+    if (m >= ma) {
+      float4 e = zero, o = zero;
+#pragma unroll
+      for (int i = F - 1; i >= 0; --i) e = fma4(ke[i], md[i], e), o = fma4(ko[i], md[i], o);
+      q[0] = e;
+      if (2 * m + 1 < M.n_out) q[M.sm_d] = o;
+      q += 2 * M.sm_d;
+    }
+#pragma unroll
+    for (int t = 0; t + 2 < NT; ++t) w[t] = w[t + 2];
+    w[NT - 2] = n0, w[NT - 1] = n1;
+    p += 2 * M.sm_s;
+  }
+}
+
 static bool march2_ok(const Taps &T, int ax) {
   static const bool off = getenv("UNIRES_CONV_MARCH") && atoi(getenv("UNIRES_CONV_MARCH")) == 0;
   return !off && ax != 2 && T.s[ax] == 2 && (T.n[ax] == 11 || T.n[ax] == 5 || T.n[ax] == 3);  // (Gaussian, triangle, trimmed rect at ratio 2)
@@ -670,6 +729,28 @@ static March2 march2_args(Dim3i sd, Dim3i dd, int ax, int n_in, int n_out, int s
   M.run = (int)std::max<long long>(8, (steps + runs - 1) / runs);
   M.run += M.run & 1;  // (even: the up pass alternates two tap sets with the parity of its step)
   return M;
+}
+
+// dst (gd_ax long along ax) = conv_up_ax(S conv_down_ax(src)) with the stride-2 taps of axis ax; the volumes
+// differ from the x-space one only along ax.  Non-zero: not available (taps, alignment) - nothing launched.
+int launch_conv_downup2(const float *src, Dim3i sd, const Taps &T, const Scaling &S, int ax, int n_mid, float *dst,
+                        const int *done, hipStream_t st) {
+  static const bool off = getenv("UNIRES_CONV_DOWNUP") && atoi(getenv("UNIRES_CONV_DOWNUP")) == 0;
+  if (off || !march2_ok(T, ax) || !conv1d_v4_ok(src, dst, sd, sd)) return 1;
+  const int n = axis_len(sd, ax);
+  if (2 * (n_mid - 1) + T.n[ax] - 1 > n - 1) return 1;
+  const bool sc = S.dim == ax;
+  March2 M = march2_args(sd, sd, ax, n, n, (n + 1) / 2, sc ? S.e : 1.f, sc ? S.o : 1.f);
+  for (int t = 0; t < 12; ++t) M.k[t] = t < T.n[ax] ? T.t[ax][t] : 0.f;
+  const int nm = (n + 1) / 2;
+  const dim3 grid((unsigned)(((long long)M.na * M.z4 + kBlock - 1) / kBlock), (unsigned)((nm + M.run - 1) / M.run));
+  if (T.n[ax] == 11)
+    hipLaunchKernelGGL((k_conv1d_downup2_m<11, 6>), grid, vol_block(), 0, st, (const float4 *)src, (float4 *)dst, M, n_mid, done);
+  else if (T.n[ax] == 5)
+    hipLaunchKernelGGL((k_conv1d_downup2_m<5, 3>), grid, vol_block(), 0, st, (const float4 *)src, (float4 *)dst, M, n_mid, done);
+  else
+    hipLaunchKernelGGL((k_conv1d_downup2_m<3, 2>), grid, vol_block(), 0, st, (const float4 *)src, (float4 *)dst, M, n_mid, done);
+  return 0;
 }
 
 void launch_conv_down_sep(const float *g, Dim3i gd, const Taps &T, const Scaling &S, float *dst,

@@ -22,6 +22,10 @@ void launch_conv_down_sep(const float *g, Dim3i gd, const Taps &T, const Scaling
                           Dim3i xd, float *a, float *b, const int *done, hipStream_t st);
 float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scaling &S, Dim3i gd,
                           float *a, float *b, hipStream_t st);
+// dst = conv_up_ax(S conv_down_ax(src)) for a stride-2 axis ax (0 or 1) in one marching pass: src and dst are sd
+// volumes, the n_mid-long intermediate stays in registers.  Non-zero: not available, nothing launched.
+int launch_conv_downup2(const float *src, Dim3i sd, const Taps &T, const Scaling &S, int ax, int n_mid, float *dst,
+                        const int *done, hipStream_t st);
 int dtd_num_blocks(Dim3i d);
 // dst = a*src + c*DtD(src); partials (nullable, dtd_num_blocks doubles) gets sum(src*dst) pieces;
 // with objb (needs partials): partials = sum (dst - 2 objb) * src and dst is not stored.

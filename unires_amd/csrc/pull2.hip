@@ -684,12 +684,16 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
   }
 #endif
   const bool k76 = T.n[2] == 7 && T.s[2] == 6;
+  static const bool no_k112 = getenv("UNIRES_P2_K112") && atoi(getenv("UNIRES_P2_K112")) == 0;
+  const bool k112 = !no_k112 && T.n[2] == 11 && T.s[2] == 2;  // the default Gaussian profile at ratio 2 (BASELINE config 4)
 #define P2_LAUNCH(HH)                                                                        \
   do {                                                                                       \
     if (gen)                                                                                 \
       hipLaunchKernelGGL((k_pull_conv2<HH, 0, 0, true>), grid, block, lds, st, P, done);     \
     else if (k76)                                                                            \
       hipLaunchKernelGGL((k_pull_conv2<HH, 7, 6, false>), grid, block, lds, st, P, done);    \
+    else if (k112)                                                                           \
+      hipLaunchKernelGGL((k_pull_conv2<HH, 11, 2, false>), grid, block, lds, st, P, done);   \
     else                                                                                     \
       hipLaunchKernelGGL((k_pull_conv2<HH, 0, 0, false>), grid, block, lds, st, P, done);    \
   } while (0)
