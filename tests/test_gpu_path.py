@@ -61,6 +61,13 @@ CASES = {
                               ((2, 1, 0), (0, 0, 1))]),
     'dn_orient': dict(dim_y=(15, 13, 11), n_channels=2, regime='dn', rot=0.1, trans=1.5,
                       orient=[((1, 0, 2), (0, 0, 0)), ((2, 0, 1), (1, 1, 1))]),
+    # many-tap profiles at ratio 2 with x-space z a multiple of 4: the separable marching passes and the one-pass
+    # conv_down_x / conv_up_x of A^T A (k_conv1d_downup2_m<3, 2>, <5, 3>, <11, 6>, <5, 3>; tools/which_kernels.py)
+    'sr_iso2_gauss_v4': dict(dim_y=(20, 24, 32), n_channels=1, thick=2, regime='sr', iso=True, prof_ip=2, scl=0.05),
+    'sr_iso2_tri_gauss_v4': dict(dim_y=(20, 24, 32), n_channels=1, thick=2, regime='sr', iso=True, prof_ip=2, prof_tp=1),
+    'sr_iso2_allgauss_v4': dict(dim_y=(24, 20, 32), n_channels=2, thick=2, regime='sr', iso=True, prof_ip=2, prof_tp=2,
+                                scl=0.05),
+    'sr_iso2_tri_v4': dict(dim_y=(24, 20, 32), n_channels=1, thick=2, regime='sr', iso=True, prof_ip=1, prof_tp=1),
 }
 
 
