@@ -874,6 +874,14 @@ static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, co
     // (probe: the fused pass takes the same taps / alignment whatever its source pointer)
     if (y_active && !launch_pull_conv2(R.pplan, in, pl->dy, R.Af, R.Tz, scaling_z(Srest), pl->gbuf, R.dim_h, R.dim_gf,
                                        pl->fov_tol, done, st)) {
+      // ... and conv_down_y in front of it in the same kernel where its taps are compiled in
+      if (!launch_conv_ydown_xdownup2(pl->gbuf, R.dim_h, R.Txy, scaling_xy(S2), R.dim_x.x, R.dim_x.y, pl->gbuf2, done,
+                                      st)) {
+        PushSrc src = push_src(R, pl->gbuf2, true, 0.f);
+        src.xd = dxy;
+        src.T.n[0] = src.T.s[0] = 1, src.T.t[0][0] = 1.f;
+        return src;
+      }
       launch_conv_down_sep(pl->gbuf, R.dim_h, Ty, scaling_xy(Srest), pl->gbuf2, dxy, pl->gbuf, pl->gbuf2, done, st);
       if (!launch_conv_downup2(pl->gbuf2, dxy, R.Tf, Sx, 0, R.dim_x.x, pl->gbuf, done, st)) {
         PushSrc src = push_src(R, pl->gbuf, true, 0.f);

@@ -620,7 +620,12 @@ __global__ void __launch_bounds__(kBlock) k_conv1d_up2_m(const float4 *__restric
   const float4 *p = src + (long long)a * M.sa_s + kz;
   float4 *q = dst + (long long)a * M.sa_d + kz + (long long)(2 * ma) * M.sm_d;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto in_at = [&](int c) { return c < 0 || c >= M.n_in ? zero : p[(long long)c * M.sm_s]; };
+  // (value-returning: `cond ? zero : p[i]` of two lvalues selects between ADDRESSES and keeps `zero` in scratch memory)
+  auto in_at = [&](int c) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c >= 0 && c < M.n_in) v = p[(long long)c * M.sm_s];
+    return v;
+  };
   // taps x slice factor of source m - i, for even and for odd m
   float te[2][F], to[2][F];
 #pragma unroll
@@ -634,7 +639,8 @@ __global__ void __launch_bounds__(kBlock) k_conv1d_up2_m(const float4 *__restric
 #pragma unroll
   for (int i = 0; i < F; ++i) w[i] = in_at(ma - i);
   auto step = [&](int m, const float (&ke)[F], const float (&ko)[F]) {
-    const float4 nx = m + 1 < mb ? in_at(m + 1) : zero;  // in flight over this step
+    float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m + 1 < mb) nx = in_at(m + 1);  // in flight over this step
     float4 e = zero, o = zero;
 #pragma unroll
     for (int i = F - 1; i >= 0; --i) e = fma4(ke[i], w[i], e), o = fma4(ko[i], w[i], o);
@@ -686,12 +692,16 @@ __global__ void __launch_bounds__(kBlock) k_conv1d_downup2_m(const float4 *__res
   const int m0 = max(ma - (F - 1), 0);
   const bool any = m0 < n_mid;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) w[t] = any ? p[(long long)(2 * m0 + t) * M.sm_s] : zero;
+  for (int t = 0; t < NT; ++t) {
+    w[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (any) w[t] = p[(long long)(2 * m0 + t) * M.sm_s];
+  }
   p += (long long)(2 * (m0 + 1) + NT - 2) * M.sm_s;  // the first of the two inputs that mid[m0 + 1] adds
   for (int m = m0; m < mb; ++m) {
     float4 n0 = zero, n1 = zero;
     if (m + 1 < n_mid && m + 1 < mb) n0 = p[0], n1 = p[M.sm_s];  // in flight over this step
-    const float4 nx = m < n_mid ? mid_of(w, m) : zero;
+    float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < n_mid) nx = mid_of(w, m);
 #pragma unroll
     for (int i = F - 1; i > 0; --i) md[i] = md[i - 1];
     md[0] = nx;
@@ -751,6 +761,168 @@ int launch_conv_downup2(const float *src, Dim3i sd, const Taps &T, const Scaling
   else
     hipLaunchKernelGGL((k_conv1d_downup2_m<3, 2>), grid, vol_block(), 0, st, (const float4 *)src, (float4 *)dst, M, n_mid, done);
   return 0;
+}
+
+// conv_down_y in front of the one-pass x pair, in the same kernel (A^T A of BASELINE config 4 with the default
+// Gaussian profile): a workgroup owns kYXRows x-space rows x kYXLanes float4 of z and walks along x.  Per input
+// plane it stages the 2 kYXRows + NTY - 2 rows its conv_down_y needs in LDS (each input element fetched once by its
+// workgroup; the next plane's loads travel while this one is reduced), every thread forms the y-reduced value
+// of its (row, z) from NTY LDS reads, and that value enters the sliding x window of k_conv1d_downup2_m.  The
+// (nx, ny / 2, nz) intermediate between the y pass and the x pair is never written: 177 MB instead of 177 + 116
+// at config 4.  Same products in the same order as the separate passes: bit-identical results.
+constexpr int kYXRows = 32, kYXLanes = 8, kYXPitch = 12;  // (pitch 12 float4: rows 2 apart land 32 banks apart)
+struct YX2 {
+  int nx, ny_in, ny_mid, z4;  // input planes / rows, output rows, float4 per row
+  int nx_mid, run;            // x-space extent along x, x-space steps per run (even)
+  int nyb, nzb;               // workgroups along y and z
+  float ky[12], kx[12];
+  float sey, soy, sex, sox;   // even / odd slice factors along y and x (1, 1: none)
+};
+
+template <int NTY, int NTX, int FX>
+__global__ void __launch_bounds__(kBlock) k_conv_ydown_xdownup2(const float4 *__restrict__ src, float4 *__restrict__ dst,
+                                                               YX2 A, const int *__restrict__ done) {
+  if (done && *done) return;
+  constexpr int ROWS = 2 * kYXRows + NTY - 2, NLOAD = (ROWS * kYXLanes + kBlock - 1) / kBlock;
+  __shared__ float4 buf[2][ROWS * kYXPitch];
+  const int tid = threadIdx.y * kWave + threadIdx.x;
+  const int tz = tid % kYXLanes, ty = tid / kYXLanes;
+  const int zb = blockIdx.x % A.nzb, yb = blockIdx.x / A.nzb;
+  const int y0 = yb * kYXRows, z = zb * kYXLanes + tz, ym = y0 + ty;
+  const bool own = ym < A.ny_mid && z < A.z4;
+  const int nm = (A.nx + 1) / 2;
+  const int ma = blockIdx.y * A.run, mb = min(ma + A.run, nm);
+  if (ma >= mb) return;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  // staging: element e = (row, lane) of the plane's patch; thread t takes e = t, t + 256, ...
+  int soff[NLOAD], loff[NLOAD];
+  bool sok[NLOAD];
+#pragma unroll
+  for (int n = 0; n < NLOAD; ++n) {
+    const int e = tid + n * kBlock, row = e / kYXLanes, lane = e - row * kYXLanes;
+    const int yi = 2 * y0 + row, zi = zb * kYXLanes + lane;
+    sok[n] = e < ROWS * kYXLanes && yi < A.ny_in && zi < A.z4;
+    soff[n] = sok[n] ? yi * A.z4 + zi : 0;
+    loff[n] = e < ROWS * kYXLanes ? row * kYXPitch + lane : -1;
+  }
+  const long long plane = (long long)A.ny_in * A.z4;
+  const float4 *rd = &buf[0][0] + 2 * ty * kYXPitch + tz;
+  const float scy = (ym & 1) ? A.soy : A.sey;
+  float kex[FX], kox[FX];
+#pragma unroll
+  for (int i = 0; i < FX; ++i) kex[i] = 2 * i < NTX ? A.kx[2 * i] : 0.f, kox[i] = 2 * i + 1 < NTX ? A.kx[2 * i + 1] : 0.f;
+  const int m0 = max(ma - (FX - 1), 0);
+  const int m_end = min(mb, A.nx_mid);  // x-space steps that read planes: m0 .. m_end - 1
+  const bool any = m0 < m_end;
+  int p = 2 * m0;
+  const int plast = 2 * (m_end - 1) + NTX - 1;
+  // (value-returning: a `cond ? src[i] : zero` of two lvalues selects between addresses and keeps `zero` in scratch)
+  auto ldz = [&](bool ok, long long i) __attribute__((always_inline)) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) v = src[i];
+    return v;
+  };
+  float4 fly[NLOAD];  // the plane after the one in LDS, in flight
+  if (any) {
+#pragma unroll
+    for (int n = 0; n < NLOAD; ++n)
+      if (loff[n] >= 0) buf[p & 1][loff[n]] = ldz(sok[n], (long long)p * plane + soff[n]);
+#pragma unroll
+    for (int n = 0; n < NLOAD; ++n) fly[n] = ldz(sok[n] && p + 1 <= plast, (long long)(p + 1) * plane + soff[n]);
+  }
+  __syncthreads();
+  // consumes plane p: its y-reduced value for this thread's (row, z).  Plane p + 1 (in registers since the last
+  // call) goes to the other LDS buffer, plane p + 2 is requested: two planes of loads in flight per workgroup.
+  auto feed = [&]() __attribute__((always_inline)) {
+    float4 nxt[NLOAD];
+    const bool more2 = p + 2 <= plast;
+#pragma unroll
+    for (int n = 0; n < NLOAD; ++n) nxt[n] = ldz(more2 && sok[n], (long long)(p + 2) * plane + soff[n]);
+    const float4 *r = rd + (p & 1) * (ROWS * kYXPitch);
+    float4 acc = zero;
+#pragma unroll
+    for (int t = 0; t < NTY; ++t) acc = fma4(A.ky[t], r[t * kYXPitch], acc);
+    if (p + 1 <= plast) {
+#pragma unroll
+      for (int n = 0; n < NLOAD; ++n)
+        if (loff[n] >= 0) buf[(p + 1) & 1][loff[n]] = fly[n];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NLOAD; ++n) fly[n] = nxt[n];
+    ++p;
+    return make_float4(acc.x * scy, acc.y * scy, acc.z * scy, acc.w * scy);
+  };
+  float4 md[FX], w[NTX];
+#pragma unroll
+  for (int i = 0; i < FX; ++i) md[i] = zero;
+#pragma unroll
+  for (int t = 0; t < NTX; ++t) w[t] = zero;
+  if (any) {
+#pragma unroll
+    for (int t = 0; t + 2 < NTX; ++t) w[t] = feed();
+  }
+  float4 *q = dst + ((long long)(2 * ma) * A.ny_mid + ym) * A.z4 + z;
+  const long long oplane = (long long)A.ny_mid * A.z4;
+  for (int m = m0; m < mb; ++m) {
+    float4 nx = zero;
+    if (m < m_end) {
+      w[NTX - 2] = feed(), w[NTX - 1] = feed();
+      float4 acc = zero;
+#pragma unroll
+      for (int t = 0; t < NTX; ++t) acc = fma4(A.kx[t], w[t], acc);
+      const float sc = (m & 1) ? A.sox : A.sex;
+      nx = make_float4(acc.x * sc, acc.y * sc, acc.z * sc, acc.w * sc);
+    }
+#pragma unroll
+    for (int i = FX - 1; i > 0; --i) md[i] = md[i - 1];
+    md[0] = nx;
+    if (m >= ma) {
+      float4 e = zero, o = zero;
+#pragma unroll
+      for (int i = FX - 1; i >= 0; --i) e = fma4(kex[i], md[i], e), o = fma4(kox[i], md[i], o);
+      if (own) {
+        q[0] = e;
+        if (2 * m + 1 < A.nx) q[oplane] = o;
+      }
+      q += 2 * oplane;
+    }
+#pragma unroll
+    for (int t = 0; t + 2 < NTX; ++t) w[t] = w[t + 2];
+  }
+}
+
+// dst (nx, ny_mid, nz) = conv_up_x(Sx conv_down_x(Sy conv_down_y(src))) for stride-2 profiles along x and y; src is
+// (nx, ny, nz), the x-space extents are nx_mid / ny_mid.  Non-zero: not available, nothing launched.
+int launch_conv_ydown_xdownup2(const float *src, Dim3i sd, const Taps &T, const Scaling &S, int nx_mid, int ny_mid,
+                               float *dst, const int *done, hipStream_t st) {
+  static const bool off = getenv("UNIRES_CONV_YX") && atoi(getenv("UNIRES_CONV_YX")) == 0;
+  if (off || !march2_ok(T, 0) || !march2_ok(T, 1) || (sd.z & 3) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return 1;
+  if (2 * (nx_mid - 1) + T.n[0] - 1 > sd.x - 1 || 2 * (ny_mid - 1) + T.n[1] - 1 > sd.y - 1) return 1;
+  if ((long long)sd.x * sd.y * (sd.z / 4) >= (1ll << 31)) return 1;
+  YX2 A;
+  A.nx = sd.x, A.ny_in = sd.y, A.ny_mid = ny_mid, A.z4 = sd.z / 4, A.nx_mid = nx_mid;
+  A.nyb = (ny_mid + kYXRows - 1) / kYXRows, A.nzb = (A.z4 + kYXLanes - 1) / kYXLanes;
+  for (int t = 0; t < 12; ++t) A.ky[t] = t < T.n[1] ? T.t[1][t] : 0.f, A.kx[t] = t < T.n[0] ? T.t[0][t] : 0.f;
+  A.sey = S.dim == 1 ? S.e : 1.f, A.soy = S.dim == 1 ? S.o : 1.f;
+  A.sex = S.dim == 0 ? S.e : 1.f, A.sox = S.dim == 0 ? S.o : 1.f;
+  // runs: ~768 workgroups (three per CU), at least 6 steps each
+  static const int want = getenv("UNIRES_CONV_YX_BLOCKS") ? atoi(getenv("UNIRES_CONV_YX_BLOCKS")) : 768;
+  const int nm = (sd.x + 1) / 2, cols = A.nyb * A.nzb;
+  const int runs = std::max(1, (want + cols - 1) / cols);
+  A.run = std::max(6, (nm + runs - 1) / runs);
+  A.run += A.run & 1;
+  const dim3 grid((unsigned)cols, (unsigned)((nm + A.run - 1) / A.run));
+#define YX_CASE(NY_, NX_, FX_)                                                                                     \
+  if (T.n[1] == NY_ && T.n[0] == NX_) {                                                                            \
+    hipLaunchKernelGGL((k_conv_ydown_xdownup2<NY_, NX_, FX_>), grid, vol_block(), 0, st, (const float4 *)src,      \
+                       (float4 *)dst, A, done);                                                                    \
+    return 0;                                                                                                      \
+  }
+  YX_CASE(11, 3, 2) YX_CASE(11, 5, 3) YX_CASE(11, 11, 6) YX_CASE(5, 3, 2) YX_CASE(5, 5, 3) YX_CASE(5, 11, 6)
+  YX_CASE(3, 3, 2) YX_CASE(3, 5, 3) YX_CASE(3, 11, 6)
+#undef YX_CASE
+  return 1;
 }
 
 void launch_conv_down_sep(const float *g, Dim3i gd, const Taps &T, const Scaling &S, float *dst,
