@@ -1069,6 +1069,91 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// conv_up along y AND z at stride 2 in one kernel, the y part through LDS (round 4; k_conv1d_up_z2<true> gathers its
+// six source rows with 8-byte global loads per lane and pass and lost to the two passes).  A workgroup takes one x
+// plane and kUpYZRows x-space rows: it stages the kUpYZRows + FY - 1 source rows their 2 kUpYZRows output rows read
+// (each source element fetched once per workgroup, 16-byte loads), then every wave forms output rows: the y sum of
+// a lane's two source voxels from FY 8-byte LDS reads, the z part by wave shifts exactly as k_conv1d_up_z2, one
+// 16-byte store per lane.  The (X, gy, sz) intermediate (119 MB each way at BASELINE config 4) is never written.
+// Same products in the same order as k_conv1d_up2_m followed by k_conv1d_up_z2: bit-identical results.
+#ifndef UNIRES_UPYZ_ROWS
+#define UNIRES_UPYZ_ROWS 16
+#endif
+constexpr int kUpYZRows = UNIRES_UPYZ_ROWS;
+struct UpYZ {
+  float kye[6], kyo[6];  // y taps at even / odd offsets
+  float sey, soy;        // even / odd slice factors along y
+  int ny_src, pitch;     // source rows; LDS floats per staged row (sz rounded up to a multiple of 4)
+};
+
+template <int FY>
+__global__ void __launch_bounds__(kBlock)
+    k_conv_up_yz2(const float *__restrict__ src, Dim3i sd, UpZ2Taps K, float se, float so, float *__restrict__ dst, Dim3i dd,
+                  UpYZ Y, int nyb) {
+  extern __shared__ __align__(16) float rows[];  // (kUpYZRows + FY - 1) x pitch
+  constexpr int NR = kUpYZRows + FY - 1;
+  const int lane = threadIdx.x, w = threadIdx.y, tid = w * kWave + lane;
+  const int x = blockIdx.x / nyb, yb = blockIdx.x - x * nyb;
+  const int my0 = yb * kUpYZRows, c0 = my0 - (FY - 1);  // first x-space row of the block, first staged row
+  const int p4 = Y.pitch / 4;
+  for (int e = tid; e < NR * p4; e += kBlock) {
+    const int r = e / p4, q = e - r * p4, c = c0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c >= 0 && c < Y.ny_src && 4 * q < sd.z)
+      v = *reinterpret_cast<const float4 *>(src + ((long long)x * Y.ny_src + c) * sd.z + 4 * q);  // (sd.z % 4 == 0)
+    reinterpret_cast<float4 *>(rows)[e] = v;
+  }
+  __syncthreads();
+  const int nm = (dd.z + 1) / 2, npair = (nm + 1) / 2;
+  constexpr int H = 3, U = kWave - H;  // halo lanes, useful lanes per pass (as k_conv1d_up_z2)
+  for (int ro = w; ro < 2 * kUpYZRows; ro += kBlock / kWave) {
+    const int uy = 2 * my0 + ro;
+    if (uy >= dd.y) break;
+    const int my = uy >> 1;
+    float ty[FY];
+    const float *yrow[FY];
+#pragma unroll
+    for (int i = 0; i < FY; ++i) {
+      const int c = my - i;
+      ty[i] = ((uy & 1) ? Y.kyo[i] : Y.kye[i]) * ((c & 1) ? Y.soy : Y.sey);
+      yrow[i] = rows + (c - c0) * Y.pitch;  // (c - c0 in [0, NR): rows outside the volume were staged as zeros)
+    }
+    float *drow = dst + ((long long)x * dd.y + uy) * dd.z;
+    for (int jb = 0; jb < npair; jb += U) {
+      const int j = jb - H + lane, c = 2 * j;
+      float s0 = 0.f, s1 = 0.f;
+      if (c >= 0 && c + 1 < sd.z) {
+#pragma unroll
+        for (int i = FY - 1; i >= 0; --i) {  // (ascending source row)
+          const float2 v = *reinterpret_cast<const float2 *>(yrow[i] + c);
+          s0 = fmaf(ty[i], v.x, s0), s1 = fmaf(ty[i], v.y, s1);
+        }
+      } else if (c >= 0 && c < sd.z) {
+#pragma unroll
+        for (int i = FY - 1; i >= 0; --i) s0 = fmaf(ty[i], yrow[i][c], s0);
+      }
+      s0 *= se, s1 *= so;
+      const float b0 = dpp_shr1(s0), b1 = dpp_shr1(s1);  // s[2j - 2], s[2j - 1]
+      const float c0v = dpp_shr1(b0), c1v = dpp_shr1(b1);  // s[2j - 4], s[2j - 3]
+      const float d1 = dpp_shr1(c1v);                      // s[2j - 5]
+      const float o0 = K.ke[0] * s0 + K.ke[1] * b1 + K.ke[2] * b0 + K.ke[3] * c1v + K.ke[4] * c0v + K.ke[5] * d1;
+      const float o1 = K.ko[0] * s0 + K.ko[1] * b1 + K.ko[2] * b0 + K.ko[3] * c1v + K.ko[4] * c0v + K.ko[5] * d1;
+      const float o2 = K.ke[0] * s1 + K.ke[1] * s0 + K.ke[2] * b1 + K.ke[3] * b0 + K.ke[4] * c1v + K.ke[5] * c0v;
+      const float o3 = K.ko[0] * s1 + K.ko[1] * s0 + K.ko[2] * b1 + K.ko[3] * b0 + K.ko[4] * c1v + K.ko[5] * c0v;
+      const int u = 4 * j;
+      if (lane >= H && j < npair) {
+        if (u + 3 < dd.z) {
+          __builtin_memcpy(drow + u, &(const float4 &)make_float4(o0, o1, o2, o3), sizeof(float4));
+        } else {
+          if (u < dd.z) drow[u] = o0;
+          if (u + 1 < dd.z) drow[u + 1] = o1;
+          if (u + 2 < dd.z) drow[u + 2] = o2;
+        }
+      }
+    }
+  }
+}
+
 float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scaling &S, Dim3i gd,
                           float *a, float *b, hipStream_t st) {
   const float *cur = xs;
@@ -1113,6 +1198,31 @@ float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scalin
     // six 8-byte row loads per lane and pass cost more than the 119 MB intermediate they spare)
     static const bool no_yz = !(getenv("UNIRES_UPYZ") && atoi(getenv("UNIRES_UPYZ")) == 1);
     const bool z2 = !no_z2 && T.s[2] == 2 && T.n[2] <= 12 && cd.z >= 2 && active(2);
+    static const bool no_yz_lds = getenv("UNIRES_UPYZ_LDS") && atoi(getenv("UNIRES_UPYZ_LDS")) == 0;
+    if (ax == 1 && z2 && !no_yz_lds && march2_ok(T, 1) && (cd.z & 3) == 0 && cd.z <= 512 && (((uintptr_t)cur) & 15) == 0) {
+      // y and z passes in one kernel, the y part through an LDS stage: no (X, gy, sz) intermediate
+      const Dim3i oz = Dim3i{cd.x, gd.y, gd.z};
+      UpZ2Taps Z;
+      UpYZ Y;
+      for (int i = 0; i < 6; ++i) {
+        Z.ke[i] = 2 * i < T.n[2] ? T.t[2][2 * i] : 0.f, Z.ko[i] = 2 * i + 1 < T.n[2] ? T.t[2][2 * i + 1] : 0.f;
+        Y.kye[i] = 2 * i < T.n[1] ? T.t[1][2 * i] : 0.f, Y.kyo[i] = 2 * i + 1 < T.n[1] ? T.t[1][2 * i + 1] : 0.f;
+      }
+      Y.sey = S.dim == 1 ? S.e : 1.f, Y.soy = S.dim == 1 ? S.o : 1.f, Y.ny_src = cd.y, Y.pitch = cd.z;
+      const int nyb = (gd.y + 2 * kUpYZRows - 1) / (2 * kUpYZRows), fy = (T.n[1] + 1) / 2;
+      const dim3 grid((unsigned)(cd.x * nyb));
+      const size_t lds = (size_t)(kUpYZRows + fy - 1) * Y.pitch * sizeof(float);
+      const float sez = S.dim == 2 ? S.e : 1.f, soz = S.dim == 2 ? S.o : 1.f;
+      if (fy == 6)
+        hipLaunchKernelGGL((k_conv_up_yz2<6>), grid, vol_block(), lds, st, cur, cd, Z, sez, soz, out, oz, Y, nyb);
+      else if (fy == 3)
+        hipLaunchKernelGGL((k_conv_up_yz2<3>), grid, vol_block(), lds, st, cur, cd, Z, sez, soz, out, oz, Y, nyb);
+      else
+        hipLaunchKernelGGL((k_conv_up_yz2<2>), grid, vol_block(), lds, st, cur, cd, Z, sez, soz, out, oz, Y, nyb);
+      cur = out, cd = oz;
+      ax = 2;  // (z is done too)
+      continue;
+    }
     if (ax == 1 && z2 && !no_yz && T.s[1] == 2 && T.n[1] <= 12) {
       // y and z passes in one kernel: no (X, gy, sz) intermediate
       const Dim3i oz = Dim3i{cd.x, gd.y, gd.z};
