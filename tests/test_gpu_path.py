@@ -62,11 +62,17 @@ CASES = {
     'dn_orient': dict(dim_y=(15, 13, 11), n_channels=2, regime='dn', rot=0.1, trans=1.5,
                       orient=[((1, 0, 2), (0, 0, 0)), ((2, 0, 1), (1, 1, 1))]),
     # many-tap profiles at ratio 2 with x-space z a multiple of 4: the separable marching passes and the one-pass
-    # conv_down_x / conv_up_x of A^T A (k_conv1d_downup2_m<3, 2>, <5, 3>, <11, 6>, <5, 3>; tools/which_kernels.py)
-    'sr_iso2_gauss_v4': dict(dim_y=(20, 24, 32), n_channels=1, thick=2, regime='sr', iso=True, prof_ip=2, scl=0.05),
-    'sr_iso2_tri_gauss_v4': dict(dim_y=(20, 24, 32), n_channels=1, thick=2, regime='sr', iso=True, prof_ip=2, prof_tp=1),
+    # conv_down_x / conv_up_x of A^T A with conv_down_y in front (k_conv_ydown_xdownup2, k_conv1d_downup2_m) and the
+    # y + z conv_up (k_conv_up_yz2) with 3, 5 and 11 taps on every axis (the channels' thick axes differ;
+    # tools/which_kernels.py lists a case's kernels)
+    'sr_iso2_gauss_v4': dict(dim_y=(20, 24, 32), n_channels=3, thick=2, regime='sr', iso=True, prof_ip=2, scl=0.05),
+    'sr_iso2_tri_gauss_v4': dict(dim_y=(20, 24, 32), n_channels=3, thick=2, regime='sr', iso=True, prof_ip=2, prof_tp=1),
     'sr_iso2_allgauss_v4': dict(dim_y=(24, 20, 32), n_channels=2, thick=2, regime='sr', iso=True, prof_ip=2, prof_tp=2,
                                 scl=0.05),
+    # ... and the observation's thick axis along y and z after the plan's relabelling (3 y taps with 11 x taps;
+    # z-profile splat with the 11 x 11 in-plane part through the fused x / y kernel)
+    'sr_iso2_gauss_orient_v4': dict(dim_y=(24, 24, 32), n_channels=3, thick=2, regime='sr', iso=True, prof_ip=2, scl=0.05,
+                                    orient=[((0, 1, 2), (0, 0, 0)), ((1, 0, 2), (0, 1, 0)), ((2, 1, 0), (0, 0, 1))]),
     'sr_iso2_tri_v4': dict(dim_y=(24, 20, 32), n_channels=1, thick=2, regime='sr', iso=True, prof_ip=1, prof_tp=1),
 }
 

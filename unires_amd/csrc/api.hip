@@ -861,11 +861,16 @@ static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, co
   }
   // S(2 scl) once between conv and conv^T  (unires/_project.py:175-177)
   const Scaling S2 = make_scaling(2.f * R.scl, R.dim_thick);
-  if (R.hybf && !R.hyb && R.sep && pl->gbuf2 && R.pplan.valid && !(R.sched.valid && R.sched.axis >= 0) &&
-      R.Tf.s[0] == 2 && !(R.Tf.n[0] == 1)) {
-    // forward-only hybrid (many-tap profiles, e.g. the default Gaussian at ratio 2): the x pair conv_down_x /
-    // conv_up_x of A^T A runs as ONE pass whose half-length intermediate stays in registers; the push source
-    // is then the volume that is x-complete already (x taps = Dirac for what follows)
+  // the push branches that take a crafted source (x-space volume x-complete already): the separable conv_up in
+  // front of the grid-source splat (forward-only hybrid) or of the z-profile splat (hybrid; where the x / y taps
+  // are beyond the fused 2-D kernels of ops.hip)
+  static const bool push_default = getenv("UNIRES_PUSH") == nullptr;
+  const bool fwd_only = R.hybf && !R.hyb && R.sep && !(R.sched.valid && R.sched.axis >= 0);
+  const bool both = R.hyb && R.sched.valid && R.sched.axis == 2 && R.Tf.n[0] * R.Tf.n[1] > 16;
+  if (push_default && (fwd_only || both) && pl->gbuf2 && R.pplan.valid && R.Tf.s[0] == 2 && !(R.Tf.n[0] == 1)) {
+    // many-tap profiles (e.g. the default Gaussian at ratio 2): the x pair conv_down_x / conv_up_x of A^T A runs
+    // as ONE pass whose half-length intermediate stays in registers; the push source is then the volume that
+    // is x-complete already (x taps = Dirac for what follows)
     Taps Ty = R.Txy;
     Ty.n[0] = Ty.s[0] = 1, Ty.t[0][0] = 1.f;
     const Dim3i dxy = Dim3i{R.dim_h.x, R.dim_x.y, R.dim_x.z};
@@ -940,7 +945,9 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
   }
   if (!use_tile && mode == nullptr && R.hyb && src.convup && R.sched.valid && R.sched.axis == 2 && pl->gbuf2) {
     // conv_up along x / y as 1-D passes, then the z-profile splat with the intermediate as its source
-    const float *h = launch_conv_up_sep(src.data, src.xd, R.Txy, scaling_xy(src.S), R.dim_h, pl->gbuf, pl->gbuf2, st);
+    Taps Txy = src.T;  // (= R.Txy, or with the x part done already: ata_forward)
+    Txy.n[2] = Txy.s[2] = 1, Txy.t[2][0] = 1.f;
+    const float *h = launch_conv_up_sep(src.data, src.xd, Txy, scaling_xy(src.S), R.dim_h, pl->gbuf, pl->gbuf2, st);
     const float4 *tab = (const float4 *)R.ctab_dev[src.S.dim == 2 ? 1 : 0];
     if (!launch_splat2(R.sched, h, R.dim_h.numel(), tab, R.ctab_n, R.src_stride, R.ctab_step, R.src_stride,
                        R.ctab_step, A, alpha, ep, out, pl->dy, done, st))
