@@ -73,6 +73,9 @@ CASES = {
     # z-profile splat with the 11 x 11 in-plane part through the fused x / y kernel)
     'sr_iso2_gauss_orient_v4': dict(dim_y=(24, 24, 32), n_channels=3, thick=2, regime='sr', iso=True, prof_ip=2, scl=0.05,
                                     orient=[((0, 1, 2), (0, 0, 0)), ((1, 0, 2), (0, 1, 0)), ((2, 1, 0), (0, 0, 1))]),
+    # ratio 2 with the rect profile (BASELINE config 4's operator): conv_down_y / x and conv_up_x / y of A^T A in one
+    # kernel (k_conv_ydown_xdownup2<3, 3, 2, 2>), the z part in the pull and the splat
+    'sr_iso2_rect_v4': dict(dim_y=(24, 20, 32), n_channels=2, thick=2, regime='sr', iso=True, scl=0.1),
     'sr_iso2_tri_v4': dict(dim_y=(24, 20, 32), n_channels=1, thick=2, regime='sr', iso=True, prof_ip=1, prof_tp=1),
 }
 

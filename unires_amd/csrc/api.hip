@@ -866,7 +866,7 @@ static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, co
   // are beyond the fused 2-D kernels of ops.hip)
   static const bool push_default = getenv("UNIRES_PUSH") == nullptr;
   const bool fwd_only = R.hybf && !R.hyb && R.sep && !(R.sched.valid && R.sched.axis >= 0);
-  const bool both = R.hyb && R.sched.valid && R.sched.axis == 2 && R.Tf.n[0] * R.Tf.n[1] > 16;
+  const bool both = R.hyb && R.sched.valid && R.sched.axis == 2 && R.Tf.s[1] == 2;
   if (push_default && (fwd_only || both) && pl->gbuf2 && R.pplan.valid && R.Tf.s[0] == 2 && !(R.Tf.n[0] == 1)) {
     // many-tap profiles (e.g. the default Gaussian at ratio 2): the x pair conv_down_x / conv_up_x of A^T A runs
     // as ONE pass whose half-length intermediate stays in registers; the push source is then the volume that
@@ -879,13 +879,20 @@ static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, co
     // (probe: the fused pass takes the same taps / alignment whatever its source pointer)
     if (y_active && !launch_pull_conv2(R.pplan, in, pl->dy, R.Af, R.Tz, scaling_z(Srest), pl->gbuf, R.dim_h, R.dim_gf,
                                        pl->fov_tol, done, st)) {
-      // ... and conv_down_y in front of it in the same kernel where its taps are compiled in
-      if (!launch_conv_ydown_xdownup2(pl->gbuf, R.dim_h, R.Txy, scaling_xy(S2), R.dim_x.x, R.dim_x.y, pl->gbuf2, done,
-                                      st)) {
+      // ... and conv_down_y in front of it in the same kernel where its taps are compiled in; where the z part
+      // lives in the splat (`both`) conv_up_y goes in as well: the push source is then x- and y-complete
+      const int gy = both ? R.dim_h.y : 0;
+      if (!launch_conv_ydown_xdownup2(pl->gbuf, R.dim_h, R.Txy, scaling_xy(S2), R.dim_x.x, R.dim_x.y, gy, pl->gbuf2,
+                                      done, st)) {
         PushSrc src = push_src(R, pl->gbuf2, true, 0.f);
-        src.xd = dxy;
+        src.xd = both ? Dim3i{R.dim_h.x, R.dim_h.y, R.dim_x.z} : dxy;
         src.T.n[0] = src.T.s[0] = 1, src.T.t[0][0] = 1.f;
+        if (both) src.T.n[1] = src.T.s[1] = 1, src.T.t[1][0] = 1.f;
         return src;
+      }
+      if (both && R.Tf.n[0] * R.Tf.n[1] <= 16) {  // (the fused 2-D kernels of ops.hip serve these taps)
+        launch_conv_down_sep(pl->gbuf, R.dim_h, R.Txy, scaling_xy(S2), pl->xbuf, R.dim_x, pl->gbuf, pl->gbuf2, done, st);
+        return push_src(R, pl->xbuf, true, 0.f);
       }
       launch_conv_down_sep(pl->gbuf, R.dim_h, Ty, scaling_xy(Srest), pl->gbuf2, dxy, pl->gbuf, pl->gbuf2, done, st);
       if (!launch_conv_downup2(pl->gbuf2, dxy, R.Tf, Sx, 0, R.dim_x.x, pl->gbuf, done, st)) {
@@ -947,7 +954,10 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
     // conv_up along x / y as 1-D passes, then the z-profile splat with the intermediate as its source
     Taps Txy = src.T;  // (= R.Txy, or with the x part done already: ata_forward)
     Txy.n[2] = Txy.s[2] = 1, Txy.t[2][0] = 1.f;
-    const float *h = launch_conv_up_sep(src.data, src.xd, Txy, scaling_xy(src.S), R.dim_h, pl->gbuf, pl->gbuf2, st);
+    const Scaling Sxy = scaling_xy(src.S);
+    const bool xy_done = Sxy.dim < 0 && Txy.n[0] == 1 && Txy.s[0] == 1 && Txy.t[0][0] == 1.f && Txy.n[1] == 1 &&
+                         Txy.s[1] == 1 && Txy.t[1][0] == 1.f;  // (ata_forward's one-kernel x / y part: nothing left)
+    const float *h = xy_done ? src.data : launch_conv_up_sep(src.data, src.xd, Txy, Sxy, R.dim_h, pl->gbuf, pl->gbuf2, st);
     const float4 *tab = (const float4 *)R.ctab_dev[src.S.dim == 2 ? 1 : 0];
     if (!launch_splat2(R.sched, h, R.dim_h.numel(), tab, R.ctab_n, R.src_stride, R.ctab_step, R.src_stride,
                        R.ctab_step, A, alpha, ep, out, pl->dy, done, st))

@@ -777,19 +777,28 @@ struct YX2 {
   int nyb, nzb;               // workgroups along y and z
   float ky[12], kx[12];
   float sey, soy, sex, sox;   // even / odd slice factors along y and x (1, 1: none)
+  int gy;                     // FY > 0: output rows (conv_up_y as well: dst is (nx, gy, nz))
 };
 
-template <int NTY, int NTX, int FX>
+// FY > 0: conv_up_y as well (fan-in FY: A^T A of the x AND the y pair in one kernel, for the regime whose z part
+// lives in the pull and the splat).  The x-complete values of a step's two planes pass through LDS once more: a
+// thread adds those of the FY - 1 rows below its own, so a workgroup computes kYXRows x-space rows and owns the
+// output rows of the upper kYXRows - (FY - 1) of them.  Products and order of k_conv1d_up2_m with unit slice
+// factors: bit-identical to the four passes.
+template <int NTY, int NTX, int FX, int FY>
 __global__ void __launch_bounds__(kBlock) k_conv_ydown_xdownup2(const float4 *__restrict__ src, float4 *__restrict__ dst,
                                                                YX2 A, const int *__restrict__ done) {
   if (done && *done) return;
   constexpr int ROWS = 2 * kYXRows + NTY - 2, NLOAD = (ROWS * kYXLanes + kBlock - 1) / kBlock;
+  constexpr int HALO = FY > 0 ? FY - 1 : 0, OWN = kYXRows - HALO;
   __shared__ float4 buf[2][ROWS * kYXPitch];
+  __shared__ float4 vb[FY > 0 ? 2 : 1][FY > 0 ? kYXRows * kYXPitch : 1];
   const int tid = threadIdx.y * kWave + threadIdx.x;
   const int tz = tid % kYXLanes, ty = tid / kYXLanes;
   const int zb = blockIdx.x % A.nzb, yb = blockIdx.x / A.nzb;
-  const int y0 = yb * kYXRows, z = zb * kYXLanes + tz, ym = y0 + ty;
-  const bool own = ym < A.ny_mid && z < A.z4;
+  const int y0 = yb * OWN - HALO, z = zb * kYXLanes + tz, ym = y0 + ty;
+  const bool mid_ok = ym >= 0 && ym < A.ny_mid;  // (x-space rows outside the volume are zeros)
+  const bool own = FY > 0 ? (ty >= HALO && 2 * ym < A.gy && z < A.z4) : (mid_ok && z < A.z4);
   const int nm = (A.nx + 1) / 2;
   const int ma = blockIdx.y * A.run, mb = min(ma + A.run, nm);
   if (ma >= mb) return;
@@ -801,13 +810,13 @@ __global__ void __launch_bounds__(kBlock) k_conv_ydown_xdownup2(const float4 *__
   for (int n = 0; n < NLOAD; ++n) {
     const int e = tid + n * kBlock, row = e / kYXLanes, lane = e - row * kYXLanes;
     const int yi = 2 * y0 + row, zi = zb * kYXLanes + lane;
-    sok[n] = e < ROWS * kYXLanes && yi < A.ny_in && zi < A.z4;
+    sok[n] = e < ROWS * kYXLanes && yi >= 0 && yi < A.ny_in && zi < A.z4;
     soff[n] = sok[n] ? yi * A.z4 + zi : 0;
     loff[n] = e < ROWS * kYXLanes ? row * kYXPitch + lane : -1;
   }
   const long long plane = (long long)A.ny_in * A.z4;
   const float4 *rd = &buf[0][0] + 2 * ty * kYXPitch + tz;
-  const float scy = (ym & 1) ? A.soy : A.sey;
+  const float scy = mid_ok ? ((ym & 1) ? A.soy : A.sey) : 0.f;
   float kex[FX], kox[FX];
 #pragma unroll
   for (int i = 0; i < FX; ++i) kex[i] = 2 * i < NTX ? A.kx[2 * i] : 0.f, kox[i] = 2 * i + 1 < NTX ? A.kx[2 * i + 1] : 0.f;
@@ -862,8 +871,12 @@ __global__ void __launch_bounds__(kBlock) k_conv_ydown_xdownup2(const float4 *__
 #pragma unroll
     for (int t = 0; t + 2 < NTX; ++t) w[t] = feed();
   }
-  float4 *q = dst + ((long long)(2 * ma) * A.ny_mid + ym) * A.z4 + z;
-  const long long oplane = (long long)A.ny_mid * A.z4;
+  const int orows = FY > 0 ? A.gy : A.ny_mid;
+  float4 *q = dst + ((long long)(2 * ma) * orows + (FY > 0 ? 2 * ym : ym)) * A.z4 + z;
+  const long long oplane = (long long)orows * A.z4;
+  float kye[FY > 0 ? FY : 1], kyo[FY > 0 ? FY : 1];  // conv_up_y taps at even / odd offsets (= A.ky: same profile)
+#pragma unroll
+  for (int i = 0; i < FY; ++i) kye[i] = 2 * i < NTY ? A.ky[2 * i] : 0.f, kyo[i] = 2 * i + 1 < NTY ? A.ky[2 * i + 1] : 0.f;
   for (int m = m0; m < mb; ++m) {
     float4 nx = zero;
     if (m < m_end) {
@@ -881,7 +894,27 @@ __global__ void __launch_bounds__(kBlock) k_conv_ydown_xdownup2(const float4 *__
       float4 e = zero, o = zero;
 #pragma unroll
       for (int i = FX - 1; i >= 0; --i) e = fma4(kex[i], md[i], e), o = fma4(kox[i], md[i], o);
-      if (own) {
+      if constexpr (FY > 0) {
+        float4 *v0 = &vb[0][ty * kYXPitch + tz], *v1 = &vb[1][ty * kYXPitch + tz];
+        *v0 = e, *v1 = o;
+        __syncthreads();
+        if (own) {
+          float4 ee = zero, eo = zero, oe = zero, oo = zero;  // plane 2m rows 2ym / 2ym + 1, plane 2m + 1 likewise
+#pragma unroll
+          for (int i = FY - 1; i >= 0; --i) {
+            const float4 a = i ? v0[-i * kYXPitch] : e, b = i ? v1[-i * kYXPitch] : o;
+            ee = fma4(kye[i], a, ee), eo = fma4(kyo[i], a, eo), oe = fma4(kye[i], b, oe), oo = fma4(kyo[i], b, oo);
+          }
+          const bool row1 = 2 * ym + 1 < A.gy;
+          q[0] = ee;
+          if (row1) q[A.z4] = eo;
+          if (2 * m + 1 < A.nx) {
+            q[oplane] = oe;
+            if (row1) q[oplane + A.z4] = oo;
+          }
+        }
+        __syncthreads();  // (vb is rewritten by the next step)
+      } else if (own) {
         q[0] = e;
         if (2 * m + 1 < A.nx) q[oplane] = o;
       }
@@ -895,14 +928,17 @@ __global__ void __launch_bounds__(kBlock) k_conv_ydown_xdownup2(const float4 *__
 // dst (nx, ny_mid, nz) = conv_up_x(Sx conv_down_x(Sy conv_down_y(src))) for stride-2 profiles along x and y; src is
 // (nx, ny, nz), the x-space extents are nx_mid / ny_mid.  Non-zero: not available, nothing launched.
 int launch_conv_ydown_xdownup2(const float *src, Dim3i sd, const Taps &T, const Scaling &S, int nx_mid, int ny_mid,
-                               float *dst, const int *done, hipStream_t st) {
+                               int gy, float *dst, const int *done, hipStream_t st) {
   static const bool off = getenv("UNIRES_CONV_YX") && atoi(getenv("UNIRES_CONV_YX")) == 0;
   if (off || !march2_ok(T, 0) || !march2_ok(T, 1) || (sd.z & 3) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return 1;
   if (2 * (nx_mid - 1) + T.n[0] - 1 > sd.x - 1 || 2 * (ny_mid - 1) + T.n[1] - 1 > sd.y - 1) return 1;
   if ((long long)sd.x * sd.y * (sd.z / 4) >= (1ll << 31)) return 1;
   YX2 A;
   A.nx = sd.x, A.ny_in = sd.y, A.ny_mid = ny_mid, A.z4 = sd.z / 4, A.nx_mid = nx_mid;
-  A.nyb = (ny_mid + kYXRows - 1) / kYXRows, A.nzb = (A.z4 + kYXLanes - 1) / kYXLanes;
+  A.gy = gy;
+  const int fy = (T.n[1] + 1) / 2, own = gy > 0 ? kYXRows - (fy - 1) : kYXRows;
+  A.nyb = gy > 0 ? ((gy + 1) / 2 + own - 1) / own : (ny_mid + own - 1) / own;
+  A.nzb = (A.z4 + kYXLanes - 1) / kYXLanes;
   for (int t = 0; t < 12; ++t) A.ky[t] = t < T.n[1] ? T.t[1][t] : 0.f, A.kx[t] = t < T.n[0] ? T.t[0][t] : 0.f;
   A.sey = S.dim == 1 ? S.e : 1.f, A.soy = S.dim == 1 ? S.o : 1.f;
   A.sex = S.dim == 0 ? S.e : 1.f, A.sox = S.dim == 0 ? S.o : 1.f;
@@ -915,8 +951,12 @@ int launch_conv_ydown_xdownup2(const float *src, Dim3i sd, const Taps &T, const 
   const dim3 grid((unsigned)cols, (unsigned)((nm + A.run - 1) / A.run));
 #define YX_CASE(NY_, NX_, FX_)                                                                                     \
   if (T.n[1] == NY_ && T.n[0] == NX_) {                                                                            \
-    hipLaunchKernelGGL((k_conv_ydown_xdownup2<NY_, NX_, FX_>), grid, vol_block(), 0, st, (const float4 *)src,      \
-                       (float4 *)dst, A, done);                                                                    \
+    if (gy > 0)                                                                                                    \
+      hipLaunchKernelGGL((k_conv_ydown_xdownup2<NY_, NX_, FX_, (NY_ + 1) / 2>), grid, vol_block(), 0, st,           \
+                         (const float4 *)src, (float4 *)dst, A, done);                                             \
+    else                                                                                                           \
+      hipLaunchKernelGGL((k_conv_ydown_xdownup2<NY_, NX_, FX_, 0>), grid, vol_block(), 0, st, (const float4 *)src, \
+                         (float4 *)dst, A, done);                                                                  \
     return 0;                                                                                                      \
   }
   YX_CASE(11, 3, 2) YX_CASE(11, 5, 3) YX_CASE(11, 11, 6) YX_CASE(5, 3, 2) YX_CASE(5, 5, 3) YX_CASE(5, 11, 6)

@@ -27,9 +27,10 @@ float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scalin
 int launch_conv_downup2(const float *src, Dim3i sd, const Taps &T, const Scaling &S, int ax, int n_mid, float *dst,
                         const int *done, hipStream_t st);
 // dst (sd.x, ny_mid, sd.z) = conv_up_x(S conv_down_x(S conv_down_y(src))), stride-2 profiles along x and y, one
-// kernel (S applies on its own axis, 0 or 1).  Non-zero: not available, nothing launched.
+// kernel (S applies on its own axis, 0 or 1).  gy > 0: conv_up_y as well, dst is (sd.x, gy, sd.z).  Non-zero: not
+// available, nothing launched.
 int launch_conv_ydown_xdownup2(const float *src, Dim3i sd, const Taps &T, const Scaling &S, int nx_mid, int ny_mid,
-                               float *dst, const int *done, hipStream_t st);
+                               int gy, float *dst, const int *done, hipStream_t st);
 int dtd_num_blocks(Dim3i d);
 // dst = a*src + c*DtD(src); partials (nullable, dtd_num_blocks doubles) gets sum(src*dst) pieces;
 // with objb (needs partials): partials = sum (dst - 2 objb) * src and dst is not stored.
