@@ -861,22 +861,20 @@ static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, co
   }
   // S(2 scl) once between conv and conv^T  (unires/_project.py:175-177)
   const Scaling S2 = make_scaling(2.f * R.scl, R.dim_thick);
-  // the push branches that take a crafted source (x-space volume x-complete already): the separable conv_up in
-  // front of the grid-source splat (forward-only hybrid) or of the z-profile splat (hybrid; where the x / y taps
-  // are beyond the fused 2-D kernels of ops.hip)
+  // A^T A with stride-2 profiles along x and y: the x-space volume is only a way station, so the passes on either
+  // side of it run as one kernel (ops.hip: k_conv_ydown_xdownup2, k_conv1d_downup2_m) and the push gets a crafted
+  // source - a volume that is x-complete (forward-only hybrid: conv_up_y and z follow as one kernel, then the
+  // grid-source splat) or x- and y-complete (hybrid: the z-profile splat takes it as it is)
   static const bool push_default = getenv("UNIRES_PUSH") == nullptr;
   const bool fwd_only = R.hybf && !R.hyb && R.sep && !(R.sched.valid && R.sched.axis >= 0);
   const bool both = R.hyb && R.sched.valid && R.sched.axis == 2 && R.Tf.s[1] == 2;
   if (push_default && (fwd_only || both) && pl->gbuf2 && R.pplan.valid && R.Tf.s[0] == 2 && !(R.Tf.n[0] == 1)) {
-    // many-tap profiles (e.g. the default Gaussian at ratio 2): the x pair conv_down_x / conv_up_x of A^T A runs
-    // as ONE pass whose half-length intermediate stays in registers; the push source is then the volume that
-    // is x-complete already (x taps = Dirac for what follows)
+    // (x taps = Dirac for what follows the x pair; y taps too where conv_up_y went in)
     Taps Ty = R.Txy;
     Ty.n[0] = Ty.s[0] = 1, Ty.t[0][0] = 1.f;
     const Dim3i dxy = Dim3i{R.dim_h.x, R.dim_x.y, R.dim_x.z};
     const Scaling Sx = S2.dim == 0 ? S2 : Scaling{1.f, 1.f, -1}, Srest = S2.dim == 0 ? Scaling{1.f, 1.f, -1} : S2;
     const bool y_active = !(Ty.n[1] == 1 && Ty.s[1] == 1 && Ty.t[1][0] == 1.f) || Srest.dim == 1;
-    // (probe: the fused pass takes the same taps / alignment whatever its source pointer)
     if (y_active && !launch_pull_conv2(R.pplan, in, pl->dy, R.Af, R.Tz, scaling_z(Srest), pl->gbuf, R.dim_h, R.dim_gf,
                                        pl->fov_tol, done, st)) {
       // ... and conv_down_y in front of it in the same kernel where its taps are compiled in; where the z part
