@@ -1,6 +1,8 @@
 """GPU parity of the fused path (plan / matvec / RHS / CG / y-update) against
 the CPU oracle on the same seeded inputs; float32 gate 1e-4 relative
 (BASELINE.json north_star)."""
+import os
+
 import pytest
 import torch
 
@@ -700,3 +702,22 @@ def test_matvec_timing_hooks_count_the_solve_and_leave_it_unchanged(dev):
         outs.append([yc.dat.clone() for yc in y])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_one_kernel_conv_passes_are_bit_identical_to_the_separate_ones():
+    """k_conv_ydown_xdownup2 / k_conv1d_downup2_m / k_conv_up_yz2 (A^T A and A^T of stride-2 profiles) against the
+    separate marching passes they replace, in fresh processes (the switches are read once)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = []
+    for env_extra in ({}, {'UNIRES_CONV_YX': '0'}, {'UNIRES_CONV_YX': '0', 'UNIRES_CONV_DOWNUP': '0'},
+                      {'UNIRES_UPYZ_LDS': '0'},
+                      {'UNIRES_CONV_YX': '0', 'UNIRES_CONV_DOWNUP': '0', 'UNIRES_UPYZ_LDS': '0'}):
+        r = subprocess.run([sys.executable, os.path.join(here, '_conv_fused_probe.py')],
+                           env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith('CONV ')])
+    assert len(outs[0]) == 8
+    for o in outs[1:]:
+        assert o == outs[0]
