@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(kBlock) k_dtd_flat(FlatArgs A, const int *__re
 struct FlatMArgs {
   FlatArgs F;
   unsigned nx, nvp, ncw, xr, nxr;  // planes; whole vectors per plane; 64-vector chunks per plane; planes per run; runs
+  int dbg;                          // UNIRES_FLAT_DBG (measurement only): 1 no edge load, 2 no stencil arithmetic, 4 centre loads only
 };
 
 template <bool DOT, bool OBJ>
@@ -258,8 +259,12 @@ __global__ void __launch_bounds__(kBlock) k_dtd_flat_m(FlatMArgs M, const int *_
     f4 cc, ym, yp, ob;
     float edge;
   };
-  const int lb = xcd_chunked_block(blockIdx.x, gridDim.x);
-  for (unsigned task = (unsigned)lb * (kBlock / kWave) + w; task < ntasks; task += gridDim.x * (kBlock / kWave)) {
+  // (the last workgroup takes the voxels beyond the planes' whole vectors and nothing else: its element-wise loads
+  // run next to the walk instead of behind it)
+  const unsigned nwg = gridDim.x - 1u;
+  const bool tail_wg = blockIdx.x == nwg;
+  const int lb = tail_wg ? 0 : xcd_chunked_block(blockIdx.x, nwg);
+  for (unsigned task = tail_wg ? ntasks : (unsigned)lb * (kBlock / kWave) + w; task < ntasks; task += nwg * (kBlock / kWave)) {
     const unsigned r = task / M.ncw, cw = task - r * M.ncw;
     const unsigned v = cw * kWave + lane;
     const bool valid = v < M.nvp;
@@ -271,24 +276,32 @@ __global__ void __launch_bounds__(kBlock) k_dtd_flat_m(FlatMArgs M, const int *_
     const bool yface = j0 == 0u || j0 + 2u >= A.ny;
     const bool y_inside = __builtin_amdgcn_ballot_w64(yface) == 0ull;
     const unsigned pstep = 4u * nynz;
-    auto load_plane = [&](unsigned bo, bool first, Plane &P) {  // (planes -1 and nx: offsets outside the array read zeros)
-      P.cc = ld4_fast(rp, bo), P.ym = ld4_fast(rp, bo - 4u * nz), P.yp = ld4_fast(rp, bo + 4u * nz);
+    // a plane's centre vector is requested TWO steps ahead, its y neighbours / edge voxel one step ahead: by then
+    // the lines they share with the centres are on their way or in the cache (requested together with the centre
+    // they were three misses on the same lines: 3.8 us for them where tools/mb_stream.hip pays 1.6)
+    auto load_rest = [&](unsigned bo, bool first, Plane &P) {  // (planes -1 and nx: offsets outside the array read zeros)
+      if (M.dbg & 4) { P.ym = P.cc, P.yp = P.cc, P.ob = P.cc, P.edge = 0.f; return; }
+      P.ym = ld4_fast(rp, bo - 4u * nz), P.yp = ld4_fast(rp, bo + 4u * nz);
       // (plane 0: the y - 1 vector of the lane whose four voxels straddle the end of line 0 starts below the
       // array; the hardware adds the components' offsets without 32-bit wrap-around, so its in-range half would
       // read as zeros too)
       if (first && o < nz) P.ym = ld4_safe(rp, (int)o - (int)nz, (int)n);
       P.ob = OBJ ? ld4_fast(rb, bo) : f4{0.f, 0.f, 0.f, 0.f};
-      P.edge = buf_load(rp, bo + eoff, 0);
+      P.edge = (M.dbg & 1) ? 0.f : buf_load(rp, bo + eoff, 0);
     };
     unsigned bo = 4u * (xa * nynz + o);  // byte offset of the lane's vector in the plane being computed
-    auto step = [&](const Plane &prev, const Plane &cur, const Plane &next, Plane &fly, unsigned vx) {
-      // in flight over two steps; beyond the run only the centre of its first plane is wanted (as x + 1)
-      if (vx + 2u < xb)
-        load_plane(bo + 2u * pstep, false, fly);
-      else if (vx + 2u == xb)
-        fly.cc = ld4_fast(rp, bo + 2u * pstep);
+    auto step = [&](const Plane &prev, const Plane &cur, Plane &next, Plane &fly, unsigned vx) {
+      // (beyond the run only the centre of its first plane is wanted, as x + 1)
+      if (vx + 2u <= xb) fly.cc = ld4_fast(rp, bo + 2u * pstep);
+      if (vx + 1u < xb) load_rest(bo + pstep, false, next);
       FlatVec L;
       L.cc = cur.cc, L.xm = prev.cc, L.xp = next.cc, L.ym = cur.ym, L.yp = cur.yp, L.ob = cur.ob, L.edge = cur.edge;
+      if (M.dbg & 2) {
+        const f4 o = cur.cc + prev.cc + next.cc + cur.ym + cur.yp;
+        if (valid) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), rq, bo, 0, kAuxNt);
+        bo += pstep;
+        return;
+      }
       // the common case - no voxel of the wave on an x or y face - carries the z tests only
       if (y_inside && vx > 0u && vx + 1u < M.nx)
         flat_vec<false, DOT, OBJ>(A, L, lane, bo >> 2, k0, j0, valid, rq, dot);
@@ -299,11 +312,9 @@ __global__ void __launch_bounds__(kBlock) k_dtd_flat_m(FlatMArgs M, const int *_
     Plane P0, P1, P2, P3;
     P0.cc = f4{0.f, 0.f, 0.f, 0.f};
     if (xa > 0u) P0.cc = ld4_fast(rp, bo - pstep);
-    load_plane(bo, xa == 0u, P1);
-    if (xa + 1u < xb)
-      load_plane(bo + pstep, false, P2);
-    else
-      P2.cc = ld4_fast(rp, bo + pstep);
+    P1.cc = ld4_fast(rp, bo);
+    load_rest(bo, xa == 0u, P1);
+    P2.cc = ld4_fast(rp, bo + pstep);
     for (unsigned vx = xa; vx < xb; vx += 4u) {  // the slots change roles: no register moves
       step(P0, P1, P2, P3, vx);
       if (vx + 1u < xb) step(P1, P2, P3, P0, vx + 1u);
@@ -313,7 +324,7 @@ __global__ void __launch_bounds__(kBlock) k_dtd_flat_m(FlatMArgs M, const int *_
     }
   }
   // the voxels a plane has beyond its whole vectors, and nothing else is left
-  if (blockIdx.x == 0) {
+  if (tail_wg) {
     const unsigned tl = nynz - 4u * M.nvp, ntail = M.nx * tl;
     const Dim3i dd{(int)M.nx, (int)A.ny, (int)nz};
     for (unsigned i = tid; i < ntail; i += kBlock) {
@@ -333,9 +344,12 @@ __global__ void __launch_bounds__(kBlock) k_dtd_flat_m(FlatMArgs M, const int *_
 // marching form: geometry of the launch; false: the flat kernel serves the volume
 static bool flat_m_geometry(Dim3i dd, FlatMArgs &M) {
   // Measured and left OFF (UNIRES_FLAT_MARCH=-1: on with automatic runs, n: planes per run): at 181 x 217 x 181
-  // the walk takes 13.5 - 14.9 us against k_dtd_flat's 13.0 - a 57 MB pass lasts ~10 us at copy rate, so a wave has
-  // time for a handful of dependent steps only, and with runs that short the run-in planes eat what the marching
-  // saves in loads (4 + 9 / xr per vector instead of 6); with long runs (1024 tasks: 20 us) it is latency-bound.
+  // the walk takes 14.2 - 15.2 us (plain launches, 2048 - 4096 wave tasks; 21 with 1024) where k_dtd_flat takes 12.7
+  // in the same harness.  By ablation (UNIRES_FLAT_DBG): the bare walk - centre loads and stores only - 10.8 - 11.2
+  // (tools/mb_stream.hip's marching copy: 8.9), y neighbours + edge + the stencil arithmetic 3 us on top: with two
+  // to four waves per SIMD a wave's ~86 instructions per plane run at the single-wave issue interval, and shorter
+  // runs pay more run-in planes.  (Before the y neighbours moved one step behind the centre loads and the planes'
+  // last voxels to a workgroup of their own: 17.5.)
   static const int mode = getenv("UNIRES_FLAT_MARCH") ? atoi(getenv("UNIRES_FLAT_MARCH")) : 0;
   if (mode == 0) return false;
   const unsigned long long nynz = (unsigned long long)dd.y * dd.z;
@@ -352,7 +366,7 @@ static bool flat_m_geometry(Dim3i dd, FlatMArgs &M) {
 
 static int flat_m_blocks(const FlatMArgs &M) {
   const unsigned long long nb = ((unsigned long long)M.ncw * M.nxr + (kBlock / kWave) - 1) / (kBlock / kWave);
-  return (int)std::min<unsigned long long>(nb, 4096);
+  return (int)std::min<unsigned long long>(nb, 4096) + 1;  // (+ the workgroup of the planes' last voxels)
 }
 
 static int flat_grid(unsigned nchunk) {
@@ -388,6 +402,8 @@ int launch_dtd_flat(const float *p, float *q, Dim3i dd, float a0, float cx, floa
   FlatMArgs M;
   if (flat_m_geometry(dd, M)) {
     M.F = A;
+    static const int fdbg = getenv("UNIRES_FLAT_DBG") ? atoi(getenv("UNIRES_FLAT_DBG")) : 0;
+    M.dbg = fdbg;
     const dim3 grid(flat_m_blocks(M)), block(kBlock);
     if (objb)
       hipLaunchKernelGGL((k_dtd_flat_m<true, true>), grid, block, 0, st, M, done);
