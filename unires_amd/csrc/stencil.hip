@@ -357,7 +357,7 @@ static bool flat_m_geometry(Dim3i dd, FlatMArgs &M) {
   M.nx = (unsigned)dd.x, M.nvp = (unsigned)(nynz / 4u), M.ncw = (M.nvp + kWave - 1u) / kWave;
   static const int tasks = getenv("UNIRES_FLAT_TASKS") ? atoi(getenv("UNIRES_FLAT_TASKS")) : 2048;
   unsigned long long xr = mode > 0 ? (unsigned long long)mode : ((unsigned long long)M.nx * M.ncw + tasks - 1) / tasks;
-  xr = std::max<unsigned long long>(4, std::min<unsigned long long>(xr, M.nx));
+  xr = std::max<unsigned long long>(mode > 0 ? 2 : 4, std::min<unsigned long long>(xr, M.nx));
   // (runs a multiple of 1 MB apart keep the concurrently walked planes on the same DRAM banks)
   if (mode <= 0 && xr < M.nx && (xr * nynz * 4u) % (1u << 20) == 0) ++xr;
   M.xr = (unsigned)xr, M.nxr = (M.nx + M.xr - 1u) / M.xr;
