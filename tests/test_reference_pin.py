@@ -19,7 +19,7 @@ from tests.helpers import rel_err
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 CASES = ['ref_sr_2ch', 'ref_sr_2rep', 'ref_dn_1ch', 'ref_id_2rep', 'ref_sr_fine', 'ref_sr_gauss',
-         'ref_sr_fine_gauss', 'ref_sr_orient']
+         'ref_sr_fine_gauss', 'ref_sr_orient', 'ref_sr_gauss_v4']
 TOL = 1e-6
 
 
@@ -99,7 +99,7 @@ def _after_admm(g, x, y, method, do_proj, tag='_a15'):
 
 
 @pytest.mark.parametrize('name', ['ref_sr_2ch', 'ref_sr_2rep', 'ref_sr_fine', 'ref_sr_gauss', 'ref_sr_fine_gauss',
-                                  'ref_sr_orient'])
+                                  'ref_sr_orient', 'ref_sr_gauss_v4'])
 def test_update_scaling(name):
     """_update_scaling (:270-393): two Gauss-Newton iterations with line search."""
     g, method, do_proj, dim_y, x, y = load_case(name)
@@ -112,7 +112,7 @@ def test_update_scaling(name):
 
 
 @pytest.mark.parametrize('name', ['ref_sr_2ch', 'ref_sr_2rep', 'ref_dn_1ch', 'ref_sr_fine', 'ref_sr_gauss',
-                                  'ref_sr_fine_gauss', 'ref_sr_orient'])
+                                  'ref_sr_fine_gauss', 'ref_sr_orient', 'ref_sr_gauss_v4'])
 def test_update_rigid_channel(name):
     """_update_rigid_channel (:541-710), no sub-sampling, same se(3) basis as the fixture."""
     g, method, do_proj, dim_y, x, y = load_case(name)
