@@ -588,6 +588,7 @@ static int build_sched(unires_plan *pl, Repeat &R) {
 
 // the pull of the same operator through the LDS-window kernel (denoising: plain pull onto the
 // grid; super-resolution: + conv_down); outside its domain the plan stays invalid
+static void build_shift(unires_plan *pl, Repeat &R);
 static void build_pull(unires_plan *pl, Repeat &R) {
   R.pplan.valid = false;
   if (pl->regime == UNIRES_REGIME_DENOISE)
@@ -596,7 +597,11 @@ static void build_pull(unires_plan *pl, Repeat &R) {
     (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tz, R.dim_h, R.dim_gf, pl->fov_tol);
   else if (pl->regime == UNIRES_REGIME_SUPERRES && !R.sep)
     (void)pull2_build(R.pplan, pl->dy, R.Af, R.Tf, R.dim_x, R.dim_gf, pl->fov_tol);
-  // translation-only operator (and a single repeat: the kernel is the whole matvec)
+  build_shift(pl, R);
+}
+
+// translation-only operator (and a single repeat: the kernel is the whole matvec); carries the slice scaling
+static void build_shift(unires_plan *pl, Repeat &R) {
   R.shift.valid = false;
   if (pl->reps.size() == 1 && pl->regime != UNIRES_REGIME_IDENTITY)
     (void)shift_build(R.shift, pl->dy, R.dim_gf, R.dim_x, R.Tf, make_scaling(2.f * R.scl, R.dim_thick), R.Af,

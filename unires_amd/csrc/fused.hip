@@ -587,12 +587,26 @@ void splat_safety(const Affine &A, int &row_sep, int &use_atomics) {
   auto disjoint = [&](int di, int dj) {
     double v[3];
     for (int r = 0; r < 3; ++r) v[r] = di * (double)A.m[4 * r] + dj * (double)A.m[4 * r + 1];
-    for (double tau = -48.0; tau <= 48.0; tau += 0.02) {
+    // min over tau in [-48, 48] of max_r |v_r + tau c_r|: convex and piecewise linear, so the minimum sits at an
+    // end, at a zero of one line or where two of the six lines +-(v_r + tau c_r) cross (r1 - r3 sampled tau in
+    // steps of 0.02: 1.2 ms per operator, most of what unires_plan_set_repeat cost the host)
+    auto f = [&](double tau) {
       double m = 0;
       for (int r = 0; r < 3; ++r) m = std::max(m, fabs(v[r] + tau * c[r]));
-      if (m < 2.0 + 0.03) return false;  // 0.03: tau sampling (0.02 * |c|) + rounding
+      return m;
+    };
+    double best = std::min(f(-48.0), f(48.0));
+    auto consider = [&](double tau) {
+      if (tau > -48.0 && tau < 48.0) best = std::min(best, f(tau));
+    };
+    for (int r = 0; r < 3; ++r) {
+      if (c[r] != 0.0) consider(-v[r] / c[r]);
+      for (int q = r + 1; q < 3; ++q) {
+        if (c[r] != c[q]) consider((v[q] - v[r]) / (c[r] - c[q]));
+        if (c[r] != -c[q]) consider((-v[q] - v[r]) / (c[r] + c[q]));
+      }
     }
-    return true;
+    return !(best < 2.0 + 0.03);  // (0.03: the margin the sampled form carried for its tau step, kept)
   };
   for (int n = 1; n <= 6; ++n) {
     bool ok = true;
