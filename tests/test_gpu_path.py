@@ -721,3 +721,35 @@ def test_one_kernel_conv_passes_are_bit_identical_to_the_separate_ones():
     assert len(outs[0]) == 8
     for o in outs[1:]:
         assert o == outs[0]
+
+
+@pytest.mark.parametrize('case', ['sr_3ch_axes', 'sr_iso2_gauss_v4', 'sr_iso2_rect_v4', 'sr_shift', 'sr_orient'])
+def test_scaling_update_in_place_equals_a_fresh_plan(dev, case):
+    """The scaling Gauss-Newton step changes po.scl only: unires_plan_set_repeat then rewrites the tables that
+    carry S(scl) and keeps window plan and splat schedule.  A p, A^T x and A^T A p after two such updates must be
+    those of a plan built from scratch with the final scaling, bit for bit."""
+    import unires_amd as U
+    from unires_amd._project import _channel_plan
+    prob = make_problem(seed=77, **CASES[case])
+    xg, yg, sett = gpu_structs(prob, dev)
+    xf, yf, _ = gpu_structs(prob, dev)
+    torch.manual_seed(3)
+    for c in range(len(xg)):
+        p = torch.rand(prob['dim_y'], device=dev) * 100
+        _channel_plan(xg[c], yg[c], prob['method'], prob['do_proj'])  # built with the problem's scaling
+        for step, d in enumerate((0.013, -0.021)):
+            for xn in xg[c]:
+                xn.po.scl = float(xn.po.scl) + d
+            q = U._proj('AtA', p, xg[c], yg[c], method=prob['method'], do=prob['do_proj'], rho=torch.tensor(prob['rho']),
+                        vx_y=torch.ones(3))
+        for a, b in zip(xf[c], xg[c]):
+            a.po.scl = float(b.po.scl)
+        q_f = U._proj('AtA', p, xf[c], yf[c], method=prob['method'], do=prob['do_proj'], rho=torch.tensor(prob['rho']),
+                      vx_y=torch.ones(3))
+        assert torch.equal(q, q_f), (case, c)
+        for n in range(len(xg[c])):
+            xv = torch.rand(tuple(xg[c][n].po.dim_x), device=dev)
+            for op, v in (('A', p), ('At', xv)):
+                o1 = U._proj(op, v, xg[c], yg[c], method=prob['method'], do=prob['do_proj'], n=n)
+                o2 = U._proj(op, v, xf[c], yf[c], method=prob['method'], do=prob['do_proj'], n=n)
+                assert torch.equal(o1, o2), (case, c, n, op)

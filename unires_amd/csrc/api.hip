@@ -508,7 +508,10 @@ static void free_ztabs(Repeat &R) {
 
 // (re)build the splat schedule of a repeat for its current operator; a non-applicable operator
 // simply leaves the schedule invalid (the general push kernels then run)
-static int build_sched(unires_plan *pl, Repeat &R) {
+// tables_only: the operator's geometry is unchanged (a new slice scaling only): the conv_up tables are rewritten,
+// the schedule itself - which does not see the scaling - stays
+static int build_sched(unires_plan *pl, Repeat &R, bool tables_only = false) {
+  const bool was_valid = R.sched.valid;
   R.sched.valid = false;
   if (pl->regime == UNIRES_REGIME_IDENTITY) return UNIRES_OK;
   int axis = -1;
@@ -579,6 +582,10 @@ static int build_sched(unires_plan *pl, Repeat &R) {
           return fail(UNIRES_ERR_HIP, "hipMemcpy conv table");
       }
     }
+  }
+  if (tables_only) {
+    R.sched.valid = was_valid;
+    return UNIRES_OK;
   }
   (void)splat2_build(R.sched, R.Af, R.Afinv, R.dim_gf, pl->dy, pl->fov_tol, R.safe, axis, rows_y,
                      (const float4 *)R.xytab_dev[0], (const float4 *)R.xytab_dev[1], R.dim_x);
@@ -778,6 +785,37 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   (void)hipDeviceSynchronize();
   drop_cg_graph(plan);  // the captured solve has the old operator baked in
   plan->prec_ready = false;  // a preconditioner built for the old operator is stale
+  {
+    // A new slice scaling on the same geometry (the scaling Gauss-Newton step, unires/_update.py:270-393, once
+    // per observation and ADMM iteration): window plan and splat schedule do not see it - only the conv_up
+    // tables that carry S(scl) and the translated regime's factors are rewritten (the schedule build's kernels are
+    // 1.2 ms at 256^3, waited for: 5.2 -> 3.9 ms per scaling step of three channels)
+    Repeat &old = plan->reps[n];
+    static const bool no_fast = getenv("UNIRES_SET_REPEAT_FULL") != nullptr;
+    auto taps_equal = [](const Taps &a, const Taps &b) {
+      for (int d = 0; d < 3; ++d) {
+        if (a.n[d] != b.n[d] || a.s[d] != b.s[d]) return false;
+        for (int t = 0; t < a.n[d]; ++t)
+          if (a.t[d][t] != b.t[d][t]) return false;
+      }
+      return true;
+    };
+    const bool same = !no_fast && !memcmp(&tmp.A, &old.A, sizeof(Affine)) && taps_equal(tmp.T, old.T) &&
+                      !memcmp(&tmp.Af, &old.Af, sizeof(Affine)) && taps_equal(tmp.Tf, old.Tf) &&
+                      !memcmp(&tmp.dim_x, &old.dim_x, sizeof(Dim3i)) && !memcmp(&tmp.dim_g, &old.dim_g, sizeof(Dim3i)) &&
+                      !memcmp(&tmp.dim_gf, &old.dim_gf, sizeof(Dim3i)) && !memcmp(&tmp.dim_xu, &old.dim_xu, sizeof(Dim3i)) &&
+                      !memcmp(&tmp.orient, &old.orient, sizeof(Orient)) && tmp.oriented == old.oriented &&
+                      tmp.dim_thick == old.dim_thick && (tmp.scl != 0.f) == (old.scl != 0.f) && tmp.sep0 == old.sep0;
+    static const bool verbose = getenv("UNIRES_SET_REPEAT_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "[set_repeat] %s (scl %g -> %g)\n", same ? "scaling only" : "full rebuild", (double)old.scl, (double)tmp.scl);
+    if (same) {
+      old.scl = tmp.scl, old.tau = tmp.tau;
+      rc = upload_ztabs(plan, old);
+      if (!rc) rc = build_sched(plan, old, true);
+      if (!rc) build_shift(plan, old);
+      return rc;
+    }
+  }
   if (tmp.dim_gf.z != plan->reps[n].dim_gf.z) free_ztabs(plan->reps[n]);
   tmp.ztab_dev[0] = plan->reps[n].ztab_dev[0];
   tmp.ztab_dev[1] = plan->reps[n].ztab_dev[1];
