@@ -141,35 +141,65 @@ __global__ void __launch_bounds__(kBlock)
 // _even_odd does ('odd' = dat[::2], 'even' = dat[1::2], _update.py:430-445);
 // out[0] = sum (x-y)^2, out[1] = sum_even y(x-y), out[2] = sum_odd y(x-y),
 // out[3] = sum_even y^2, out[4] = sum_odd y^2  - float32 terms, float64 sums.
+// Two stages, both in a fixed order (r1 - r3 added the workgroups' sums with float64 atomics: a result that
+// depended on the order they finished in, and one 64-bit division per voxel for the slice parity): every workgroup
+// walks the volume with a fixed stride keeping (x, y, z) of its voxel by carry arithmetic, writes its five sums to
+// part[5 * blockIdx.x ..]; k_scaling_sums_final adds the workgroups' sums in index order.
+constexpr int kScalingBlocks = 1024;
 __global__ void __launch_bounds__(kBlock)
     k_scaling_sums(const float *__restrict__ x, const float *__restrict__ y, Dim3i d, int dim_thick,
-                   double *__restrict__ out) {
+                   double *__restrict__ part) {
   const size_t n = d.numel(), stride = (size_t)gridDim.x * blockDim.x;
-  const size_t div = dim_thick == 2 ? 1 : (dim_thick == 1 ? (size_t)d.z : (size_t)d.y * d.z);
-  const int len = dim_thick == 2 ? d.z : (dim_thick == 1 ? d.y : d.x);
+  // stride = sx * (dy dz) + sy * dz + sz; position of voxel i0 = blockIdx.x * blockDim.x + threadIdx.x
+  const size_t plane = (size_t)d.y * d.z;
+  const int sx = (int)(stride / plane), sy = (int)((stride % plane) / d.z), sz = (int)(stride % d.z);
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int px = (int)(i0 / plane), py = (int)((i0 % plane) / d.z), pz = (int)(i0 % d.z);
   double s0 = 0.0, ge = 0.0, go = 0.0, he = 0.0, ho = 0.0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  for (size_t i = i0; i < n; i += stride) {
     const float xv = x[i];
-    if (xv == 0.f) continue;
-    const float yv = y[i], r = __fsub_rn(xv, yv);
-    const bool even = ((i / div) % (size_t)len) & 1;  // index 1::2 along dim_thick
-    s0 += (double)__fmul_rn(r, r);
-    const double g = (double)__fmul_rn(yv, r), h = (double)__fmul_rn(yv, yv);
-    if (even)
-      ge += g, he += h;
-    else
-      go += g, ho += h;
+    if (xv != 0.f) {
+      const float yv = y[i], r = __fsub_rn(xv, yv);
+      const bool even = (dim_thick == 2 ? pz : (dim_thick == 1 ? py : px)) & 1;  // index 1::2 along dim_thick
+      s0 += (double)__fmul_rn(r, r);
+      const double g = (double)__fmul_rn(yv, r), h = (double)__fmul_rn(yv, yv);
+      if (even)
+        ge += g, he += h;
+      else
+        go += g, ho += h;
+    }
+    pz += sz;
+    if (pz >= d.z) pz -= d.z, ++py;
+    py += sy;
+    if (py >= d.y) py -= d.y, ++px;  // (py + carry + sy <= 2 dy - 1: once)
+    px += sx;
   }
   const double v[5] = {block_sum(s0), block_sum(ge), block_sum(go), block_sum(he), block_sum(ho)};
   if (threadIdx.x == 0)
-    for (int k = 0; k < 5; ++k) atomicAdd(out + k, v[k]);
+    for (int k = 0; k < 5; ++k) part[5 * blockIdx.x + k] = v[k];
 }
 
-void launch_scaling_sums(const float *x, const float *y, Dim3i d, int dim_thick, double *out,
-                         hipStream_t st) {
+__global__ void __launch_bounds__(kBlock) k_scaling_sums_final(const double *__restrict__ part, int nb, double *__restrict__ out) {
+  // thread t adds workgroups t, t + 256, ... in order; block_sum's tree is fixed too
+  for (int k = 0; k < 5; ++k) {
+    double a = 0.0;
+    for (int b = threadIdx.x; b < nb; b += kBlock) a += part[5 * b + k];
+    const double tot = block_sum(a);
+    if (threadIdx.x == 0) out[k] = tot;
+  }
+}
+
+int scaling_sums_blocks(Dim3i d) {
   size_t b = (d.numel() + kBlock - 1) / kBlock;
-  if (b > 256) b = 256;
-  hipLaunchKernelGGL(k_scaling_sums, dim3((int)b), dim3(kBlock), 0, st, x, y, d, dim_thick, out);
+  return (int)(b > (size_t)kScalingBlocks ? (size_t)kScalingBlocks : b);
+}
+
+// part: 5 * scaling_sums_blocks(d) doubles of scratch
+void launch_scaling_sums(const float *x, const float *y, Dim3i d, int dim_thick, double *part, double *out,
+                         hipStream_t st) {
+  const int nb = scaling_sums_blocks(d);
+  hipLaunchKernelGGL(k_scaling_sums, dim3(nb), dim3(kBlock), 0, st, x, y, d, dim_thick, part);
+  hipLaunchKernelGGL(k_scaling_sums_final, dim3(1), dim3(kBlock), 0, st, part, nb, out);
 }
 
 // Gauss-Newton sums of the rigid update (unires/_update.py:622-650).  With s_i(v) =

@@ -12,7 +12,9 @@ int launch_jtv_scale(const float *const *y, const float *lam, int nc, const floa
                      float *scale, double *partials, int norm_only, hipStream_t st);
 void launch_zw_update(const float *y, float lam, const float *scale, float *z, float *w, Dim3i d,
                       const float vx[3], float rho, float alpha, hipStream_t st);
-void launch_scaling_sums(const float *x, const float *y, Dim3i d, int dim_thick, double *out,
+int scaling_sums_blocks(Dim3i d);
+// part: 5 * scaling_sums_blocks(d) doubles of scratch (per-workgroup sums, added in index order)
+void launch_scaling_sums(const float *x, const float *y, Dim3i d, int dim_thick, double *part, double *out,
                          hipStream_t st);
 void launch_rigid_sums(const float *gr3, const float *diff, const float *ctc, Dim3i dm,
                        const float D[6][12], double *out, hipStream_t st);

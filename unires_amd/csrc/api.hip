@@ -1800,8 +1800,19 @@ extern "C" int unires_scaling_sums(const float *x, const float *ay, const int32_
   if (!dims_ok(dim)) return fail(UNIRES_ERR_DIM, "bad dims");
   if (dim_thick < 0 || dim_thick > 2) return fail(UNIRES_ERR_ARG, "bad dim_thick");
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(out_dev, 0, 5 * sizeof(double), st));
-  launch_scaling_sums(x, ay, mk(dim), dim_thick, out_dev, st);
+  // per-workgroup sums: 40 KB of scratch per (device, stream), kept (used in stream order by the two launches)
+  double *part = nullptr;
+  {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, double *> scratch;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    double *&slot = scratch[std::make_pair(dev, st)];
+    if (!slot) HIP_TRY(hipMalloc((void **)&slot, 5 * 1024 * sizeof(double)));
+    part = slot;
+  }
+  launch_scaling_sums(x, ay, mk(dim), dim_thick, part, out_dev, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
