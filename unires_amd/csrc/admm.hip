@@ -47,7 +47,7 @@ template <int NC>
 __global__ void __launch_bounds__(kBlock)
     k_jtv_scale(ChanPtrs C, const float *__restrict__ w, const float *__restrict__ z_old, Dim3i d,
                 float ivx, float ivy, float ivz, float rho, float alpha, float *__restrict__ scale,
-                double *__restrict__ partials /* single accumulator */, int norm_only) {
+                double *__restrict__ partials /* one per workgroup */, int norm_only) {
   const size_t n = d.numel();
   const float irho = 1.f / rho;
   double tot = 0.0;
@@ -87,9 +87,9 @@ __global__ void __launch_bounds__(kBlock)
         scale[idx] = fmaxf(nrm - irho, 0.f) / (nrm + 1e-7f);
       }
     }
-  if (partials && C.last) {  // one float64 atomic per workgroup (<= 4096 per launch, once per ADMM iteration)
+  if (partials && C.last) {  // one sum per workgroup, added in index order by k_sum_cols (no atomics: the same result every run)
     const double s = block_sum(tot);
-    if (threadIdx.x == 0 && threadIdx.y == 0) atomicAdd(partials, s);
+    if (threadIdx.x == 0 && threadIdx.y == 0) partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
   }
 }
 
@@ -133,7 +133,20 @@ __global__ void __launch_bounds__(kBlock)
     }
   }
   const double s = block_sum(acc);
-  if (threadIdx.x == 0) atomicAdd(partials, s);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// out[k] = sum_b part[b * ncols + k], b in index order (thread t takes b = t, t + 256, ...; block_sum's tree is fixed)
+__global__ void __launch_bounds__(kBlock) k_sum_cols(const double *__restrict__ part, int nb, int ncols, double *__restrict__ out) {
+  for (int k = 0; k < ncols; ++k) {
+    double a = 0.0;
+    for (int b = threadIdx.x; b < nb; b += kBlock) a += part[(size_t)b * ncols + k];
+    const double tot = block_sum(a);
+    if (threadIdx.x == 0) out[k] = tot;
+  }
+}
+void launch_sum_cols(const double *part, int nb, int ncols, double *out, hipStream_t st) {
+  hipLaunchKernelGGL(k_sum_cols, dim3(1), dim3(kBlock), 0, st, part, nb, ncols, out);
 }
 
 // The five masked sums of the even/odd slice-scaling Gauss-Newton step
@@ -144,7 +157,7 @@ __global__ void __launch_bounds__(kBlock)
 // Two stages, both in a fixed order (r1 - r3 added the workgroups' sums with float64 atomics: a result that
 // depended on the order they finished in, and one 64-bit division per voxel for the slice parity): every workgroup
 // walks the volume with a fixed stride keeping (x, y, z) of its voxel by carry arithmetic, writes its five sums to
-// part[5 * blockIdx.x ..]; k_scaling_sums_final adds the workgroups' sums in index order.
+// part[5 * blockIdx.x ..]; k_sum_cols adds the workgroups' sums in index order.
 constexpr int kScalingBlocks = 1024;
 __global__ void __launch_bounds__(kBlock)
     k_scaling_sums(const float *__restrict__ x, const float *__restrict__ y, Dim3i d, int dim_thick,
@@ -179,16 +192,6 @@ __global__ void __launch_bounds__(kBlock)
     for (int k = 0; k < 5; ++k) part[5 * blockIdx.x + k] = v[k];
 }
 
-__global__ void __launch_bounds__(kBlock) k_scaling_sums_final(const double *__restrict__ part, int nb, double *__restrict__ out) {
-  // thread t adds workgroups t, t + 256, ... in order; block_sum's tree is fixed too
-  for (int k = 0; k < 5; ++k) {
-    double a = 0.0;
-    for (int b = threadIdx.x; b < nb; b += kBlock) a += part[5 * b + k];
-    const double tot = block_sum(a);
-    if (threadIdx.x == 0) out[k] = tot;
-  }
-}
-
 int scaling_sums_blocks(Dim3i d) {
   size_t b = (d.numel() + kBlock - 1) / kBlock;
   return (int)(b > (size_t)kScalingBlocks ? (size_t)kScalingBlocks : b);
@@ -199,7 +202,7 @@ void launch_scaling_sums(const float *x, const float *y, Dim3i d, int dim_thick,
                          hipStream_t st) {
   const int nb = scaling_sums_blocks(d);
   hipLaunchKernelGGL(k_scaling_sums, dim3(nb), dim3(kBlock), 0, st, x, y, d, dim_thick, part);
-  hipLaunchKernelGGL(k_scaling_sums_final, dim3(1), dim3(kBlock), 0, st, part, nb, out);
+  launch_sum_cols(part, nb, 5, out, st);
 }
 
 // Gauss-Newton sums of the rigid update (unires/_update.py:622-650).  With s_i(v) =
@@ -243,17 +246,22 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
   for (int t = 0; t < 27; ++t) {
     const double tot = block_sum(acc[t]);
-    if (threadIdx.x == 0) atomicAdd(out + t, tot);
+    if (threadIdx.x == 0) out[27 * blockIdx.x + t] = tot;  // (per-workgroup sums: k_sum_cols adds them in order)
   }
 }
 
+int rigid_sums_blocks(Dim3i dm) {
+  size_t b = (dm.numel() + kBlock - 1) / kBlock;
+  return (int)(b > 512 ? 512 : b);
+}
+// part: 27 * rigid_sums_blocks(dm) doubles of scratch
 void launch_rigid_sums(const float *gr3, const float *diff, const float *ctc, Dim3i dm,
-                       const float D[6][12], double *out, hipStream_t st) {
+                       const float D[6][12], double *part, double *out, hipStream_t st) {
   RigidD R;
   memcpy(R.d, D, sizeof(R.d));
-  size_t b = (dm.numel() + kBlock - 1) / kBlock;
-  if (b > 512) b = 512;
-  hipLaunchKernelGGL(k_rigid_sums, dim3((int)b), dim3(kBlock), 0, st, gr3, diff, ctc, dm, R, out);
+  const int b = rigid_sums_blocks(dm);
+  hipLaunchKernelGGL(k_rigid_sums, dim3(b), dim3(kBlock), 0, st, gr3, diff, ctc, dm, R, part);
+  launch_sum_cols(part, b, 27, out, st);
 }
 
 // y[v] = 0 where M v falls outside [0, dim_x) on any axis  (fit()'s clean_fov, run.py:150-164:
@@ -276,25 +284,29 @@ void launch_clean_fov(float *y, Dim3i d, const Affine &M, Dim3i dx, hipStream_t 
   hipLaunchKernelGGL(k_clean_fov, grid, vblock(), 0, st, y, d, M, (float)dx.x, (float)dx.y,
                      (float)dx.z);
 }
-static inline int tile_blocks(Dim3i d) {
-  // <= 1024 workgroups: each ends with ONE float64 atomic on a single accumulator
-  const long long nt = (long long)((d.z + kWave - 1) / kWave) * ((d.y + 3) / 4) * d.x;
-  return (int)(nt < 1024 ? nt : 1024);
+// workgroups of a k_jtv_scale launch: (z, y) patches x as many x slots as keep the launch at ~4096 workgroups
+static dim3 jtv_grid(Dim3i d) {
+  const int tz = (d.z + kWave - 1) / kWave, ty = (d.y + 3) / 4;
+  int gx = (int)std::min<long long>(d.x, std::max<long long>(1, 4096 / ((long long)tz * ty)));
+  if ((long long)tz * ty * gx > 65535ll * 16) gx = 1;
+  return dim3(tz, ty, gx);
+}
+int jtv_scale_blocks(Dim3i d) {
+  const dim3 g = jtv_grid(d);
+  return (int)(g.x * g.y * g.z);
 }
 
 int launch_jtv_scale(const float *const *y, const float *lam, int nc, const float *w,
                      const float *z_old, Dim3i d, const float vx[3], float rho, float alpha,
-                     float *scale, double *partials, int norm_only, hipStream_t st) {
+                     float *scale, double *part, double *out, int norm_only, hipStream_t st) {
   // The joint-TV magnitude couples all channels of a voxel (unires/_update.py:166-173 loops over any
   // C); the kernel takes 8 channel pointers by value, so more channels run as a chain of launches
   // that carry the running sum of squares in `scale`.
   if (nc > 8 && !scale) return -1;
-  // (z, y) patches x as many x slots as keep the launch at ~4096 workgroups
-  const int tz = (d.z + kWave - 1) / kWave, ty = (d.y + 3) / 4;
-  int gx = (int)std::min<long long>(d.x, std::max<long long>(1, 4096 / ((long long)tz * ty)));
-  if ((long long)tz * ty * gx > 65535ll * 16) gx = 1;
-  const dim3 grid(tz, ty, gx);
-  const int g = tz * ty * gx;
+  // part (jtv_scale_blocks(d) doubles of scratch) + out: the sum of the norms, added in workgroup order
+  const dim3 grid = jtv_grid(d);
+  const int g = (int)(grid.x * grid.y * grid.z);
+  double *partials = out ? part : nullptr;
   for (int c0 = 0; c0 < nc; c0 += 8) {
     ChanPtrs C;
     C.n = nc - c0 < 8 ? nc - c0 : 8;
@@ -312,6 +324,7 @@ int launch_jtv_scale(const float *const *y, const float *lam, int nc, const floa
     }
 #undef JTV_LAUNCH
   }
+  if (out) launch_sum_cols(part, g, 1, out, st);
   return g;
 }
 
@@ -322,12 +335,16 @@ void launch_zw_update(const float *y, float lam, const float *scale, float *z, f
                      1.f / vx[1], 1.f / vx[2], rho, alpha);
 }
 
-int launch_masked_sse(const float *x, const float *ay, size_t n, double *partials, hipStream_t st) {
+int masked_sse_blocks(size_t n) {
   size_t b = (n + kBlock - 1) / kBlock;
-  if (b > 512) b = 512;  // one float64 atomic per workgroup on a single accumulator
-  if (b < 1) b = 1;
-  hipLaunchKernelGGL(k_masked_sse, dim3((int)b), dim3(kBlock), 0, st, x, ay, n, partials);
-  return (int)b;
+  return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
+}
+// part: masked_sse_blocks(n) doubles of scratch
+int launch_masked_sse(const float *x, const float *ay, size_t n, double *part, double *out, hipStream_t st) {
+  const int b = masked_sse_blocks(n);
+  hipLaunchKernelGGL(k_masked_sse, dim3(b), dim3(kBlock), 0, st, x, ay, n, part);
+  launch_sum_cols(part, b, 1, out, st);
+  return b;
 }
 
 }  // namespace unires

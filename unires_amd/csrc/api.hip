@@ -1736,6 +1736,29 @@ static int check_channels(const float *const *y_ptrs, const float *lam, int32_t 
   return UNIRES_OK;
 }
 
+// scratch of the float64 reductions (per-workgroup sums, added in index order by a second launch): one buffer per
+// (device, stream), grown on demand, used in stream order by the launches that share it
+static int reduce_scratch(hipStream_t st, size_t ndoubles, double **out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, std::pair<double *, size_t>> scratch;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto &slot = scratch[std::make_pair(dev, st)];
+  if (slot.second < ndoubles) {
+    if (slot.first) {
+      HIP_TRY(hipDeviceSynchronize());
+      (void)hipFree(slot.first);
+      slot = {nullptr, 0};
+    }
+    const size_t n = std::max<size_t>(ndoubles, 16384);
+    HIP_TRY(hipMalloc((void **)&slot.first, n * sizeof(double)));
+    slot.second = n;
+  }
+  *out = slot.first;
+  return UNIRES_OK;
+}
+
 extern "C" int unires_zw_update(const float *const *y_ptrs, const float *lam, int32_t n_channels,
                                 const int32_t dim[3], const float vx[3], float rho, float alpha,
                                 float *z, float *w, float *jtv, void *stream) {
@@ -1747,7 +1770,7 @@ extern "C" int unires_zw_update(const float *const *y_ptrs, const float *lam, in
   if (!(rho > 0.f)) return fail(UNIRES_ERR_ARG, "rho must be positive");
   hipStream_t st = (hipStream_t)stream;
   const Dim3i d = mk(dim);
-  launch_jtv_scale(y_ptrs, lam, n_channels, w, z, d, vx, rho, alpha, jtv, nullptr, 0, st);
+  launch_jtv_scale(y_ptrs, lam, n_channels, w, z, d, vx, rho, alpha, jtv, nullptr, nullptr, 0, st);
   const size_t n = d.numel();
   for (int c = 0; c < n_channels; ++c)
     launch_zw_update(y_ptrs[c], lam[c], jtv, z + (size_t)c * 3 * n, w + (size_t)c * 3 * n, d, vx,
@@ -1789,7 +1812,9 @@ extern "C" int unires_nll_prior(const float *const *y_ptrs, const float *lam, in
     }
     acc = slot.first;
   }
-  launch_jtv_scale(y_ptrs, lam, n_channels, nullptr, nullptr, mk(dim), vx, 1.f, 1.f, acc, out_dev, 1, st);
+  double *part = nullptr;
+  if ((rc = reduce_scratch(st, (size_t)jtv_scale_blocks(mk(dim)), &part))) return rc;
+  launch_jtv_scale(y_ptrs, lam, n_channels, nullptr, nullptr, mk(dim), vx, 1.f, 1.f, acc, part, out_dev, 1, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -1800,18 +1825,8 @@ extern "C" int unires_scaling_sums(const float *x, const float *ay, const int32_
   if (!dims_ok(dim)) return fail(UNIRES_ERR_DIM, "bad dims");
   if (dim_thick < 0 || dim_thick > 2) return fail(UNIRES_ERR_ARG, "bad dim_thick");
   hipStream_t st = (hipStream_t)stream;
-  // per-workgroup sums: 40 KB of scratch per (device, stream), kept (used in stream order by the two launches)
   double *part = nullptr;
-  {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, double *> scratch;
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(mu);
-    double *&slot = scratch[std::make_pair(dev, st)];
-    if (!slot) HIP_TRY(hipMalloc((void **)&slot, 5 * 1024 * sizeof(double)));
-    part = slot;
-  }
+  if (int rc = reduce_scratch(st, 5 * (size_t)scaling_sums_blocks(mk(dim)), &part)) return rc;
   launch_scaling_sums(x, ay, mk(dim), dim_thick, part, out_dev, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
@@ -1823,10 +1838,11 @@ extern "C" int unires_rigid_sums(const float *gr3, const float *diff, const floa
   if (!gr3 || !diff || !dim || !d_rigid || !out_dev) return fail(UNIRES_ERR_NULL, "null argument");
   if (!dims_ok(dim)) return fail(UNIRES_ERR_DIM, "bad dims");
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(out_dev, 0, 27 * sizeof(double), st));
   float D[6][12];
   memcpy(D, d_rigid, sizeof(D));
-  launch_rigid_sums(gr3, diff, ctc, mk(dim), D, out_dev, st);
+  double *part = nullptr;
+  if (int rc = reduce_scratch(st, 27 * (size_t)rigid_sums_blocks(mk(dim)), &part)) return rc;
+  launch_rigid_sums(gr3, diff, ctc, mk(dim), D, part, out_dev, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -1847,8 +1863,9 @@ extern "C" int unires_masked_sse(const float *x, const float *ay, int64_t n, dou
   if (!x || !ay || !out_dev) return fail(UNIRES_ERR_NULL, "null argument");
   if (n < 1) return fail(UNIRES_ERR_DIM, "bad length");
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(double), st));
-  launch_masked_sse(x, ay, (size_t)n, out_dev, st);
+  double *part = nullptr;
+  if (int rc = reduce_scratch(st, (size_t)masked_sse_blocks((size_t)n), &part)) return rc;
+  launch_masked_sse(x, ay, (size_t)n, part, out_dev, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
