@@ -644,6 +644,31 @@ def test_fit_with_rigid_and_scaling_updates(dev):
         assert rel_err(dat[..., c].cpu(), y_ref[c].dat) < 5e-3
 
 
+def test_fit_repeats_bit_for_bit(dev):
+    """Two runs of fit() with the scaling and rigid updates on, from the same start: reconstruction, objective
+    trace and scalings are identical to the last bit (every float64 reduction on the device - CG dot products,
+    objective, likelihood, Gauss-Newton sums - adds per-workgroup sums in a fixed order; none uses atomics).
+    The rigid parameters pass through the host's float64 6 x 6 solve and matrix exponential (LAPACK, whose
+    last ulp may depend on buffer alignment): equal to 1e-12."""
+    import unires_amd as U
+    prob = make_problem(seed=54, **CASES['sr_3ch_axes'])
+    outs = []
+    for rep in range(2):
+        xo, yo, xg, yg, sett, Bo = _rigid_setup(prob, dev, perturb=0.01)
+        for c in range(len(yg)):
+            yg[c].dat = prob['y0'][c].clone().to(dev)
+            yg[c].lam0 = float(yg[c].lam) / 4.0
+        sett.max_iter, sett.tolerance, sett.reg_scl, sett.sched_num = 4, 1e-4, 4.0, 3
+        sett.unified_rigid, sett.scaling, sett.rigid_samp = True, True, 1
+        dat, mat, R, info = U.fit(xg, yg, sett)
+        outs.append((dat.clone(), info['obj'].clone(), [r.clone() for r in R],
+                     [float(xn.po.scl) for xc in xg for xn in xc]))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert a[3] == b[3]
+    assert all((p - q).abs().max() < 1e-12 for p, q in zip(a[2], b[2]))
+
+
 @pytest.mark.parametrize('case', ['sr_3ch_axes', 'dn_2ch', 'sr_2rep'])
 def test_update_y_on_channel_streams_and_one_after_the_other(dev, case):
     """settings.channel_streams: True / False / 'auto' run the same kernels per channel - streams only
