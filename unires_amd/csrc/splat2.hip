@@ -232,6 +232,11 @@ __global__ void __launch_bounds__(kWave)
   // instruction that has room, fewer than kS2MaxSeg members and no member it could collide with
   // (rows closer than row_sep whose plane ranges touch).
   __shared__ unsigned short order[kSegs];
+  // (lane 0's work arrays and the lanes' start lists live in LDS - the block is one wave; indexed at run time they
+  // sat in scratch memory: 928 bytes per lane, build kernels 494 + 678 -> 454 + 556 us at 256^3)
+  __shared__ int cnt[33];
+  __shared__ unsigned short tmp[kSegs];
+  __shared__ int start_all[kWave][kS2MaxSeg];
   bool al = true;
   for (int s0 = 0; s0 < nseg; s0 += kWave) {
     const int s = s0 + lane;
@@ -242,7 +247,6 @@ __global__ void __launch_bounds__(kWave)
   auto seg_pos = [&](const S2Seg q) { return aligned ? (zdown ? 31 - (int)q.lzmax : (int)q.lzmin) : 0; };
   // stable counting sort by first lane position (one lane: deterministic schedule)
   if (lane == 0) {
-    int cnt[33];
     for (int i = 0; i < 33; ++i) cnt[i] = 0;
     for (int s = 0; s < nseg; ++s) ++cnt[seg_pos(segs[s]) + 1];
     for (int i = 0; i < 32; ++i) cnt[i + 1] += cnt[i];
@@ -255,7 +259,6 @@ __global__ void __launch_bounds__(kWave)
     // none (26 instructions per config-3 tile for 44 segments).  Offered in this order the row half the
     // cross-section away - 4 to 5 rows over - comes right behind its partner.
     {
-      unsigned short tmp[kSegs];
       const int h = (nseg + 1) / 2;
       for (int s = 0; s < nseg; ++s) tmp[s] = order[s];
       for (int s = 0; s < nseg; ++s) order[s] = tmp[(s & 1) ? h + (s >> 1) : (s >> 1)];
@@ -320,7 +323,7 @@ __global__ void __launch_bounds__(kWave)
   if (lane < nbins) {
     S2Entry *out = entries + base.x + (incl - nent);
     // members in lane order (aligned: by half, then position; else: as packed)
-    int start_of[kS2MaxSeg];
+    int *start_of = start_all[lane];
     int run = 0;
     for (int j = 0; j < nmem; ++j) {
       const S2Seg q = segs[member[lane][j] & 0x7fff];
