@@ -27,6 +27,7 @@
 #include "pull2.hpp"
 #include "shift.hpp"
 #include "splat2.hpp"
+#include "ata1.hpp"
 #include "stencil.hpp"
 
 using namespace unires;
@@ -302,6 +303,7 @@ struct Repeat {
   int xytab_cap[2] = {0, 0};
   PullPlan pplan;  // LDS-window pull: per-workgroup geometry of this operator (pull2.hip)
   ShiftPlan shift;  // translation-only operators: factors of AtA for the one-kernel matvec (shift.hip)
+  F1Sched f1;       // denoising regime: schedule of the single-pass AtA kernel (ata1.hip)
 };
 
 struct unires_plan {
@@ -421,6 +423,7 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
   out.sched = SplatSched();
   out.pplan = PullPlan();
   out.shift = ShiftPlan();
+  out.f1 = F1Sched();
   out.orient = Orient();
   out.ctab_step = 1;
   out.tau = in->tau;
@@ -626,6 +629,11 @@ static int build_repeat_kernels(unires_plan *pl, Repeat &R) {
   int rc = build_sched(pl, R);
   if (rc) return rc;
   build_pull(pl, R);
+  R.f1.valid = false;
+  if (pl->regime == UNIRES_REGIME_DENOISE) {  // pull and push in one pass where the operator allows it
+    (void)ata1_build(R.f1, R.Af, R.Afinv, R.dim_gf, pl->dy, pl->fov_tol, R.safe);
+    (void)hipGetLastError();
+  }
   if (R.hyb && !(R.pplan.valid && R.sched.valid && R.sched.axis == 2)) {
     R.hyb = false;
     R.sep = R.sep0;
@@ -641,6 +649,7 @@ static void free_sched(Repeat &R) {
   splat2_free(R.sched);
   pull2_free(R.pplan);
   shift_free(R.shift);
+  ata1_free(R.f1);
   for (int v = 0; v < 2; ++v) {
     if (R.ctab_dev[v]) (void)hipFree(R.ctab_dev[v]), R.ctab_dev[v] = nullptr;
     if (R.xytab_dev[v]) (void)hipFree(R.xytab_dev[v]), R.xytab_dev[v] = nullptr;
@@ -823,6 +832,7 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   tmp.sched = plan->reps[n].sched;
   tmp.pplan = plan->reps[n].pplan;
   tmp.shift = plan->reps[n].shift;
+  tmp.f1 = plan->reps[n].f1;
   tmp.ctab_dev[0] = plan->reps[n].ctab_dev[0];
   tmp.ctab_dev[1] = plan->reps[n].ctab_dev[1];
   tmp.ctab_cap = plan->reps[n].ctab_cap;
@@ -857,7 +867,7 @@ extern "C" int unires_plan_repeat_info(const unires_plan_t *plan, int32_t n, int
   info[3] = id ? 0 : (R.orient.flip[0] | (R.orient.flip[1] << 1) | (R.orient.flip[2] << 2));
   info[4] = R.pplan.valid ? 1 : 0;
   info[5] = R.sched.valid ? 2 + R.sched.axis : 0;
-  info[6] = R.shift.valid ? 1 : 0;
+  info[6] = (R.shift.valid ? 1 : 0) | (R.f1.valid ? 2 : 0);
   info[7] = R.sep ? 1 : 0;
   return UNIRES_OK;
 }
@@ -1095,8 +1105,11 @@ extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, con
   } else if (op == UNIRES_OP_AT) {
     at_accumulate(plan, R, in, out, 1.f, false, st);
   } else {
-    const PushSrc src = ata_forward(plan, R, in, nullptr, st);
-    push_any(plan, src, R, 1.f, PushEpilogue(), out, nullptr, st);
+    if (!(plan->regime == UNIRES_REGIME_DENOISE && R.f1.valid &&
+          !launch_ata1(R.f1, in, R.Af, 1.f, PushEpilogue(), out, plan->dy, nullptr, st))) {
+      const PushSrc src = ata_forward(plan, R, in, nullptr, st);
+      push_any(plan, src, R, 1.f, PushEpilogue(), out, nullptr, st);
+    }
   }
   CHECK_LAUNCH();
   return UNIRES_OK;
@@ -1150,7 +1163,6 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
   int npart = 0;
   for (size_t n = 0; n < nrep; ++n) {
     const Repeat &R = pl->reps[n];
-    const PushSrc src = ata_forward(pl, R, p, done, st);
     PushEpilogue ep;
     ep.p = p;
     ep.accumulate = n > 0;
@@ -1160,6 +1172,13 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
       ep.cz = c / (pl->vx[2] * pl->vx[2]);
     }
     if (n + 1 == nrep) ep.partials = part, ep.objb = objb;
+    // denoising regime: pull, push, stencil and dot in ONE pass over p (ata1.hip)
+    if (pl->regime == UNIRES_REGIME_DENOISE && R.f1.valid &&
+        !launch_ata1(R.f1, p, R.Af, R.tau, ep, q, pl->dy, done, st)) {
+      npart = ep.partials ? ata1_blocks(pl->dy) : 0;
+      continue;
+    }
+    const PushSrc src = ata_forward(pl, R, p, done, st);
     npart = push_any(pl, src, R, R.tau, ep, q, done, st);
   }
   return npart;
