@@ -445,6 +445,7 @@ int ata1_build(F1Sched &S, const Affine &A, const Affine &Ainv, Dim3i gd, Dim3i 
 struct F1Args {
   const float *src;
   const uint4 *desc;
+  size_t desc_bytes;
   const uint4 *hdr;
   const uint2 *tile_off;
   const uint2 *tile_org;  // {x0 | y0 << 16, z0} of the tile in processing slot u
@@ -463,7 +464,9 @@ struct F1Args {
   int prio_rot;
 };
 
-template <int TX, int TY, int NW>
+// MODE 0: dst = q (+ dot p q if asked); 1: objective mode (partials = sum (q - 2 objb) p, q not stored);
+// 2: general (dst += q first - a later repeat of a multi-repeat operator - then as 0 or 1)
+template <int TX, int TY, int NW, int MODE>
 __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restrict__ done) {
   if (done && *done) return;
   constexpr int SX = TX + 2, SY = TY + 2, SZ = kF1SZ, N = SX * SY * SZ, XS = SY * SZ, YS = SZ;
@@ -472,10 +475,12 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
   static_assert(XS + YS + 1 < 256, "ds_read2 / ds_write2 offsets are 8 bits");
   __shared__ __align__(16) float win_all[NW][N];
   __shared__ __align__(16) float acc_all[NW][N];
+  __shared__ __align__(16) uint4 ring_all[NW][kWave];  // segment entries: 2 chunks of 32
   const int lane = threadIdx.x & (kWave - 1), grp = lane >> 5, gl = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *win = win_all[wave];
   float *acc = acc_all[wave];
+  uint4 *ring = ring_all[wave];
   const Dim3i dd = P.dd;
   float *__restrict__ dst = P.dst;
   if ((int)blockIdx.x >= P.active) {
@@ -494,7 +499,8 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
   const float t0 = P.A.m[3], t1 = P.A.m[7], t2 = P.A.m[11];
   const size_t nbytes = dd.numel() * sizeof(float);
   const __amdgpu_buffer_rsrc_t rs = make_rsrc(P.src, nbytes), rd = make_rsrc(dst, nbytes),
-                               rb = make_rsrc(P.objb ? P.objb : P.src, nbytes);
+                               rb = make_rsrc(P.objb ? P.objb : P.src, nbytes),
+                               re = make_rsrc(P.desc, P.desc_bytes);
   const unsigned sxb = 4u * (unsigned)(dd.y * dd.z), syb = 4u * (unsigned)dd.z;
   constexpr unsigned kOob = 0x80000000u;
   double dot = 0.0;
@@ -512,31 +518,59 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
       const int y = y0 - 1 + 2 * m + grp;
       voff[m] = (zok && (unsigned)y < (unsigned)dd.y) ? (unsigned)y * syb + 4u * (unsigned)kz : kOob;
     }
+    if (x0 >= 1 && x0 + TX < dd.x) {  // every x slab of the window inside the volume
+      const unsigned s0 = (unsigned)(x0 - 1) * sxb;
 #pragma unroll
-    for (int lx = 0; lx < SX; ++lx) {
-      const int x = x0 - 1 + lx;
-      const bool xok = (unsigned)x < (unsigned)dd.x;  // wave-uniform
-      const unsigned soff = xok ? (unsigned)x * sxb : 0u;
+      for (int lx = 0; lx < SX; ++lx)
 #pragma unroll
-      for (int m = 0; m < SY / 2; ++m)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(win + (lx * SY + 2 * m) * SZ),
-                                                 4, xok ? voff[m] : kOob, soff, 0, 0);
+        for (int m = 0; m < SY / 2; ++m)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(win + (lx * SY + 2 * m) * SZ),
+                                                   4, voff[m], s0 + (unsigned)lx * sxb, 0, 0);
+    } else {
+#pragma unroll
+      for (int lx = 0; lx < SX; ++lx) {
+        const int x = x0 - 1 + lx;
+        const bool xok = (unsigned)x < (unsigned)dd.x;  // wave-uniform
+        const unsigned soff = xok ? (unsigned)x * sxb : 0u;
+        const unsigned kill = xok ? 0u : kOob;
+#pragma unroll
+        for (int m = 0; m < SY / 2; ++m)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(win + (lx * SY + 2 * m) * SZ),
+                                                   4, voff[m] | kill, soff, 0, 0);
+      }
     }
+  };
+  // ... and its first 64 segment entries into the ring (one 16-byte LDS-DMA piece per lane)
+  auto stage_entries = [&](unsigned first) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (__attribute__((address_space(3))) void *)ring, 16,
+                                             (first + (unsigned)lane) * 16u, 0, 0, 0);
   };
   auto origin = [&](int t, int &x0, int &y0, int &z0) {  // (host-tabulated: the index arithmetic costs two divisions)
     const uint2 g = P.tile_org[t];
     x0 = __builtin_amdgcn_readfirstlane((int)(g.x & 0xffffu)), y0 = __builtin_amdgcn_readfirstlane((int)(g.x >> 16)),
     z0 = __builtin_amdgcn_readfirstlane((int)g.y);
   };
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int j = 0; j < (N / 4 + kWave - 1) / kWave; ++j)
+      if (lane + j * kWave < N / 4) reinterpret_cast<float4 *>(acc)[lane + j * kWave] = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
   int t = t_lo + slot;
   int x0 = 0, y0 = 0, z0 = 0;
   uint4 myh = make_uint4(0u, 0u, 0u, 0u);
+  uint2 off0 = make_uint2(0u, 0u);
+  int nent = 0, ninstr = 0;
   if (t < t_hi) {
     origin(t, x0, y0, z0);
+    off0 = P.tile_off[t];
+    const uint2 off1 = P.tile_off[t + 1];
+    nent = (int)(off1.x - off0.x), ninstr = (int)(off1.y - off0.y);
     stage(x0, y0, z0);
-    myh = P.hdr[P.tile_off[t].y + lane];
+    stage_entries(off0.x);
+    myh = P.hdr[off0.y + lane];
   }
-  for (int i = lane; i < N / 4; i += kWave) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  zero_acc();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (first tile: nothing younger than its requests is in flight)
   int round = 0;
   for (; t < t_hi; t += slots, ++round) {
     if (P.prio_rot) {  // (the SIMD issues from its oldest wave first: rotate the ranking, see k_splat2)
@@ -548,25 +582,49 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
       }
     }
     const int ey = min(TY, dd.y - y0), ez = min(kF1TZ, dd.z - z0);
-    const uint2 off0 = P.tile_off[t], off1 = P.tile_off[t + 1];
-    const int ninstr = (int)(off1.y - off0.y);
-    const uint4 *E = P.desc + off0.x;
     // lane l keeps the header of instruction l (a tile has at most 64): segment-start mask, first entry
     const int hlo_v = (int)myh.x, hhi_v = (int)myh.y, hfe_v = (int)myh.z;
-    // a lane's segment of instruction i: entry (first entry of i) + (segment starts at or below the lane)
-    auto entry_of = [&](int i) {
+    // The window, the ring and the header were requested one tile ahead (at the previous epilogue's head);
+    // what may still be in flight behind them are that epilogue's stores, which nobody waits for.
+    if (MODE == 0)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HX * TY) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    F1_FENCE();
+    // ---- the instruction stream: gather + scatter of up to 64 grid points at a time.
+    // (Tried and dropped: the stream software-pipelined - instruction i + 1 decoded and its gather issued
+    // between the two read-add-write groups of instruction i, the entry of i + 2 requested from the ring: a
+    // wave's chain per instruction is then two LDS round trips instead of five, and the kernel is SLOWER,
+    // 47.1 / 49.3 us against 44.4 / 47.3 (config 2, hot / cold operands): the carried state costs ~15 more
+    // instructions per stream instruction, and issue slots - not a wave's latency chain - are what four waves
+    // per SIMD run out of: 3.6e7 issues per launch x 2.1 clocks = 31 us of the kernel's 45.)
+    const float xb = (float)(x0 - 1), yb = (float)(y0 - 1), zb = (float)(z0 - 1);
+    int loaded_hi = 64;  // entries of this tile requested so far (the ring holds the last 64 of them)
+    bool pending = false;
+    auto one = [&](int i, auto big_tag) {
+      constexpr bool BIG = decltype(big_tag)::value;
       const unsigned mlo = (unsigned)__builtin_amdgcn_readlane(hlo_v, i), mhi = (unsigned)__builtin_amdgcn_readlane(hhi_v, i);
       const int fe = __builtin_amdgcn_readlane(hfe_v, i);
-      return fe + (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-    };
-    uint4 d = make_uint4(0u, 0u, 0u, kF1KBias);
-    if (ninstr > 0) d = E[entry_of(0)];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the window (staged one tile ahead) and the first entry
-    F1_FENCE();
-    // ---- the instruction stream: gather + scatter of up to 64 grid points at a time ----
-    const float xb = (float)(x0 - 1), yb = (float)(y0 - 1), zb = (float)(z0 - 1);
-    for (int i = 0; i < ninstr; ++i) {
-      const uint4 dn = E[entry_of(min(i + 1, ninstr - 1))];
+      // (tiles with more than 64 segments: once the stream has moved into the younger chunk the older one
+      // is refilled - 32 entries, lanes 0 .. 31 - and waited for when an instruction first reaches past
+      // what has landed)
+      if (BIG) {
+        const int fe_next = fe + __popc(mlo) + __popc(mhi) + 1;
+        if (pending && fe_next > loaded_hi - 32) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          pending = false;
+        }
+        if (!pending && fe >= loaded_hi - 32 && loaded_hi < nent) {
+          if (lane < 32)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (__attribute__((address_space(3))) void *)(ring + (loaded_hi & 32)), 16,
+                                                     (off0.x + (unsigned)loaded_hi + (unsigned)lane) * 16u, 0, 0, 0);
+          loaded_hi += 32;
+          pending = true;
+        }
+      }
+      const int sl = fe + (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+      uint4 d = ring[sl & 63];
+      asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));  // (one 16-byte read, not a dword + 12 bytes with a wait between)
       const unsigned pk = d.w;
       const int kb = (int)(pk & kF1KMask) - (int)kF1KBias;
       const unsigned pos = (pk >> 13) & 63u, len = pk >> 19;
@@ -578,18 +636,21 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
       const float lxf = gx - xb, lyf = gy - yb, lzf = gz - zb;
       const float wx1 = __builtin_amdgcn_fractf(lxf), wy1 = __builtin_amdgcn_fractf(lyf),
                   wz1 = __builtin_amdgcn_fractf(lzf);
-      const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
+      const float wz0 = 1.f - wz1;
       const float cf = fmaf(lxf - wx1, (float)XS, fmaf(lyf - wy1, (float)YS, lzf - wz1));
       const int cell = (int)cf;
       if ((unsigned)(lane - (int)pos) < len) {
         const float *w = win + cell;
-        // gather: four z pairs of the window (ds_read2_b32 offsets 0, 1) -> the trilinear sample
+        // gather: four z pairs of the window (ds_read2_b32 offsets 0, 1) -> the trilinear sample (lerps)
         const float p000 = w[0], p001 = w[1], p010 = w[YS], p011 = w[YS + 1];
         const float p100 = w[XS], p101 = w[XS + 1], p110 = w[XS + YS], p111 = w[XS + YS + 1];
-        const float v = (wx0 * wy0) * (wz0 * p000 + wz1 * p001) + (wx0 * wy1) * (wz0 * p010 + wz1 * p011) +
-                        (wx1 * wy0) * (wz0 * p100 + wz1 * p101) + (wx1 * wy1) * (wz0 * p110 + wz1 * p111);
-        const float vx0 = v * wx0, vx1 = v * wx1;
-        const float a00 = vx0 * wy0, a01 = vx0 * wy1, a10 = vx1 * wy0, a11 = vx1 * wy1;
+        const float z00 = fmaf(wz1, p001 - p000, p000), z01 = fmaf(wz1, p011 - p010, p010);
+        const float z10 = fmaf(wz1, p101 - p100, p100), z11 = fmaf(wz1, p111 - p110, p110);
+        const float y0v = fmaf(wy1, z01 - z00, z00), y1v = fmaf(wy1, z11 - z10, z10);
+        const float v = fmaf(wx1, y1v - y0v, y0v);
+        // scatter weights: v wx wy, with 1 - f formed as v - v f (one FMA less per product pair)
+        const float vx1 = v * wx1, vx0 = v - vx1;
+        const float a01 = vx0 * wy1, a00 = vx0 - a01, a11 = vx1 * wy1, a10 = vx1 - a11;
         float *q = acc + cell;
         {
           const float o00 = q[0], o01 = q[YS], o10 = q[XS], o11 = q[XS + YS];
@@ -603,14 +664,19 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
         }
       }
       F1_FENCE();
-      d = dn;
+    };
+    if (nent > 64) {
+      for (int i = 0; i < ninstr; ++i) one(i, std::true_type{});
+    } else {
+      for (int i = 0; i < ninstr; ++i) one(i, std::false_type{});
     }
+    if (pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a refill nobody used: the ring is rewritten below)
     F1_FENCE();
     // ---- epilogue: q = [q +] alpha acc + a0 p + c DtD p ; dot += p q.  Lane gl of a half holds z plane
     // z0 - 1 + gl; half h owns x slabs h HX .. h HX + HX - 1.  p comes from the window (read once into a
     // register window), its z neighbours from the adjacent lanes (DPP wave shifts).  Once the register
-    // window is read the LDS window is dead: the NEXT tile's window is requested right here (LDS-DMA) and
-    // travels while this tile's outputs are formed and stored.
+    // window is read the LDS window is dead: the NEXT tile's window, entries and header are requested right
+    // here (LDS-DMA) and travel while this tile's outputs are formed and stored.
     {
       const int kz = z0 - 1 + gl;
       const bool out_z = gl >= 1 && gl <= ez, lz_ok = kz > 0, hz_ok = kz + 1 < dd.z;
@@ -632,18 +698,33 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       F1_FENCE();
       const int tn = t + slots;
-      int x0n = 0, y0n = 0, z0n = 0;
+      int x0n = 0, y0n = 0, z0n = 0, nentn = 0, ninstrn = 0;
+      uint2 off0n = make_uint2(0u, 0u);
       if (tn < t_hi) {
         origin(tn, x0n, y0n, z0n);
+        off0n = P.tile_off[tn];
+        const uint2 off1n = P.tile_off[tn + 1];
+        nentn = (int)(off1n.x - off0n.x), ninstrn = (int)(off1n.y - off0n.y);
         stage(x0n, y0n, z0n);
-        myh = P.hdr[P.tile_off[tn].y + lane];
+        stage_entries(off0n.x);
+        myh = P.hdr[off0n.y + lane];
       }
-#pragma unroll
-      for (int j = 0; j < (N / 4 + kWave - 1) / kWave; ++j)
-        if (lane + j * kWave < N / 4) reinterpret_cast<float4 *>(acc)[lane + j * kWave] = make_float4(0.f, 0.f, 0.f, 0.f);
+      zero_acc();
       // (per-lane byte offset of (first owned slab, first owned row, own plane): the half's slab goes into the
       // VECTOR offset - a scalar offset that differs between the halves makes every store a waterfall loop)
       const unsigned e1 = (unsigned)xg * sxb + (unsigned)y0 * syb + 4u * (unsigned)kz;
+      float ob[HX][TY], od[HX][TY];
+      if (MODE != 0) {  // the epilogue's loads, all issued before the first is used
+#pragma unroll
+        for (int sa = 1; sa <= HX; ++sa)
+#pragma unroll
+          for (int la = 1; la <= TY; ++la) {
+            const bool ok = out_z && xg + sa - 1 < dd.x && la - 1 < ey;
+            const unsigned so = (unsigned)(sa - 1) * sxb + (unsigned)(la - 1) * syb;
+            ob[sa - 1][la - 1] = P.objb ? buf_load(rb, ok ? e1 : kOob, so) : 0.f;
+            od[sa - 1][la - 1] = P.accumulate ? buf_load(rd, ok ? e1 : kOob, so) : 0.f;
+          }
+      }
 #pragma unroll
       for (int sa = 1; sa <= HX; ++sa) {
         const int x = xg + sa - 1;
@@ -664,17 +745,16 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
           const float zf = (hz_ok ? vzp : 0.f) - c, zbk = lz_ok ? c - vzm : 0.f;
           const float st = P.cx * (xbk - xf) + P.cy * (ybk - yf) + P.cz * (zbk - zf);
           q += P.a0 * c + st;
-          if (P.accumulate) q += buf_load(rd, vo, so);
-          if (P.objb) {
-            const float ob = buf_load(rb, vo, so);
-            if (ok) dot += (double)obj_term(q, ob, c);
+          if (MODE == 2) q += od[sa - 1][la - 1];
+          if (MODE == 1 || (MODE == 2 && P.objb)) {
+            if (ok) dot += (double)obj_term(q, ob[sa - 1][la - 1], c);
           } else {
             buf_store(q, rd, vo, so);  // (lanes that own nothing point out of range: dropped)
             if (ok && P.want_dot) dot += (double)__fmul_rn(c, q);
           }
         }
       }
-      x0 = x0n, y0 = y0n, z0 = z0n;
+      x0 = x0n, y0 = y0n, z0 = z0n, off0 = off0n, nent = nentn, ninstr = ninstrn;
     }
     F1_FENCE();
   }
@@ -698,9 +778,9 @@ int ata1_blocks(Dim3i dd) {
 }
 
 static const void *f1_fn(int tx) {
-  return tx == 8   ? (const void *)k_ata1<8, 4, kF1Waves>
-         : tx == 6 ? (const void *)k_ata1<6, 4, kF1Waves>
-                   : (const void *)k_ata1<4, 4, kF1Waves>;
+  return tx == 8   ? (const void *)k_ata1<8, 4, kF1Waves, 0>
+         : tx == 6 ? (const void *)k_ata1<6, 4, kF1Waves, 0>
+                   : (const void *)k_ata1<4, 4, kF1Waves, 0>;
 }
 
 // workgroups the device holds at once, rounded down to whole rounds over the 8 XCDs
@@ -734,7 +814,7 @@ int launch_ata1(const F1Sched &S, const float *src, const Affine &A, float alpha
   if (ep.p && ep.p != src) return 1;
   if (dd.numel() >= (1ull << 30)) return 1;
   F1Args P;
-  P.src = src, P.desc = S.desc, P.hdr = S.hdr, P.tile_off = S.tile_off, P.tile_org = S.tile_org, P.ntiles = S.ntiles;
+  P.src = src, P.desc = S.desc, P.desc_bytes = S.cap_entries * sizeof(uint4), P.hdr = S.hdr, P.tile_off = S.tile_off, P.tile_org = S.tile_org, P.ntiles = S.ntiles;
   P.A = A, P.alpha = alpha;
   P.a0 = ep.p ? ep.a0 : 0.f, P.cx = ep.p ? ep.cx : 0.f, P.cy = ep.p ? ep.cy : 0.f, P.cz = ep.p ? ep.cz : 0.f;
   P.dst = dst, P.dd = dd, P.accumulate = ep.accumulate, P.partials = ep.partials, P.objb = ep.partials ? ep.objb : nullptr;
@@ -748,12 +828,23 @@ int launch_ata1(const F1Sched &S, const float *src, const Affine &A, float alpha
   static const int prio_rot = getenv("UNIRES_F1_PRIO") ? atoi(getenv("UNIRES_F1_PRIO")) : 1;
   P.prio_rot = prio_rot;
   P.active = f1_active(tx, (int)grid.x);
+  const int mode = P.accumulate ? 2 : (P.objb ? 1 : 0);
+#define F1_LAUNCH(TX_)                                                                                   \
+  do {                                                                                                   \
+    if (mode == 0)                                                                                       \
+      hipLaunchKernelGGL((k_ata1<TX_, 4, kF1Waves, 0>), grid, block, 0, st, P, done);                    \
+    else if (mode == 1)                                                                                  \
+      hipLaunchKernelGGL((k_ata1<TX_, 4, kF1Waves, 1>), grid, block, 0, st, P, done);                    \
+    else                                                                                                 \
+      hipLaunchKernelGGL((k_ata1<TX_, 4, kF1Waves, 2>), grid, block, 0, st, P, done);                    \
+  } while (0)
   if (tx == 8)
-    hipLaunchKernelGGL((k_ata1<8, 4, kF1Waves>), grid, block, 0, st, P, done);
+    F1_LAUNCH(8);
   else if (tx == 6)
-    hipLaunchKernelGGL((k_ata1<6, 4, kF1Waves>), grid, block, 0, st, P, done);
+    F1_LAUNCH(6);
   else
-    hipLaunchKernelGGL((k_ata1<4, 4, kF1Waves>), grid, block, 0, st, P, done);
+    F1_LAUNCH(4);
+#undef F1_LAUNCH
   return 0;
 }
 
