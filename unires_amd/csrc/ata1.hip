@@ -30,6 +30,14 @@
 namespace unires {
 
 #define F1_FENCE() asm volatile("" ::: "memory")
+// phase-ablation switches: compiled in only with -DUNIRES_ABLATE (then UNIRES_F1_DBG selects bits: 1 no
+// instruction stream, 2 no epilogue arithmetic / stores, 4 no window staging, 8 no LDS updates, 16 no gather);
+// product builds carry none of it
+#ifdef UNIRES_ABLATE
+#define F1_ABL(bit) ((P.dbg & (bit)) != 0)
+#else
+#define F1_ABL(bit) (false)
+#endif
 
 constexpr int kF1Waves = 4;  // waves (= independent tiles in flight) per workgroup
 constexpr int kF1TZ = 30, kF1SZ = 32;
@@ -354,7 +362,7 @@ int ata1_build(F1Sched &S, const Affine &A, const Affine &Ainv, Dim3i gd, Dim3i 
   // Processing order, as the splat's (splat2_build): contiguous runs of tiles per XCD with equal COST (a
   // tile costs its instructions + a constant for staging and epilogue); inside a run the tiles with (next
   // to) no instructions go last, emptiest at the very end.
-  constexpr double kTileCost = 5.0;
+  static const double kTileCost = getenv("UNIRES_F1_TILE_COST") ? atof(getenv("UNIRES_F1_TILE_COST")) : 5.0;
   std::vector<int> geom((size_t)nt + 1);
   {
     double total = 0.0;
@@ -462,6 +470,7 @@ struct F1Args {
   int xlo[9];
   int active;
   int prio_rot;
+  int dbg;  // UNIRES_F1_DBG ablation bits (read only by -DUNIRES_ABLATE builds)
 };
 
 // MODE 0: dst = q (+ dot p q if asked); 1: objective mode (partials = sum (q - 2 objb) p, q not stored);
@@ -510,6 +519,7 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
   // outside the volume come from an out-of-range buffer offset: zeros, which is the reference's zero bound for
   // the gather AND what the stencil's forward differences want at the volume's far faces.
   auto stage = [&](int x0, int y0, int z0) {
+    if (F1_ABL(4)) return;
     const int kz = z0 - 1 + gl;
     const bool zok = (unsigned)kz < (unsigned)dd.z;
     unsigned voff[SY / 2];
@@ -640,7 +650,7 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
       const float cf = fmaf(lxf - wx1, (float)XS, fmaf(lyf - wy1, (float)YS, lzf - wz1));
       const int cell = (int)cf;
       if ((unsigned)(lane - (int)pos) < len) {
-        const float *w = win + cell;
+        const float *w = win + (F1_ABL(16) ? 0 : cell);
         // gather: four z pairs of the window (ds_read2_b32 offsets 0, 1) -> the trilinear sample (lerps)
         const float p000 = w[0], p001 = w[1], p010 = w[YS], p011 = w[YS + 1];
         const float p100 = w[XS], p101 = w[XS + 1], p110 = w[XS + YS], p111 = w[XS + YS + 1];
@@ -652,6 +662,9 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
         const float vx1 = v * wx1, vx0 = v - vx1;
         const float a01 = vx0 * wy1, a00 = vx0 - a01, a11 = vx1 * wy1, a10 = vx1 - a11;
         float *q = acc + cell;
+        if (F1_ABL(8)) {
+          if (a00 + a01 + a10 + a11 == 123.f) q[0] = 1.f;
+        } else {
         {
           const float o00 = q[0], o01 = q[YS], o10 = q[XS], o11 = q[XS + YS];
           q[0] = o00 + a00 * wz0, q[YS] = o01 + a01 * wz0, q[XS] = o10 + a10 * wz0, q[XS + YS] = o11 + a11 * wz0;
@@ -662,10 +675,12 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
           q[1] = o00 + a00 * wz1, q[YS + 1] = o01 + a01 * wz1, q[XS + 1] = o10 + a10 * wz1,
           q[XS + YS + 1] = o11 + a11 * wz1;
         }
+        }
       }
       F1_FENCE();
     };
-    if (nent > 64) {
+    if (F1_ABL(1)) {
+    } else if (nent > 64) {
       for (int i = 0; i < ninstr; ++i) one(i, std::true_type{});
     } else {
       for (int i = 0; i < ninstr; ++i) one(i, std::false_type{});
@@ -710,6 +725,11 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
         myh = P.hdr[off0n.y + lane];
       }
       zero_acc();
+      if (F1_ABL(2)) {
+        if (pv[1][1] + av[0][0] == 123.f) dst[0] = 1.f;
+        x0 = x0n, y0 = y0n, z0 = z0n, off0 = off0n, nent = nentn, ninstr = ninstrn;
+        continue;
+      }
       // (per-lane byte offset of (first owned slab, first owned row, own plane): the half's slab goes into the
       // VECTOR offset - a scalar offset that differs between the halves makes every store a waterfall loop)
       const unsigned e1 = (unsigned)xg * sxb + (unsigned)y0 * syb + 4u * (unsigned)kz;
@@ -827,6 +847,8 @@ int launch_ata1(const F1Sched &S, const float *src, const Affine &A, float alpha
   }
   static const int prio_rot = getenv("UNIRES_F1_PRIO") ? atoi(getenv("UNIRES_F1_PRIO")) : 1;
   P.prio_rot = prio_rot;
+  static const int dbg = getenv("UNIRES_F1_DBG") ? atoi(getenv("UNIRES_F1_DBG")) : 0;
+  P.dbg = dbg;
   P.active = f1_active(tx, (int)grid.x);
   const int mode = P.accumulate ? 2 : (P.objb ? 1 : 0);
 #define F1_LAUNCH(TX_)                                                                                   \
