@@ -385,7 +385,8 @@ def cpu_baseline(wl, seconds_budget=25.0, device=None):
     reported next to the timing (gate 1e-4)."""
     from oracle import nitorch_restated as N
     dim_y = wl['dim_y']
-    all_threads = torch.get_num_threads()
+    keep_threads = torch.get_num_threads()  # (batch.init_from_env caps the rank's threads: the baseline gets the host)
+    all_threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     # ---- thread scan on the half-size problem (a fraction of a second per point) ----
     small = tuple(max(16, d // 2) for d in dim_y)
     Ps = oracle_channel(wl, small, seed=1)
@@ -400,7 +401,7 @@ def cpu_baseline(wl, seconds_budget=25.0, device=None):
             lhs_s(Ps['b'])
             scan[nt] = time.perf_counter() - t0
     finally:
-        torch.set_num_threads(all_threads)
+        torch.set_num_threads(keep_threads)
     best = min(scan, key=scan.get)
     # ---- the bounded full-size sample at the fastest thread count ----
     P = oracle_channel(wl, dim_y)
@@ -416,7 +417,7 @@ def cpu_baseline(wl, seconds_budget=25.0, device=None):
         N.cg(lhs, P['b'], P['yc'].dat, max_iter=n_it, tolerance=0, stop='max_gain')
         dt = time.perf_counter() - t0
     finally:
-        torch.set_num_threads(all_threads)
+        torch.set_num_threads(keep_threads)
     nvox = dim_y[0] * dim_y[1] * dim_y[2]
     # cg(tolerance=0) does n_it + 1 matvecs for n_it iterations; report iterations/s
     out = dict(value=n_it / dt, unit='cg_iters/s', cores=best, kind='port', cpu_model=host_cpu_model(),

@@ -163,8 +163,8 @@ int64_t unires_plan_workspace_bytes(const unires_plan_t *plan);
  * voxel axes so that sagittal / coronal / reflected storage takes the same kernels as axial).
  * info[0..2] = caller's voxel axis behind canonical axis 0..2, info[3] = bit j set where canonical axis
  * j is reversed, info[4] = 1 if the LDS-window pull serves it, info[5] = 0 if the schedule-driven
- * splat does not serve it, else 2 + its conv_up axis (1: grid-space source, 2..4: along x / y / z, 5: all), info[6] = 1 if the translation-only one-kernel
- * matvec serves it, info[7] = 1 if the convolutions run as separable passes. */
+ * splat does not serve it, else 2 + its conv_up axis (1: grid-space source, 2..4: along x / y / z, 5: all), info[6] bit 0 = the translation-only one-kernel
+ * matvec serves it, bit 1 = the single-pass AtA kernel of the denoising regime does (ata1.hip), info[7] = 1 if the convolutions run as separable passes. */
 int unires_plan_repeat_info(const unires_plan_t *plan, int32_t n, int32_t info[8]);
 /* The relabelling a plan applies to an operator with grid -> output affine M (host arithmetic only, no device
  * call): perm[j] = caller's voxel axis behind canonical axis j, flip[j] = 1 where it is reversed, chosen so that

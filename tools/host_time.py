@@ -14,12 +14,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import unires_amd as U
 dev = torch.device('cuda:0')
+host = None
+if os.environ.get('LOCAL_WORLD_SIZE'):  # one of several ranks on this host (tools/host_contention.py): take a share of it
+    from unires_amd._host import configure_host
+    host = configure_host(int(os.environ.get('LOCAL_RANK', '0')), int(os.environ['LOCAL_WORLD_SIZE']),
+                          gpu_numa=os.environ.get('GPU_NUMA', '1') != '0')
 name = os.environ.get('WL', 'cfg3_256c3_thick6z')
 x, y, z, w, rho, sett = bench.build_subject(bench.WORKLOADS[name], dev, seed=1234)
 tmp = torch.zeros_like(y[0].dat)
 sett.tolerance = 1e-4
 n = 20
-out = {'workload': name, 'host_cores': os.cpu_count()}
+out = {'workload': name, 'host_cores': os.cpu_count(), 'host_config': host, 'host_pace': int(os.environ.get('PACE', '2'))}
+sett.host_pace = int(os.environ.get('PACE', '2'))
 for tol in (0.0, 1e-3):
     sett.cgs_tol = tol
     obj = torch.zeros((n + 4, 3), dtype=torch.float64, device=dev)

@@ -103,12 +103,14 @@ class ChannelPlan:
 
     def repeat_info(self, n):
         """Which kernels repeat n runs on and how its voxel axes were relabelled
-        (``unires_plan_repeat_info``): dict(perm, flip, pull2, splat2_axis, shift, separable)."""
+        (``unires_plan_repeat_info``): dict(perm, flip, pull2, splat2_axis, shift, separable, fused);
+        ``fused``: the single-pass AtA kernel (denoising regime, ata1.hip) serves the CG matvec."""
         info = (C.c_int32 * 8)()
         check(self.lib.unires_plan_repeat_info(self._h, int(n), info))
         v = list(info)
         return dict(perm=tuple(v[:3]), flip=tuple((v[3] >> j) & 1 for j in range(3)), pull2=bool(v[4]),
-                    splat2_axis=None if v[5] == 0 else v[5] - 2, shift=bool(v[6]), separable=bool(v[7]))
+                    splat2_axis=None if v[5] == 0 else v[5] - 2, shift=bool(v[6] & 1), separable=bool(v[7]),
+                    fused=bool(v[6] & 2))
 
     @on_device
     def time_matvecs(self, on=True):
@@ -253,12 +255,23 @@ class ChannelPlan:
             check(self.lib.unires_cg_solve(self._h, float(rho), float(lam), _ptr(b), _ptr(x),
                                            int(max_iter), float(tolerance), mode, pm, C.byref(it),
                                            obj, _stream()))
-            trace = list(obj)[:it.value + 1] if tolerance else None
+            trace = _trace(list(obj), it.value) if tolerance else None
             return it.value, trace
         check(self.lib.unires_cg_solve(self._h, float(rho), float(lam), _ptr(b), _ptr(x),
                                        int(max_iter), float(tolerance), mode, pm, None, None,
                                        _stream()))
         return None
+
+
+def _trace(ring, it):
+    """Objective trace of a solve that realised ``it`` iterations from the library's ring of ``len(ring)``
+    slots (iteration k lives in slot k mod len): all it + 1 values while they fit, else the LAST len(ring) of
+    them, oldest first (budgets beyond 4 096 iterations, `optim.cg(max_iter=None)`)."""
+    n = len(ring)
+    if it < n:
+        return ring[:it + 1]
+    start = (it + 1) % n
+    return ring[start:] + ring[:start]
 
 
 def cg_many(plans, bs, xs, rho, lams, streams, max_iter=20, tolerance=1e-3, stop='max_gain', precond='none',
@@ -289,4 +302,4 @@ def cg_many(plans, bs, xs, rho, lams, streams, max_iter=20, tolerance=1e-3, stop
             _lib.PRECOND[precond], it, obj, (C.c_void_p * n)(*[st.cuda_stream for st in streams])))
     if not sync:
         return None
-    return [(it[c], list(obj[c * nobj:c * nobj + it[c] + 1]) if tolerance else None) for c in range(n)]
+    return [(it[c], _trace(list(obj[c * nobj:(c + 1) * nobj]), it[c]) if tolerance else None) for c in range(n)]

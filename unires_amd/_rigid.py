@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib, _ops
+from ._host import light_host
 from ._lib import check, i3
 from ._ops import _ptr, _stream, on_device
 from ._project import _apply_scaling, _proj_info, _taps
@@ -143,6 +144,7 @@ def _ctc(po, dim, device):
 
 
 @on_device
+@light_host
 def _update_rigid_channel(xc, yc, sett, max_niter_gn=1, num_linesearch=4, verbose=0, samp=3, c=1):
     """Updates the rigid parameters of all images of one channel (unires/_update.py:541-710)."""
     lib = _lib.load()
@@ -209,6 +211,7 @@ def _update_rigid_channel(xc, yc, sett, max_niter_gn=1, num_linesearch=4, verbos
 
 
 @on_device
+@light_host
 def _update_rigid(x, y, sett, mean_correct=True, max_niter_gn=1, num_linesearch=4, verbose=0, samp=3):
     """Updates each input image's registration parameters x[c][n].rigid_q by Gauss-Newton and
     refreshes x[c][n].po.rigid (unires/_update.py:198-266).  Returns (x, sll)."""

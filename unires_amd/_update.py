@@ -7,9 +7,13 @@ import torch
 from . import _lib
 from ._lib import check, f3, i3
 from ._ops import _ptr, _stream, on_device
+from ._host import Pacer
 from ._plan import cg_many
 from ._project import _channel_plan, _proj
 from .spatial import voxel_size
+
+
+_PACERS = {}
 
 
 def _admm_aux(y, sett):
@@ -257,4 +261,14 @@ def _update_admm(x, y, z, w, rho, tmp, obj, n_iter, sett, info=None):
     if obj is not None and sett.tolerance > 0:
         obj[n_iter, 0], obj[n_iter, 1], obj[n_iter, 2] = _compute_nll(x, y, sett, rho)
     z, w, tmp = _update_zw(y, z, w, rho, tmp, sett)
+    # An iteration is enqueue-only (no read-back): a host loop would run ahead until the hardware queue is
+    # full and then spin inside every launch call.  The pacer parks the thread - blocking-sync events -
+    # until the device is at most `host_pace` iterations behind (settings.host_pace; 0: off).
+    depth = int(getattr(sett, 'host_pace', 2) or 0)
+    if depth > 0 and y[0].dat.is_cuda:
+        key = (y[0].dat.device.index, depth)
+        pacer = _PACERS.get(key)
+        if pacer is None:
+            pacer = _PACERS[key] = Pacer(depth)
+        pacer.step()
     return y, z, w, tmp, obj

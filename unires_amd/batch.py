@@ -14,6 +14,10 @@ import time
 import torch
 import torch.distributed as dist
 
+from ._host import configure_host
+
+host_config = None  # what init_from_env applied: dict(threads, cpus)
+
 
 def partition(n_subjects, world_size, rank):
     """Indices of the subjects rank ``rank`` reconstructs (round-robin)."""
@@ -24,10 +28,16 @@ def partition(n_subjects, world_size, rank):
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun style).
-    Returns (rank, world_size, local_rank).  world_size 1 needs no process group."""
+    Returns (rank, world_size, local_rank).  world_size 1 needs no process group.
+
+    Also gives the rank its share of the host (``_host.configure_host``): torch intra-op threads capped at
+    cores / local world size (<= 8), the process pinned to a core set of its own - NUMA-local to its GPU
+    where sysfs says which node that is.  LOCAL_WORLD_SIZE (torchrun) counts the ranks of this host."""
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    global host_config
+    host_config = configure_host(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')

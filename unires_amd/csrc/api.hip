@@ -350,6 +350,13 @@ struct unires_plan {
   float prec_rho = 0.f, prec_lam = 0.f;
   int prec_mode = UNIRES_PRECOND_IDENTITY;
   bool prec_ready = false;
+  // the last launch that reads this plan's tables: unires_plan_set_repeat / the graph teardown wait for THIS
+  // event instead of the whole device (other channels' streams keep running).  A launch enqueued while its
+  // stream was being captured cannot be waited for through an event: `captured_use` sends those to the
+  // device-wide wait.
+  hipEvent_t last_use = nullptr;
+  std::vector<hipStream_t> use_streams;
+  bool captured_use = false;
 };
 
 // Drop the captured CG solve.  A launch of it may still be in flight (the ADMM loop never syncs):
@@ -359,9 +366,66 @@ static void drop_timing(unires_plan *pl) {
   pl->tev.clear();
 }
 
+// note / await the plan's last use (see unires_plan::last_use).  Noting is free - the stream is remembered, no
+// event is recorded per call (an event per entry point kept a second host thread busy: host_share 1.04 -> 2.0 in
+// tools/host_time.py); the event is recorded on the remembered streams when somebody has to wait, and waited for
+// between sleeps (hipEventSynchronize polls flat out unless the process set hipDeviceScheduleBlockingSync before
+// its context existed, tools/wait_probe.py).
+static void mark_use(unires_plan *pl, hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    cs = hipStreamCaptureStatusNone;
+  }
+  if (cs != hipStreamCaptureStatusNone) {
+    pl->captured_use = true;
+    return;
+  }
+  for (hipStream_t s : pl->use_streams)
+    if (s == st) return;
+  if (pl->use_streams.size() >= 8)
+    pl->captured_use = true;  // (more streams than anybody uses: fall back to the device-wide wait)
+  else
+    pl->use_streams.push_back(st);
+}
+static void await_use(unires_plan *pl) {
+  static const bool device_wide = getenv("UNIRES_SET_REPEAT_DEVICE_SYNC") != nullptr;  // (measurement: the r4 behaviour)
+  if (pl->captured_use || device_wide) {
+    (void)hipDeviceSynchronize();
+    pl->captured_use = false;
+    pl->use_streams.clear();
+    return;
+  }
+  if (pl->use_streams.empty()) return;
+  if (!pl->last_use && hipEventCreateWithFlags(&pl->last_use, hipEventDisableTiming) != hipSuccess) {
+    pl->last_use = nullptr;
+    (void)hipDeviceSynchronize();
+    pl->use_streams.clear();
+    return;
+  }
+  for (hipStream_t s : pl->use_streams) {
+    if (hipEventRecord(pl->last_use, s) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+      break;
+    }
+    unsigned spins = 0;
+    for (;;) {
+      const hipError_t q = hipEventQuery(pl->last_use);
+      if (q != hipErrorNotReady) break;
+      if (++spins > 4096) {  // (the usual wait is a kernel or two: spin that long, then sleep)
+        const struct timespec nap = {0, 50000};
+        (void)nanosleep(&nap, nullptr);
+      }
+    }
+    (void)hipGetLastError();
+  }
+  pl->use_streams.clear();
+}
+
 static void drop_cg_chunk_graphs(unires_plan *pl) {
   if (!pl->cg_start_exec && !pl->cg_chunk_exec) return;
-  (void)hipDeviceSynchronize();
+  await_use(pl);
   if (pl->cg_start_exec) (void)hipGraphExecDestroy(pl->cg_start_exec);
   if (pl->cg_chunk_exec) (void)hipGraphExecDestroy(pl->cg_chunk_exec);
   pl->cg_start_exec = pl->cg_chunk_exec = nullptr;
@@ -370,7 +434,7 @@ static void drop_cg_chunk_graphs(unires_plan *pl) {
 static void drop_cg_graph(unires_plan *pl) {
   drop_cg_chunk_graphs(pl);
   if (!pl->cg_exec) return;
-  (void)hipDeviceSynchronize();
+  await_use(pl);
   (void)hipGraphExecDestroy(pl->cg_exec);
   pl->cg_exec = nullptr;
 }
@@ -748,6 +812,7 @@ extern "C" int unires_plan_destroy(unires_plan_t *plan) {
   if (plan->cg_start_exec) (void)hipGraphExecDestroy(plan->cg_start_exec);
   if (plan->cg_chunk_exec) (void)hipGraphExecDestroy(plan->cg_chunk_exec);
   if (plan->progress) (void)hipHostFree(plan->progress);
+  if (plan->last_use) (void)hipEventDestroy(plan->last_use);
   drop_timing(plan);
   fftpre_destroy(plan->fft);
   for (Repeat &R : plan->reps) free_ztabs(R), free_sched(R);
@@ -790,8 +855,9 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
     return fail(UNIRES_ERR_DIM, "new repeat needs the separable-conv scratch the plan was built without");
   // The tables rebuilt below (pull records, splat schedule, conv tables) are rewritten by kernels on
   // the NULL stream and synchronous copies; work queued on the caller's - possibly non-blocking -
-  // streams may still be reading them: wait for the device first.
-  (void)hipDeviceSynchronize();
+  // streams may still be reading them: wait for the plan's last launch (an event every entry point
+  // records - not the whole device: the other channels' streams keep running).
+  await_use(plan);
   drop_cg_graph(plan);  // the captured solve has the old operator baked in
   plan->prec_ready = false;  // a preconditioner built for the old operator is stale
   {
@@ -1111,6 +1177,7 @@ extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, con
       push_any(plan, src, R, 1.f, PushEpilogue(), out, nullptr, st);
     }
   }
+  mark_use(plan, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -1191,6 +1258,7 @@ extern "C" int unires_ata_matvec(unires_plan_t *plan, float rho, float lam, cons
   hipStream_t st = (hipStream_t)stream;
   const int g = matvec(plan, rho, lam, p, q, dot_dev ? plan->part0 : nullptr, nullptr, st);
   if (dot_dev) launch_sum_to(plan->part0, g, dot_dev, st);
+  mark_use(plan, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -1261,6 +1329,7 @@ extern "C" int unires_precond_build(unires_plan_t *plan, int32_t precond_mode, f
   }
   if (m_out)
     HIP_TRY(hipMemcpyAsync(m_out, plan->precM, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
+  mark_use(plan, st);
   CHECK_LAUNCH();
   plan->prec_rho = rho, plan->prec_lam = lam, plan->prec_mode = precond_mode, plan->prec_ready = true;
   return UNIRES_OK;
@@ -1278,6 +1347,7 @@ extern "C" int unires_precond_apply(unires_plan_t *plan, const float *in, float 
   } else {
     launch_div(in, plan->precM, out, ny, st);
   }
+  mark_use(plan, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -1294,6 +1364,7 @@ extern "C" int unires_rhs_assemble(unires_plan_t *plan, const float *const *x_pt
   // b += tau_n At_n x_n         (unires/_update.py:125-128)
   for (size_t n = 0; n < plan->reps.size(); ++n)
     at_accumulate(plan, plan->reps[n], x_ptrs[n], b, plan->reps[n].tau, true, st);
+  mark_use(plan, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -1309,6 +1380,7 @@ extern "C" int unires_atx_assemble(unires_plan_t *plan, const float *const *x_pt
   for (size_t n = 0; n < plan->reps.size(); ++n)
     at_accumulate(plan, plan->reps[n], x_ptrs[n], atx, plan->reps[n].tau,
                   n > 0 || plan->regime == UNIRES_REGIME_IDENTITY, st);
+  mark_use(plan, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -1450,6 +1522,17 @@ struct CgRun {
   bool use_graph = false;
 };
 
+// The host counts the solves it starts (cg_gen), k_sc_init counts the ones that run (state->gen); the chunked
+// driver matches the two in the progress word.  After an enqueue / capture / launch that FAILED somewhere
+// between the two increments they may be out of step for the life of the plan: read the device's back.
+static void cg_resync_gen(unires_plan *pl) {
+  (void)hipDeviceSynchronize();
+  (void)hipGetLastError();
+  unsigned g = pl->cg_gen;
+  if (pl->state && hipMemcpy(&g, &pl->state->gen, sizeof(g), hipMemcpyDeviceToHost) == hipSuccess) pl->cg_gen = g;
+  (void)hipGetLastError();
+}
+
 static int cg_chunk_size() {
   static const int k = [] {
     const char *e = getenv("UNIRES_CG_CHUNK");
@@ -1497,7 +1580,7 @@ static int cg_run_enqueue_chunk(CgRun &R) {
   return UNIRES_OK;
 }
 
-static int cg_run_start(CgRun &R) {
+static int cg_run_start_impl(CgRun &R) {
   unires_plan *pl = R.pl;
   if (!pl->progress) {
     HIP_TRY(hipHostMalloc((void **)&pl->progress, 64, hipHostMallocMapped));
@@ -1543,6 +1626,12 @@ static int cg_run_start(CgRun &R) {
   return UNIRES_OK;
 }
 
+static int cg_run_start(CgRun &R) {
+  const int rc = cg_run_start_impl(R);
+  if (rc) cg_resync_gen(R.pl);
+  return rc;
+}
+
 // One look at the progress word (never blocks): enqueues the next chunk when the older chunk in flight is
 // through and the solve has not converged.
 static int cg_run_poll(CgRun &R) {
@@ -1578,7 +1667,7 @@ static int cg_runs_drive(std::vector<CgRun> &runs) {
     // a chunk is hundreds of microseconds of device work and one more is queued behind it: after a short spin
     // the thread sleeps between looks (eight ranks on one host must not each burn a core on the wait)
     if (++spins > 256) {
-      const struct timespec nap = {0, 20000};
+      const struct timespec nap = {0, 50000};
       (void)nanosleep(&nap, nullptr);
     }
     if ((spins & 0x3ff) == 0 || (spins > 256 && (spins & 0xf) == 0)) {
@@ -1626,6 +1715,15 @@ static bool cg_graphs_on() {
 }
 
 // chunked enqueue: solves that can stop early, unless switched off (UNIRES_CG_CHUNK=0: the full enqueue)
+static bool stream_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return cs != hipStreamCaptureStatusNone;
+}
+
 static bool cg_chunked(double tol, int max_iter) {
   static const bool off = getenv("UNIRES_CG_CHUNK") && atoi(getenv("UNIRES_CG_CHUNK")) == 0;
   return tol != 0.0 && max_iter > 0 && (!off || max_iter > kMaxCgIter);
@@ -1667,10 +1765,14 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
   hipStream_t st = (hipStream_t)stream;
   unires_plan *pl = plan;
 
-  if (cg_chunked(tol, max_iter)) {
+  // (a stream under capture - e.g. the caller's torch.cuda.graph - runs nothing until the graph is launched: the
+  // chunk feeder would wait for progress that never comes.  The whole solve then joins the capture, as in r3;
+  // kernels after convergence return at entry.)
+  if (cg_chunked(tol, max_iter) && !(stream_capturing(st) && max_iter <= kMaxCgIter)) {
     std::vector<CgRun> runs(1, cg_make_run(pl, rho, lam, b, x, max_iter, tol, stop_mode, precond_mode, st));
     if ((rc = cg_run_start(runs[0]))) return rc;
     if ((rc = cg_runs_drive(runs))) return rc;
+    mark_use(pl, st);
     CHECK_LAUNCH();
     return iters_out ? cg_read_back(pl, max_iter, tol, iters_out, obj_trace, st) : UNIRES_OK;
   }
@@ -1689,14 +1791,22 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
     rc = graphable ? capture_graph(st, &pl->cg_exec, [&] {
       return cg_enqueue(pl, rho, lam, b, x, max_iter, tol, stop_mode, M, fft, st);
     }) : -1;
-    if (rc > 0) return rc;
+    if (rc > 0) {
+      cg_resync_gen(pl);
+      return rc;
+    }
     if (rc == 0) {
       pl->cg_key = key;
-      HIP_TRY(hipGraphLaunch(pl->cg_exec, st));
+      if (hipGraphLaunch(pl->cg_exec, st) != hipSuccess) {
+        cg_resync_gen(pl);
+        return fail(UNIRES_ERR_HIP, "hipGraphLaunch failed");
+      }
     } else if ((rc = cg_enqueue(pl, rho, lam, b, x, max_iter, tol, stop_mode, M, fft, st))) {
+      cg_resync_gen(pl);
       return rc;
     }
   }
+  mark_use(pl, st);
   CHECK_LAUNCH();
   return iters_out ? cg_read_back(pl, max_iter, tol, iters_out, obj_trace, st) : UNIRES_OK;
 }
@@ -1715,7 +1825,9 @@ extern "C" int unires_cg_solve_many(int32_t n, unires_plan_t *const *plans, cons
     for (int d = 0; d < c; ++d)
       if (plans[d] == plans[c]) return fail(UNIRES_ERR_ARG, "one plan per solve");
   }
-  if (!cg_chunked(tol, max_iter)) {  // nothing to steer: each solve is enqueued whole
+  bool capturing = false;
+  for (int c = 0; c < n; ++c) capturing = capturing || stream_capturing((hipStream_t)streams[c]);
+  if (!cg_chunked(tol, max_iter) || (capturing && max_iter <= kMaxCgIter)) {  // nothing to steer: each solve is enqueued whole
     for (int c = 0; c < n; ++c) {
       const int rc = unires_cg_solve(plans[c], rho[c], lam[c], b[c], x[c], max_iter, tol, stop_mode, precond_mode,
                                      nullptr, nullptr, streams[c]);
@@ -1732,6 +1844,7 @@ extern "C" int unires_cg_solve_many(int32_t n, unires_plan_t *const *plans, cons
     }
     const int rc = cg_runs_drive(runs);
     if (rc) return rc;
+    for (int c = 0; c < n; ++c) mark_use(plans[c], (hipStream_t)streams[c]);
     CHECK_LAUNCH();
   }
   if (iters_out)

@@ -438,11 +438,18 @@ int ata1_build(F1Sched &S, const Affine &A, const Affine &Ainv, Dim3i gd, Dim3i 
   S.visits = (double)hs[0] / (double)dd.numel();
   // (a grid much finer or coarser than the output cuts every row into crumbs: the pair of kernels does better)
   static const double min_fill = getenv("UNIRES_F1_MIN_FILL") ? atof(getenv("UNIRES_F1_MIN_FILL")) : 0.45;
-  if (verbose)
+  if (verbose) {
+    unsigned emax = 0;
+    for (int i = 0; i < nt; ++i) emax = std::max(emax, cnt2[i].x);
     fprintf(stderr, "[ata1] tile %d x %d x %d: %d tiles, %llu instructions, %llu points (%.2f per output voxel), "
-            "lane fill %.3f, schedule %.1f MB, row_sep %d\n", tx, ty, kF1TZ, nt, hs[1], hs[0], S.visits, S.fill,
-            (re + ri) * 16.0 / 1e6, safe.row_sep);
-  if (hs[1] > 0 && S.fill < min_fill) return 1;
+            "lane fill %.3f, schedule %.1f MB, row_sep %d, max segments per tile %u\n", tx, ty, kF1TZ, nt, hs[1], hs[0],
+            S.visits, S.fill, (re + ri) * 16.0 / 1e6, safe.row_sep, emax);
+  }
+  // (lane = z plane: a volume whose z extent does not fill its layers of tiles cannot fill the lanes whatever the
+  // operator - 33 planes are a full layer and one of 3 planes: judged against what its layers can hold)
+  const int ntz = (dd.z + kF1TZ - 1) / kF1TZ;
+  const double reach = std::min(1.0, (double)(dd.z + ntz) / (double)(ntz * kF1SZ));
+  if (hs[1] > 0 && S.fill < min_fill * reach) return 1;
   S.valid = true;
   return 0;
 }

@@ -401,6 +401,9 @@ __device__ __forceinline__ void record_obj(CgState *st, int k, double obj, doubl
   st->obj_min = fmin(st->obj_min, obj);
   const double gain = (prev - obj) / (st->obj_max - st->obj_min);
   if (fabs(gain) < tol) st->done = 1;  // NaN compares false, like torch
+  // (a non-finite objective never passes that test: nitorch would grind through its whole budget - 10 numel
+  // iterations by default - on NaNs; the device-resident solve stops instead and reports where)
+  if (!isfinite(obj)) st->done = 1;
 }
 
 __global__ void __launch_bounds__(kBlock)

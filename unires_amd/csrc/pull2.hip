@@ -606,7 +606,7 @@ int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd,
   hipLaunchKernelGGL(k_pull2_plan, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, G, (int)nblk, tol, W, H,
                      Q.rec);
   Q.tol = tol;
-  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipStreamSynchronize(nullptr) != hipSuccess) return 1;  // (the plan kernel ran on the NULL stream; other streams are not waited for)
   static const bool verbose = getenv("UNIRES_PULL2_VERBOSE") != nullptr;
   if (verbose) {  // one line per plan: what the workgroups of this operator look like
     std::vector<int> rec((size_t)nblk * kP2Rec);

@@ -40,7 +40,7 @@ def cg(A, b, x=None, precond=None, max_iter=None, tolerance=1e-5, verbose=False,
     if max_iter is None:
         # nitorch: 10 numel.  With a tolerance the solve is enqueued chunk by chunk and takes any budget;
         # without one every iteration would really run, and one captured solve holds 4 096 of them
-        max_iter = 10 * b.numel() if tolerance else 4096
+        max_iter = min(10 * b.numel(), 2 ** 31 - 1) if tolerance else 4096  # (int32 at the C ABI)
     if x is None:
         x = torch.zeros_like(b)
     elif not inplace:

@@ -5,6 +5,7 @@ updates, clean_fov post-processing.  Everything heavy goes through libunires_hip
 import torch
 
 from . import _lib
+from ._host import wait_blocking
 from ._lib import check, i3
 from ._ops import _ptr, _stream, on_device
 from ._rigid import _update_rigid
@@ -72,6 +73,7 @@ def fit(x, y, sett):
             n_done = n_iter + 1
             # one host read-back per ADMM iteration: the convergence logic below is the
             # reference's, on the same float64 objective values
+            wait_blocking(dev)  # (sleep until the iteration is through: `.cpu()` alone polls)
             gain = get_gain(obj[:n_iter + 1, 0].cpu(), monotonicity='decreasing')
             if sett.do_print >= 1:
                 print('{:3d} - Convergence ({} | {} | {} | gain={:0.7f})'.format(

@@ -97,5 +97,8 @@ class settings:
         # translated -5.6 %, thick axis x / y / z +1.6 % - three channels' vectors (800 MB) no longer
         # share the 256 MB Infinity Cache; 384^3 (config 4): +-1 %, Gaussian profile +3 %
         self.channel_streams = 'auto'
+        # ADMM iterations the host may run ahead of its GPU before it sleeps (blocking-sync events; 0: never
+        # waits - the runtime then spins in the launch calls once the hardware queue is full), _host.Pacer
+        self.host_pace = 2
         # build-side knob: keep sum_n tau_n At x_n across ADMM iterations (recomputed on change)
         self.cache_atx = True
