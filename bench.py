@@ -58,6 +58,8 @@ WORKLOADS = {
     # single-channel denoising with A = I (R0), 3-channel 1 mm recon after coregistration (R1)
     'cfg1_181c1_denoise': dict(dim_y=(181, 217, 181), C=1, thick=1, axes=(2,), regime='id'),
     'cfg2_181c3_1mm': dict(dim_y=(181, 217, 181), C=3, thick=1, axes=(2, 2, 2), regime='dn'),
+    # the pull / push operator of config 2 at the headline's size (what the single-pass kernel does at 256^3)
+    'dn_256c3_1mm': dict(dim_y=(256, 256, 256), C=3, thick=1, axes=(2, 2, 2), regime='dn'),
 }
 
 

@@ -343,7 +343,13 @@ def smooth1d(kind, fwhm, gauss_lim=None):
     kind: -1 dirac | 0 rect | 1 tri | 2 gauss.  Support x in [-L, L]:
       rect  L = floor((w+2)/2)     (w=4 -> [0,.125,.25,.25,.25,.125,0])
       tri   L = floor((2w+2)/2)
-      gauss L = floor((4w+2)/2)    -- truncation UNPINNED; override via gauss_lim
+      gauss L = floor((4w+2)/2)    -- truncation UNPINNED; override via gauss_lim.
+            Two recollections of nitorch's `_gauss1` disagree: this one (w = FWHM: 11 taps
+            at ratio 2) and `lim = floor(4 sigma + 1)` with sigma = w / sqrt(8 ln 2) (9 taps at ratio 2).  The
+            two outer taps are ~1e-8 of the sum, so A differs by float32 rounding only; what WOULD differ is
+            `po.smo_ker.shape` / `po.dim_yx` (and `mat_yx`'s offset, which compensates: unires/_project.py:280-285).
+            Kept at 11 until someone runs tests/golden/make_golden_from_reference.py --real-nitorch; every
+            fixture records the kernel it was made with (`po_smo_ker`), so a regenerated set shows the answer.
     Zero end-taps do not change the operator A: the offset compensation in
     unires/_project.py:280-285 makes A invariant to symmetric zero padding.
     """

@@ -29,7 +29,10 @@ def _tri_w_second_antiderivative(t, w):
 
 
 def smooth1d(kind, fwhm, gauss_lim=None):
-    """1-D kernel as a float64 numpy vector. kind: -1 dirac, 0 rect, 1 tri, 2 gauss."""
+    """1-D kernel as a float64 numpy vector. kind: -1 dirac, 0 rect, 1 tri, 2 gauss.
+    (Gaussian support: `floor((4 fwhm + 2) / 2)` unless ``gauss_lim`` says otherwise - the truncation nitorch
+    applies is unpinned here, see oracle/nitorch_restated.py:smooth1d; the taps beyond the narrower candidate
+    are ~1e-8 of the sum.)"""
     w = float(fwhm)
     if kind == -1:
         return np.ones(1)
