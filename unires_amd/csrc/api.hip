@@ -905,7 +905,9 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   for (int d = 0; d < 2; ++d) tmp.xytab_dev[d] = plan->reps[n].xytab_dev[d], tmp.xytab_cap[d] = plan->reps[n].xytab_cap[d];
   plan->reps[n] = tmp;
   rc = upload_ztabs(plan, plan->reps[n]);
+  sched_set_thorough(false);  // (an operator changing under a running reconstruction: the quick schedule builds)
   if (!rc) rc = build_repeat_kernels(plan, plan->reps[n]);
+  sched_set_thorough(true);
   return rc;
 }
 

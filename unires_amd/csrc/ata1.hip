@@ -15,6 +15,7 @@
 // lane, and the two segments of an instruction either come from rows >= row_sep apart or occupy
 // disjoint plane ranges.  The schedule is fixed: results are bit-reproducible.
 #include "ata1.hpp"
+#include "splat2.hpp"
 
 #include <math.h>
 #include <stdio.h>
@@ -76,6 +77,8 @@ struct F1BuildArgs {
   Dim3i gd, dd;
   float tol;
   int row_sep;
+  int pack;  // 1: segments may sit on lanes other than their z plane's (see the packing)
+  int exact;  // 1: close rows are tested point by point instead of being kept apart wholesale
 };
 struct F1Seg {
   short ui, uj, k0;
@@ -189,14 +192,13 @@ __global__ void __launch_bounds__(kWave)
   }
   F1_FENCE();
   __syncthreads();
-  // ---- packing: lane b is instruction b of the tile.  Lane position = z plane inside each 32-lane half, so a
-  // half takes any set of segments whose plane ranges are disjoint (a row that leaves the tile through a side
-  // face and the neighbour that enters there share a half: with one segment per half a rotated subject filled
-  // 0.44 - 0.53 of the lanes, the unrotated one 0.84), and the two halves' segments must not be able to collide
-  // (rows closer than row_sep whose plane ranges intersect).  A segment joins the first instruction that has
-  // room; the segments are offered sorted by first plane, then as 0, h, 1, h + 1, ... (h = half the count): in
-  // scan order a row's successors are its neighbours, the row half the cross-section away comes right behind
-  // its partner (what took the splat's lane fill from 0.75 to 0.84).
+  // ---- packing: lane b is instruction b of the tile; a segment joins the first instruction that has room
+  // for it (below) and none of whose segments it can collide with.  The segments are offered sorted by first
+  // plane, then as 0, h, 1, h + 1, ... (h = half the count): in scan order a row's successors are its
+  // neighbours, the row half the cross-section away comes right behind its partner (what took the splat's
+  // lane fill from 0.75 to 0.84).  Lane fill on config 2 (unrotated / rotated channels): one
+  // segment per 32-lane half 0.84 / 0.44 - 0.51; any plane-disjoint set per half 0.85 / 0.65 - 0.69; close
+  // rows tested point by point instead of kept apart wholesale 0.89 / 0.80 - 0.82.
   __shared__ int cnt[33];
   __shared__ unsigned short member[kWave][kF1MaxSeg];
   if (lane == 0) {
@@ -209,30 +211,67 @@ __global__ void __launch_bounds__(kWave)
   }
   F1_FENCE();
   __syncthreads();
-  unsigned occ0 = 0u, occ1 = 0u;
+  // Lane occupancy of this instruction (64 bits).  A segment is placed, in this order of preference: (1) in the
+  // first EXISTING instruction that has its plane-aligned lanes free (lane = z plane in half 0 or 1: no LDS
+  // bank is asked twice), (2) - B.pack - in the first existing instruction with ANY run of free lanes long
+  // enough (a rotated subject's rows cross a 4-wide tile in ~12 planes, all at different heights: plane-aligned
+  // alone filled 0.65 - 0.69 of the lanes; the misplaced lanes pay a two-way bank conflict on their reads, the
+  // stream has a quarter fewer instructions), (3) aligned in a new instruction.  Always subject to the
+  // collision rule against every segment already there.
+  unsigned long long occ = 0ull;
+  unsigned char start_lane[kF1MaxSeg];
   int nmem = 0, nbins = 0;
   for (int si = 0; si < nseg; ++si) {
     const int s = order[si];
     const F1Seg q = segs[s];
-    const unsigned pm = (q.len >= 32 ? 0xffffffffu : ((1u << q.len) - 1u)) << q.pos;
+    const unsigned long long lm = q.len >= 64 ? ~0ull : ((1ull << q.len) - 1ull);
     bool free = lane <= nbins && nmem < kF1MaxSeg;
-    for (int j = 0; j < nmem; ++j) {
-      const F1Seg m = segs[member[lane][j] & 0x7fff];
+    for (int j = 0; j < nmem && free; ++j) {
+      const F1Seg m = segs[member[lane][j]];
       const bool rows_close = max(abs(m.ui - q.ui), abs(m.uj - q.uj)) < B.row_sep;
-      const bool planes_meet = (int)m.pos <= (int)q.pos + q.len - 1 && (int)q.pos <= (int)m.pos + m.len - 1;
-      free = free && !(rows_close && planes_meet);
+      const int lo = max((int)m.pos, (int)q.pos), hi = min((int)m.pos + m.len, (int)q.pos + q.len) - 1;
+      if (!rows_close || lo > hi) continue;  // far apart whatever the planes, or no plane in common
+      // (adjacent rows - at most one apart in both indices - overlap wherever they share a plane: no need to look)
+      if (!B.exact || max(abs(m.ui - q.ui), abs(m.uj - q.uj)) < 2) {
+        free = false;
+        break;
+      }
+      // ... else exactly: two lanes meet only in the same read-add-write group on the same z plane, i.e. two
+      // points with the same floor plane whose 2 x 2 cell footprints overlap.  Both segments walk one plane per
+      // point, so the points that share plane pl are known; their floor cells are compared, computed with the
+      // kernel's own arithmetic (rows two apart - which the blanket rule, row_sep = 3 for a rotated operator,
+      // keeps out of each other's instructions - almost always pass)
+      const RowBase ra = affine_row(B.A, (float)m.ui, (float)m.uj), rq = affine_row(B.A, (float)q.ui, (float)q.uj);
+      for (int pl = lo; pl <= hi; ++pl) {
+        float ax, ay, az, bx, by, bz;
+        f1_point(B.A, ra.x, ra.y, ra.z, (float)((int)m.k0 + pl - (int)m.pos), ax, ay, az);
+        f1_point(B.A, rq.x, rq.y, rq.z, (float)((int)q.k0 + pl - (int)q.pos), bx, by, bz);
+        if (fabsf(floorf(ax) - floorf(bx)) < 2.f && fabsf(floorf(ay) - floorf(by)) < 2.f) {
+          free = false;
+          break;
+        }
+      }
     }
-    const bool ok0 = free && (occ0 & pm) == 0u, ok1 = free && (occ1 & pm) == 0u;
-    const unsigned long long m = __ballot(ok0 || ok1);
+    const bool ok0 = free && (occ & (lm << q.pos)) == 0ull, ok1 = free && (occ & (lm << (32 + q.pos))) == 0ull;
+    int any = -1;  // first run of free lanes anywhere
+    if (free && B.pack && !(ok0 || ok1) && lane < nbins) {
+      for (int st = 0; st + q.len <= kWave && any < 0; ++st)
+        if ((occ & (lm << st)) == 0ull) any = st;
+    }
+    const unsigned long long m_al = __ballot((ok0 || ok1) && lane < nbins);
+    const unsigned long long m_any = __ballot(any >= 0);
+    const unsigned long long m_new = __ballot((ok0 || ok1) && lane == nbins);
+    const unsigned long long m = m_al ? m_al : (m_any ? m_any : m_new);
     if (m == 0ull) {  // more than 64 instructions in one tile
       if (lane == 0) atomicExch(err, 1);
       break;
     }
     const int chosen = __ffsll((long long)m) - 1;
     if (lane == chosen) {
-      const int half = ok0 ? 0 : 1;
-      member[lane][nmem++] = (unsigned short)(s | (half << 15));
-      if (half == 0) occ0 |= pm; else occ1 |= pm;
+      const int st = (m_al || !m_any) ? (ok0 ? q.pos : 32 + q.pos) : any;
+      member[lane][nmem] = (unsigned short)s;
+      start_lane[nmem++] = (unsigned char)st;
+      occ |= lm << st;
     }
     nbins = max(nbins, chosen + 1);
   }
@@ -254,7 +293,7 @@ __global__ void __launch_bounds__(kWave)
     // members in lane order (insertion sort by first lane)
     int start_of[kF1MaxSeg];
 #pragma unroll
-    for (int j = 0; j < kF1MaxSeg; ++j) start_of[j] = j < nmem ? 32 * (member[lane][j] >> 15) + segs[member[lane][j] & 0x7fff].pos : 1 << 20;
+    for (int j = 0; j < kF1MaxSeg; ++j) start_of[j] = j < nmem ? (int)start_lane[j] : 1 << 20;
     unsigned long long starts = 0ull;
     uint4 *out = desc + base.x + (incl - nent);
     for (int j = 0; j < nmem; ++j) {
@@ -267,7 +306,7 @@ __global__ void __launch_bounds__(kWave)
         for (int b = 0; b < kF1MaxSeg; ++b) rank += (start_of[b] < start_of[a]) ? 1 : 0;
         if (rank == j && a < nmem) pick = a;
       }
-      const F1Seg q = segs[member[lane][pick] & 0x7fff];
+      const F1Seg q = segs[member[lane][pick]];
       const int start = start_of[pick];
       const RowBase rb = affine_row(B.A, (float)q.ui, (float)q.uj);
       uint4 e;
@@ -346,6 +385,10 @@ int ata1_build(F1Sched &S, const Affine &A, const Affine &Ainv, Dim3i gd, Dim3i 
   unsigned long long *stats_dev = S.scratch + 1;
   F1BuildArgs B;
   B.A = A, B.Ainv = Ainv, B.gd = gd, B.dd = dd, B.tol = tol, B.row_sep = safe.row_sep;
+  static const int pack = getenv("UNIRES_F1_PACK") ? atoi(getenv("UNIRES_F1_PACK")) : 1;
+  B.pack = pack;
+  static const int exact = getenv("UNIRES_F1_EXACT") ? atoi(getenv("UNIRES_F1_EXACT")) : -1;  // (-1: as the plan asks)
+  B.exact = exact >= 0 ? exact : (sched_thorough() ? 1 : 0);
   auto run = [&](bool fill, const int *geom) {
     if (tx == 8)
       f1_launch_build<8, 4>(fill, B, nt, S.tile_off, geom, S.desc, S.hdr, err_dev, fill ? stats_dev : nullptr);

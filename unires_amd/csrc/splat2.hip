@@ -97,6 +97,7 @@ struct S2BuildArgs {
   int axis, rows_y;
   const float4 *xtab, *ytab;  // axis 3
   Dim3i xd;
+  int exact;  // close rows tested point by point (aligned schedules) instead of kept apart wholesale
 };
 
 struct S2Seg {
@@ -275,11 +276,32 @@ __global__ void __launch_bounds__(kWave)
     const int a = seg_pos(q);
     const unsigned pm = (q.len >= 32 ? 0xffffffffu : ((1u << q.len) - 1u)) << a;
     bool free = true;
-    for (int j = 0; j < nmem; ++j) {
+    for (int j = 0; j < nmem && free; ++j) {
       const S2Seg m = segs[member[lane][j] & 0x7fff];
       const bool rows_close = max(abs(m.ui - q.ui), abs(m.uj - q.uj)) < B.row_sep;
       const bool planes_touch = (int)m.lzmin <= (int)q.lzmax + 1 && (int)q.lzmin <= (int)m.lzmax + 1;
-      free = free && !(rows_close && planes_touch);
+      if (!(rows_close && planes_touch)) continue;
+      // (adjacent rows - at most one apart in both indices - overlap wherever they share a plane: no need to look)
+      if (!(B.exact && aligned && !zdown) || max(abs(m.ui - q.ui), abs(m.uj - q.uj)) < 2) {
+        free = false;
+        break;
+      }
+      // (r5, as ata1.hip's packing) ... else exactly: two lanes meet only in the same read-add-write group on the
+      // same z plane - two points with the same floor plane whose 2 x 2 cell footprints overlap.  Aligned segments
+      // walk one plane per point, so the points that share plane pl are known: their floor cells are compared, in
+      // the kernel's own arithmetic.  Rows two apart, which the blanket rule (row_sep 3 for a rotated operator)
+      // keeps out of each other's instructions, almost always pass.
+      const int lo = max((int)m.lzmin, (int)q.lzmin), hi = min((int)m.lzmax, (int)q.lzmax);
+      const RowBase ra = affine_row(B.A, (float)m.ui, (float)m.uj), rq = affine_row(B.A, (float)q.ui, (float)q.uj);
+      for (int pl = lo; pl <= hi; ++pl) {
+        float ax, ay, az, bx, by, bz;
+        s2_point(B.A, ra.x, ra.y, ra.z, (float)((int)m.k0 + pl - (int)m.lzmin), ax, ay, az);
+        s2_point(B.A, rq.x, rq.y, rq.z, (float)((int)q.k0 + pl - (int)q.lzmin), bx, by, bz);
+        if (fabsf(floorf(ax) - floorf(bx)) < 2.f && fabsf(floorf(ay) - floorf(by)) < 2.f) {
+          free = false;
+          break;
+        }
+      }
     }
     free = free && lane <= nbins && nmem < kS2MaxSeg;
     bool ok0, ok1;
@@ -371,6 +393,10 @@ __global__ void __launch_bounds__(kWave)
   }
 }
 
+static thread_local bool t_thorough = true;
+void sched_set_thorough(bool on) { t_thorough = on; }
+bool sched_thorough() { return t_thorough; }
+
 void splat2_free(SplatSched &S) {
   if (S.entries) (void)hipFree(S.entries);
   if (S.ext) (void)hipFree(S.ext);
@@ -416,6 +442,8 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
   B.A = A, B.Ainv = Ainv, B.gd = gd, B.dd = dd, B.tol = tol, B.row_sep = safe.row_sep;
   B.axis = axis, B.rows_y = rows_y;
   B.xtab = xtab, B.ytab = ytab, B.xd = xd;
+  static const int exact = getenv("UNIRES_S2_EXACT") ? atoi(getenv("UNIRES_S2_EXACT")) : -1;  // (-1: as the plan asks)
+  B.exact = exact >= 0 ? exact : (sched_thorough() ? 1 : 0);
   hipLaunchKernelGGL(k_splat2_build<false>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off, (const int *)nullptr,
                      (S2Entry *)nullptr, (S2Ext *)nullptr, (ulonglong2 *)nullptr, err_dev,
                      (unsigned long long *)nullptr);

@@ -56,6 +56,13 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
                  const float4 *ytab = nullptr, Dim3i xd = Dim3i{0, 0, 0});
 void splat2_free(SplatSched &S);
 
+// How hard the schedule builders (splat2_build, ata1_build) of the calling thread try: thorough = rows closer than
+// row_sep are tested point by point (a better lane fill, 2 - 4 x the build time); quick = kept apart wholesale.
+// The plan builds thoroughly once (unires_plan_create) and quickly whenever an operator changes under a running
+// reconstruction (unires_plan_set_repeat: every rigid Gauss-Newton step).
+void sched_set_thorough(bool on);
+bool sched_thorough();
+
 int splat2_blocks(Dim3i dd);
 // tab_dev: gn float4 {bits(koff), w0, w1, -} conv_up table along the schedule's axis (nullptr for
 // a direct source); row_stride: elements per source row (axis 2 / -1), per ui (axis 1) or per uj
