@@ -290,8 +290,6 @@ struct Repeat {
   bool hybf = false;
   Taps Tz, Txy;
   Dim3i dim_h;
-  // device tables for the on-the-fly conv_up of k_gather2: [0] no scaling (AtA), [1] S(scl) (At)
-  float *ztab_dev[2] = {nullptr, nullptr};
   // schedule-driven splat (splat2.hip): per-tile segment lists of this operator + conv_up tables
   // along the schedule's axis ([0] no scaling, [1] S(scl)); ctab_n entries, second x-space value
   // ctab_step elements after the first
@@ -549,30 +547,6 @@ static int fill_repeat(const unires_plan *pl, const unires_repeat_t *in, Repeat 
   return UNIRES_OK;
 }
 
-// (re)build the device z tables of a super-resolution repeat
-static int upload_ztabs(unires_plan *pl, Repeat &R) {
-  if (pl->regime != UNIRES_REGIME_SUPERRES) return UNIRES_OK;
-  const int gz = R.dim_gf.z;
-  std::vector<float> host((size_t)gz * 4);
-  for (int v = 0; v < 2; ++v) {
-    if (!R.ztab_dev[v]) {
-      hipError_t e = hipMalloc((void **)&R.ztab_dev[v], host.size() * sizeof(float));
-      if (e != hipSuccess) return fail(UNIRES_ERR_ALLOC, "hipMalloc z table");
-    }
-    gather2_ztab(R.Tf, v ? make_scaling(R.scl, R.dim_thick) : Scaling{1.f, 1.f, -1}, gz,
-                 R.dim_x.z, host.data());
-    hipError_t e = hipMemcpy(R.ztab_dev[v], host.data(), host.size() * sizeof(float),
-                             hipMemcpyHostToDevice);
-    if (e != hipSuccess) return fail(UNIRES_ERR_HIP, "hipMemcpy z table");
-  }
-  return UNIRES_OK;
-}
-
-static void free_ztabs(Repeat &R) {
-  for (int v = 0; v < 2; ++v)
-    if (R.ztab_dev[v]) (void)hipFree(R.ztab_dev[v]), R.ztab_dev[v] = nullptr;
-}
-
 // (re)build the splat schedule of a repeat for its current operator; a non-applicable operator
 // simply leaves the schedule invalid (the general push kernels then run)
 // tables_only: the operator's geometry is unchanged (a new slice scaling only): the conv_up tables are rewritten,
@@ -791,10 +765,10 @@ extern "C" int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3],
     return UNIRES_ERR_HIP;
   }
   for (Repeat &R : pl->reps) {
-    int rc = upload_ztabs(pl, R);
+    int rc = UNIRES_OK;
     if (!rc) rc = build_repeat_kernels(pl, R);
     if (rc) {
-      for (Repeat &Q : pl->reps) free_ztabs(Q), free_sched(Q);
+      for (Repeat &Q : pl->reps) free_sched(Q);
       (void)hipFree(pl->ws);
       delete pl;
       return rc;
@@ -815,7 +789,7 @@ extern "C" int unires_plan_destroy(unires_plan_t *plan) {
   if (plan->last_use) (void)hipEventDestroy(plan->last_use);
   drop_timing(plan);
   fftpre_destroy(plan->fft);
-  for (Repeat &R : plan->reps) free_ztabs(R), free_sched(R);
+  for (Repeat &R : plan->reps) free_sched(R);
   delete plan;
   return UNIRES_OK;
 }
@@ -885,15 +859,11 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
     if (verbose) fprintf(stderr, "[set_repeat] %s (scl %g -> %g)\n", same ? "scaling only" : "full rebuild", (double)old.scl, (double)tmp.scl);
     if (same) {
       old.scl = tmp.scl, old.tau = tmp.tau;
-      rc = upload_ztabs(plan, old);
-      if (!rc) rc = build_sched(plan, old, true);
+      rc = build_sched(plan, old, true);
       if (!rc) build_shift(plan, old);
       return rc;
     }
   }
-  if (tmp.dim_gf.z != plan->reps[n].dim_gf.z) free_ztabs(plan->reps[n]);
-  tmp.ztab_dev[0] = plan->reps[n].ztab_dev[0];
-  tmp.ztab_dev[1] = plan->reps[n].ztab_dev[1];
   // the schedule and conv tables keep their device allocations; contents are rebuilt below
   tmp.sched = plan->reps[n].sched;
   tmp.pplan = plan->reps[n].pplan;
@@ -904,7 +874,7 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   tmp.ctab_cap = plan->reps[n].ctab_cap;
   for (int d = 0; d < 2; ++d) tmp.xytab_dev[d] = plan->reps[n].xytab_dev[d], tmp.xytab_cap[d] = plan->reps[n].xytab_cap[d];
   plan->reps[n] = tmp;
-  rc = upload_ztabs(plan, plan->reps[n]);
+  rc = UNIRES_OK;
   sched_set_thorough(false);  // (an operator changing under a running reconstruction: the quick schedule builds)
   if (!rc) rc = build_repeat_kernels(plan, plan->reps[n]);
   sched_set_thorough(true);
@@ -1047,28 +1017,10 @@ static PushSrc ata_forward(unires_plan *pl, const Repeat &R, const float *in, co
 static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float alpha,
                      const PushEpilogue &ep, float *out, const int *done, hipStream_t st) {
   const Affine &A = src.convup ? R.Af : R.A;
-  // default: owner-computes LDS splat (k_push_tile); UNIRES_PUSH=gather selects the
-  // gather-form kernel (3.6x more instructions, but no LDS tile and any geometry)
-  static const bool use_gather = getenv("UNIRES_PUSH") && !strcmp(getenv("UNIRES_PUSH"), "gather");
-  if (use_gather) {
-    // gather form: conv_up is materialised in grid space first (regime 2)
-    const float *g = src.data;
-    if (src.convup) {
-      launch_conv_up(src.data, src.xd, src.T, src.S, pl->gbuf, src.gd, st);
-      g = pl->gbuf;
-    }
-    if (!launch_push_gather(g, src.gd, A, R.Afinv, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
-      return ep.partials ? push_gather_blocks(pl->dy) : 0;
-  }
+  // default: the schedule-driven splat (k_splat2), then the r1 tile kernels where an operator is outside its
+  // domain; UNIRES_PUSH=tile forces the general tile kernel (tests' cross-check)
   static const char *mode = getenv("UNIRES_PUSH");
   static const bool use_tile = mode && !strcmp(mode, "tile");
-  static const bool use_gather2 = mode && !strcmp(mode, "gather2");
-  // measured on config 3: k_splat 219 us, k_gather2 336 us, k_push_tile 470 us, k_push_gather 1030 us
-  if (use_gather2) {
-    const float4 *zt = src.convup ? (const float4 *)R.ztab_dev[src.S.dim >= 0 ? 1 : 0] : nullptr;
-    if (!launch_gather2(src, zt, A, R.Afinv, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
-      return ep.partials ? gather2_blocks(pl->dy) : 0;
-  }
   if (!use_tile && mode == nullptr && R.hyb && src.convup && R.sched.valid && R.sched.axis == 2 && pl->gbuf2) {
     // conv_up along x / y as 1-D passes, then the z-profile splat with the intermediate as its source
     Taps Txy = src.T;  // (= R.Txy, or with the x part done already: ata_forward)

@@ -689,154 +689,3 @@ int launch_push_tile(const PushSrc &src, const Affine &A, const Affine &Ainv,
 }
 
 }  // namespace unires
-
-// ==========================================================================
-// k_push_gather - the adjoint of the trilinear pull in GATHER form.
-//
-// out[v] = sum over grid voxels u with |g(u) - v|_inf < 1 of
-//          prod_d (1 - |g_d(u) - v_d|) * mask(g(u)) * src[u]
-//
-// which is exactly what the scatter (nitorch grid_push) accumulates into v: v is
-// one of the 8 corners of g(u) iff |g_d(u) - v_d| < 1 for every axis, and the
-// trilinear weight of that corner is prod (1 - |g_d - v_d|).  No atomics, no LDS
-// tile, fixed summation order (bit-reproducible), full occupancy; the price is
-// enumerating candidate sources: grid rows (ui,uj) within +-h of M^-1 v, and per
-// row the 2-3 grid-z positions whose image is within one voxel of v along z.
-// ==========================================================================
-namespace unires {
-
-struct GatherArgs {
-  const float *src;  // grid-space volume
-  Dim3i gd;
-  Affine A, Ainv;
-  float hx, hy, hz;  // half-widths of M^-1 (-1,1)^3 per grid axis
-  int nrx, nry, nrz; // candidates per axis = ceil(2h)
-  int zsolve;        // |dz/dk| large enough to solve the grid-z candidates per row
-  float alpha, tol;
-  const float *p;
-  float a0, cx, cy, cz;
-  float *dst;
-  Dim3i dd;
-  int accumulate;
-  double *partials;
-  const float *objb;
-};
-
-__device__ __forceinline__ float hat(float d) {
-  return __builtin_amdgcn_fmed3f(1.f - fabsf(d), 0.f, 1.f);  // one v_sub_f32 |d| clamp
-}
-
-__global__ void __launch_bounds__(kBlock)
-    k_push_gather(GatherArgs G, const int *__restrict__ done) {
-  if (done && *done) return;
-  const Dim3i dd = G.dd, gd = G.gd;
-  const float *__restrict__ src = G.src;
-  const float *__restrict__ pin = G.p;
-  float *__restrict__ dst = G.dst;
-  const int tz = (dd.z + kWave - 1) / kWave, ty = (dd.y + 3) / 4;
-  const long long ntiles = (long long)tz * ty * dd.x;
-  const float c2 = G.A.m[10];
-  const float inv_c2 = G.zsolve ? 1.f / c2 : 0.f;
-  const float span = G.zsolve ? fabsf(inv_c2) : 0.f;  // grid-z half-width of |dz| < 1
-  double dot = 0.0;
-  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int kc = (int)(t % tz);
-    const long long t2 = t / tz;
-    const int jq = (int)(t2 % ty);
-    const int i = (int)(t2 / ty);
-    const int k = kc * kWave + threadIdx.x;
-    const int j = jq * 4 + threadIdx.y;
-    if (k >= dd.z || j >= dd.y) continue;
-    const float vx = (float)i, vy = (float)j, vz = (float)k;
-    float ux, uy, uz;
-    affine_point(G.Ainv, vx, vy, vz, ux, uy, uz);
-    // first integer strictly above u* - h  (candidates: that one and the next n-1)
-    const int ix0 = (int)floorf(ux - G.hx) + 1, iy0 = (int)floorf(uy - G.hy) + 1;
-    const int iz0 = (int)floorf(uz - G.hz) + 1;
-    const bool edge = i == 0 || j == 0 || k == 0 || i == dd.x - 1 || j == dd.y - 1 || k == dd.z - 1;
-    float acc = 0.f;
-    for (int a = 0; a < G.nrx; ++a) {
-      const int ui = ix0 + a;
-      if (ui < 0 || ui >= gd.x) continue;
-      for (int b = 0; b < G.nry; ++b) {
-        const int uj = iy0 + b;
-        if (uj < 0 || uj >= gd.y) continue;
-        const RowBase rb = affine_row(G.A, (float)ui, (float)uj);
-        const float *row = src + ((size_t)ui * gd.y + uj) * gd.z;
-        int k0, nk;
-        if (G.zsolve) {
-          // |r.z + c2*uk + m11 - vz| < 1  ->  uk in (tc - span, tc + span)
-          const float tc = (vz - (rb.z + G.A.m[11])) * inv_c2;
-          k0 = (int)floorf(tc - span - 1e-3f) + 1;
-          nk = 2 + (int)(span > 1.f) + 1;  // covers the open interval plus rounding slack
-          // cheap row rejection: x,y offsets at the interval centre, widened by their drift
-          float gx, gy, gz;
-          affine_along(G.A, rb, tc, gx, gy, gz);
-          const float slack = 1.f + (span + 1.f) * (fabsf(G.A.m[2]) + fabsf(G.A.m[6]));
-          if (fabsf(gx - vx) >= slack || fabsf(gy - vy) >= slack) continue;
-        } else {
-          k0 = iz0, nk = G.nrz;
-        }
-        for (int m = 0; m < nk; ++m) {
-          const int uk = k0 + m;
-          float gx, gy, gz;
-          affine_along(G.A, rb, (float)uk, gx, gy, gz);
-          float w = hat(gx - vx) * hat(gy - vy) * hat(gz - vz);
-          if (uk < 0 || uk >= gd.z) w = 0.f;
-          if (edge && !in_fov(gx, gy, gz, dd, G.tol)) w = 0.f;
-          acc = fmaf(w, row[min(max(uk, 0), gd.z - 1)], acc);
-        }
-      }
-    }
-    const size_t idx = ((size_t)i * dd.y + j) * dd.z + k;
-    float q = G.alpha * acc;
-    float pc = 0.f;
-    if (pin) {
-      const float st = dtd_at(pin, idx, i, j, k, dd, G.cx, G.cy, G.cz, pc);
-      q += G.a0 * pc + st;
-    }
-    if (G.accumulate) q += dst[idx];
-    matvec_emit(dst, idx, q, pc, G.objb, G.partials != nullptr, dot);
-  }
-  if (G.partials) {
-    const double tot = block_sum(dot);
-    if (threadIdx.x == 0 && threadIdx.y == 0) G.partials[blockIdx.x] = tot;
-  }
-}
-
-int push_gather_blocks(Dim3i dd) {
-  const long long ntiles = (long long)((dd.z + kWave - 1) / kWave) * ((dd.y + 3) / 4) * dd.x;
-  return (int)(ntiles < kMaxPartials ? ntiles : kMaxPartials);
-}
-
-// Returns non-zero (nothing launched) when the candidate box would be unreasonably large.
-int launch_push_gather(const float *src, Dim3i gd, const Affine &A, const Affine &Ainv,
-                       float alpha, float tol, const PushEpilogue &ep, float *dst, Dim3i dd,
-                       const int *done, hipStream_t st) {
-  GatherArgs G;
-  G.src = src;
-  G.gd = gd;
-  G.A = A;
-  G.Ainv = Ainv;
-  float h[3];
-  for (int r = 0; r < 3; ++r)
-    h[r] = fabsf(Ainv.m[4 * r]) + fabsf(Ainv.m[4 * r + 1]) + fabsf(Ainv.m[4 * r + 2]) + 1e-3f;
-  G.hx = h[0], G.hy = h[1], G.hz = h[2];
-  G.nrx = (int)ceilf(2.f * h[0]), G.nry = (int)ceilf(2.f * h[1]), G.nrz = (int)ceilf(2.f * h[2]);
-  if (G.nrx > 8 || G.nry > 8 || G.nrz > 8) return 1;
-  G.zsolve = fabsf(A.m[10]) > 0.5f;
-  G.alpha = alpha;
-  G.tol = tol;
-  G.p = ep.p;
-  G.a0 = ep.a0, G.cx = ep.cx, G.cy = ep.cy, G.cz = ep.cz;
-  G.dst = dst;
-  G.dd = dd;
-  G.accumulate = ep.accumulate;
-  G.partials = ep.partials;
-  G.objb = ep.objb;
-  hipLaunchKernelGGL(k_push_gather, dim3(push_gather_blocks(dd)), dim3(kWave, kBlock / kWave), 0, st,
-                     G, done);
-  return 0;
-}
-
-}  // namespace unires

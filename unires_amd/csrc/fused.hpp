@@ -47,18 +47,4 @@ int launch_splat(const PushSrc &src, const Affine &A, const Affine &Ainv, const 
                  float alpha, float tol, const PushEpilogue &ep, float *dst, Dim3i dd,
                  const int *done, hipStream_t st);
 
-// Register-blocked gather push (gather2.hip) for near-identity operators; `ztab_dev` is the
-// device copy of gather2_ztab() when src is an x-space volume (conv_up along z on the fly).
-int gather2_blocks(Dim3i dd);
-void gather2_ztab(const Taps &T, const Scaling &S, int gz, int xdz, float *out);
-int launch_gather2(const PushSrc &src, const float4 *ztab_dev, const Affine &A, const Affine &Ainv,
-                   float alpha, float tol, const PushEpilogue &ep, float *dst, Dim3i dd,
-                   const int *done, hipStream_t st);
-
-// Gather-form push from a grid-space volume (no atomics, no LDS tile, deterministic).
-int push_gather_blocks(Dim3i dd);
-int launch_push_gather(const float *src, Dim3i gd, const Affine &A, const Affine &Ainv,
-                       float alpha, float tol, const PushEpilogue &ep, float *dst, Dim3i dd,
-                       const int *done, hipStream_t st);
-
 }  // namespace unires
