@@ -267,3 +267,29 @@ def test_orientation_relabelling_of_every_signed_permutation(lib):
                 assert all(p_out[perm[a]] == a and f_out[perm[a]] == flip[a] for a in range(3))
     bad = _lib.c_f32x12(*([float('nan')] * 12))
     assert lib.unires_orient_of(bad, _lib.c_i32x3(), _lib.c_i32x3()) != 0
+
+
+def test_host_shares_and_pacer_without_a_gpu():
+    """_host.py: every rank gets a contiguous, disjoint share of the cores (at least one), the thread cap
+    is applied once, and the pacer / blocking wait are no-ops where there is no device."""
+    import torch
+    from unires_amd import _host
+    cores = list(range(3, 3 + 64))
+    shares = [_host.core_share(cores, 8, r) for r in range(8)]
+    assert all(len(s) == 8 for s in shares)
+    flat = [c for s in shares for c in s]
+    assert sorted(flat) == cores and len(set(flat)) == 64
+    assert _host.core_share(list(range(5)), 8, 7) and len(_host.core_share(list(range(5)), 8, 7)) == 1
+    assert _host._parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    keep = torch.get_num_threads()
+    try:
+        cfg = _host.configure_host(local_rank=0, world=1)
+        assert 1 <= cfg['threads'] <= 8 and cfg['cpus'] is None  # one rank: no pinning
+    finally:
+        torch.set_num_threads(keep)
+    if not torch.cuda.is_available():
+        p = _host.Pacer(2)
+        for _ in range(5):
+            p.step()
+        p.drain()
+        _host.wait_blocking()

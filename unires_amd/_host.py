@@ -7,7 +7,6 @@ solves, 6 x 6 Gauss-Newton systems) out over ALL cores - 32 ms of CPU for a 5 ms
 every launch call, and (iii) spins in every device synchronisation - `host_cpu_ms_per_iteration` 14.2 for a
 13.7 ms ADMM iteration (profiles/r04_host_time.jsonl): a core per rank burnt on waiting.  Nothing of this
 is the reference's (single process, `unires/run.py`); it is what the batch mode adds around it."""
-import contextlib
 import os
 import time
 
@@ -81,28 +80,33 @@ def configure_host(local_rank=0, world=1, gpu_numa=True):
     return dict(threads=threads, cpus=cpus)
 
 
-@contextlib.contextmanager
-def few_threads(n=2):
-    """Tiny host algebra (4 x 4 solves, matrix exponentials) with at most ``n`` torch threads: fanned out over a
-    whole host it costs more CPU than the GPU step it prepares."""
-    keep = torch.get_num_threads()
-    if keep > n:
+_capped = False
+
+
+def cap_threads(n=8):
+    """Cap torch's intra-op threads at ``n`` ONCE per process (UNIRES_HOST_THREADS overrides; a process that
+    wants more sets it after).  The package's host work is tiny matrices (4 x 4 solves, matrix exponentials,
+    6 x 6 Gauss-Newton systems): fanned out over a 256-thread host the rigid step cost 32 ms of CPU for 5 ms of
+    wall (profiles/r04_fit.jsonl).  Not a context manager on purpose: switching the pool between 2 and 256
+    threads around every call costs as much again (measured: 34 ms of CPU on the demo-shaped subject)."""
+    global _capped
+    if _capped:
+        return
+    _capped = True
+    if os.environ.get('UNIRES_HOST_THREADS'):
+        n = max(1, int(os.environ['UNIRES_HOST_THREADS']))
+    if torch.get_num_threads() > n:
         torch.set_num_threads(n)
-    try:
-        yield
-    finally:
-        if keep > n:
-            torch.set_num_threads(keep)
 
 
 def light_host(fn):
-    """Decorator: run ``fn`` under `few_threads()` (host sections made of tiny matrices)."""
+    """Decorator: ``fn`` is a host section made of tiny matrices - see `cap_threads`."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(*a, **k):
-        with few_threads():
-            return fn(*a, **k)
+        cap_threads()
+        return fn(*a, **k)
     return wrapped
 
 

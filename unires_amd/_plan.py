@@ -238,7 +238,9 @@ class ChannelPlan:
            precond='none'):
         """In-place CG on x (must be contiguous (X,Y,Z)).  Returns (iters, obj) when
         ``sync`` (one stream sync), else None with everything left enqueued.
-        ``precond='jacobi' | 'fft'`` needs :meth:`precond_build` with the same mode, rho, lam first."""
+        ``precond='jacobi' | 'fft'`` needs :meth:`precond_build` with the same mode, rho, lam first.
+        With a tolerance the call keeps the calling thread until the last chunk of iterations is enqueued
+        (``sync=False`` does not return early then); on a capturing stream the whole solve joins the capture."""
         if precond not in _lib.PRECOND:
             raise ValueError('Undefined preconditioner')
         pm = _lib.PRECOND[precond]

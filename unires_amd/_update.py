@@ -71,6 +71,12 @@ def _update_y(x, y, z, w, rho, tmp, sett, info=None):
     issue-bound push kernel of one channel overlaps the HBM-bound vector kernels of
     another.  Results are identical to the sequential loop; ``tmp`` (the reference's
     shared RHS buffer) holds channel 0's b, the other channels use per-plan buffers.
+
+    With ``sett.cgs_tol > 0`` (the reference's default) the solves can stop early: the library feeds them to
+    the device chunk by chunk and this call returns when the LAST chunk is enqueued - the calling thread stays
+    in the feeder (napping between looks at a host-mapped progress word) for about as long as the solves run;
+    host / device overlap beyond that needs ``cgs_tol = 0``.  Under stream capture the whole solve is enqueued
+    instead (kernels after convergence return at entry).
     """
     vx_y = voxel_size(y[0].mat).float()
     rho = float(rho)

@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(kWave)
   // for it (below) and none of whose segments it can collide with.  The segments are offered sorted by first
   // plane, then as 0, h, 1, h + 1, ... (h = half the count): in scan order a row's successors are its
   // neighbours, the row half the cross-section away comes right behind its partner (what took the splat's
-  // lane fill from 0.75 to 0.84).  Lane fill on config 2 (unrotated / rotated channels): one
+  // lane fill from 0.75 to 0.84, EXPERIMENTS E3).  Lane fill on config 2 (unrotated / rotated channels): one
   // segment per 32-lane half 0.84 / 0.44 - 0.51; any plane-disjoint set per half 0.85 / 0.65 - 0.69; close
   // rows tested point by point instead of kept apart wholesale 0.89 / 0.80 - 0.82.
   __shared__ int cnt[33];

@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(kBlock) k_ata_shift2(ShiftArgs A, const int *_
 // two, a plane costs four loads for two lines instead of three for one.
 //
 // The instruction stream is what bounds this kernel (a step's loads have long arrived when it looks for them;
-// -DUNIRES_SHIFT_PROF timeline), so the step is written for few instructions: four plane slots
+// -DUNIRES_SHIFT_PROF timeline, EXPERIMENTS E4), so the step is written for few instructions: four plane slots
 // that change ROLES (previous / current / next / in flight) instead of registers being copied, the walk
 // unrolled by four; everything in 4-vectors, which the compiler packs into v_pk_* instructions; the
 // volume's faces on a path of their own, so that the interior carries no selects; pointers bumped, not

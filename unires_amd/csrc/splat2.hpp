@@ -73,7 +73,7 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
                   float alpha,
                   const PushEpilogue &ep, float *dst, Dim3i dd, const int *done, hipStream_t st);
 
-// host: conv_up table along `axis` (gn entries of 4 floats), same packing as gather2_ztab
+// host: conv_up table along `axis` (gn entries of 4 floats), {bits(first x-space index), w0, w1, -}
 void splat2_convtab(const Taps &T, const Scaling &S, int axis, int gn, int xdn, float *out);
 
 }  // namespace unires
