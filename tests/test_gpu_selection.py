@@ -15,11 +15,11 @@ EXPECT = {
     # workload: predicate on repeat_info of every channel's repeat
     'cfg2_181c3_1mm': lambda i: i['fused'] and i['pull2'] and i['splat2_axis'] == -1,
     'cfg3_256c3_thick6z': lambda i: i['pull2'] and i['splat2_axis'] == 2 and not i['separable'],
-    'cfg3_256c3_thick6_orient': lambda i: i['pull2'] and i['splat2_axis'] == 2 and not i['separable'],
-    'cfg3_256c3_thick6xyz': lambda i: i['pull2'] and i['splat2_axis'] == 2 and not i['separable'],
+    'cfg3_256c3_thick6_orient': lambda i: i['pull2'] and i['splat2_axis'] in (0, 1, 2) and not i['separable'],
+    'cfg3_256c3_thick6xyz': lambda i: i['pull2'] and i['splat2_axis'] in (0, 1, 2) and not i['separable'],
     'cfg4_384c4_iso2': lambda i: i['pull2'] and i['splat2_axis'] == 2 and not i['separable'],
     'cfg4_384c4_iso2_gauss': lambda i: i['pull2'] and i['splat2_axis'] is not None,
-    'demo_181c3_thick4xyz': lambda i: i['pull2'] and i['splat2_axis'] == 2 and not i['separable'],
+    'demo_181c3_thick4xyz': lambda i: i['pull2'] and i['splat2_axis'] in (0, 1, 2) and not i['separable'],
 }
 
 

@@ -1,9 +1,8 @@
 """Host-side housekeeping of the one-process-per-GPU batch mode: how many CPU threads a
 rank may use, which cores it sits on, and how it waits for its GPU.
 
-Eight ranks share one host.  Left alone, every rank (i) lets torch fan its tiny host-side algebra (4 x 4
-solves, 6 x 6 Gauss-Newton systems) out over ALL cores - 32 ms of CPU for a 5 ms rigid step at 256 cores
-(profiles/r04_fit.jsonl), (ii) runs ahead of its GPU until the hardware queue is full and then SPINS in
+Eight ranks share one host.  Left alone, every rank (i) lets torch / BLAS fan tiny host-side algebra (4 x 4
+solves, 6 x 6 Gauss-Newton systems) out over all cores, (ii) runs ahead of its GPU until the hardware queue is full and then SPINS in
 every launch call, and (iii) spins in every device synchronisation - `host_cpu_ms_per_iteration` 14.2 for a
 13.7 ms ADMM iteration (profiles/r04_host_time.jsonl): a core per rank burnt on waiting.  Nothing of this
 is the reference's (single process, `unires/run.py`); it is what the batch mode adds around it."""
@@ -86,9 +85,10 @@ _capped = False
 def cap_threads(n=8):
     """Cap torch's intra-op threads at ``n`` ONCE per process (UNIRES_HOST_THREADS overrides; a process that
     wants more sets it after).  The package's host work is tiny matrices (4 x 4 solves, matrix exponentials,
-    6 x 6 Gauss-Newton systems): fanned out over a 256-thread host the rigid step cost 32 ms of CPU for 5 ms of
-    wall (profiles/r04_fit.jsonl).  Not a context manager on purpose: switching the pool between 2 and 256
-    threads around every call costs as much again (measured: 34 ms of CPU on the demo-shaped subject)."""
+    6 x 6 Gauss-Newton systems): nothing to gain from a 256-thread pool, and eight ranks' pools would fight.
+    Not a context manager on purpose: switching the pool's size around every call is work of its own.  (The
+    "32 ms of CPU for a 5 ms rigid step" of profiles/r04_fit.jsonl turned out to be wall + three scheduler
+    ticks charged to runtime helper threads, tools/rigid_threads.py - not this.)"""
     global _capped
     if _capped:
         return
@@ -99,14 +99,36 @@ def cap_threads(n=8):
         torch.set_num_threads(n)
 
 
+_blas_ctl = None
+
+
+def _blas_one_thread():
+    """Context: numpy / scipy BLAS (OpenBLAS / MKL pools, which spin after every call) on ONE thread - the 4 x 4
+    `expm` / `logm` / 6 x 6 solves of the Gauss-Newton steps would wake a pool of as many threads as the host has
+    cores.  threadpoolctl where it is installed
+    (the controller is made once: introspecting the loaded libraries costs milliseconds), else nothing."""
+    global _blas_ctl
+    if _blas_ctl is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _blas_ctl = ThreadpoolController()
+        except Exception:
+            _blas_ctl = False
+    if _blas_ctl:
+        return _blas_ctl.limit(limits=1, user_api='blas')
+    import contextlib
+    return contextlib.nullcontext()
+
+
 def light_host(fn):
-    """Decorator: ``fn`` is a host section made of tiny matrices - see `cap_threads`."""
+    """Decorator: ``fn`` is a host section made of tiny matrices - see `cap_threads`, `_blas_one_thread`."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(*a, **k):
         cap_threads()
-        return fn(*a, **k)
+        with _blas_one_thread():
+            return fn(*a, **k)
     return wrapped
 
 
