@@ -17,7 +17,7 @@ import torch
 
 from oracle import nitorch_restated as N
 from oracle import unires_restated as O
-from tests.helpers import rigid_matrix
+from tests.helpers import SIGNED_PERMS, orient_axes, rigid_matrix
 from unires_amd._plan import ChannelPlan
 
 pytestmark = pytest.mark.gpu
@@ -90,6 +90,41 @@ def test_denoising_disagreements_lie_within_reach_of_fov_ties(dev, trans, rot):
             assert not bool((bad & ~cover).any()), '%s (%s) differs from the oracle out of reach of every FOV tie' % (op, name)
     # and the ties are few: the operators agree on (nearly) the whole volume
     assert float(cover.float().mean()) < 0.5
+
+
+@pytest.mark.parametrize('iperm', [9, 22, 41])
+@pytest.mark.parametrize('trans,rot', GEOMS[:2] + [((1.0, -0.5, 0.05), (0.0, 0.0, 0.0))])
+def test_reoriented_storage_disagreements_lie_within_reach_of_fov_ties(dev, iperm, trans, rot):
+    """The same for observations STORED in another voxel order (sagittal / coronal / reflected: a signed axis
+    permutation in the affine).  The plan relabels their axes and evaluates the grid coordinates from permuted,
+    sign-flipped terms with the flip offset folded into the translation (api.hip: canonicalise) - equal to the
+    reference's `lin @ ijk + off` to the last ulp or one off: a mask may flip where a coordinate
+    ties with a threshold, nowhere else.  Thresholds hit by integer, half-voxel and 0.05-voxel translations."""
+    import unires_amd as U
+    dim_y = (26, 24, 22)
+    mat_y = torch.eye(4, dtype=torch.float64)
+    perm, flip = SIGNED_PERMS[iperm]
+    dim_x, mat_x = orient_axes(dim_y, mat_y, perm, flip)
+    rigid = rigid_matrix(list(trans), list(rot))
+    po_o = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid)
+    po_g = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, device=dev)
+    mat, dim_g = O.proj_matrix(po_o, 'denoising')
+    near, g = _tie_points(mat, dim_g, dim_y, eps=1e-4)
+    torch.manual_seed(7)
+    p = torch.rand(dim_y) + 0.5
+    v = torch.rand(dim_g) + 0.5
+    cover = _reach(near, g, dim_y, reach=2)
+    plan = ChannelPlan(dim_y, (1.0, 1.0, 1.0), [(po_g, 1.0)], 'denoising', True, device=dev)
+    assert plan.repeat_info(0)['perm'] != (0, 1, 2) or any(plan.repeat_info(0)['flip'])
+    ref = O.proj_apply('A', p[None, None], po_o, method='denoising')[0, 0]
+    out = plan.proj_apply(0, 'A', p.to(dev)).cpu()
+    bad = (out - ref).abs() > 1e-5 * float(ref.abs().max())
+    assert not bool((bad & ~near).any()), 'A differs from the oracle away from every FOV tie'
+    for op, arg in (('At', v), ('AtA', p)):
+        ref = O.proj_apply(op, arg[None, None], po_o, method='denoising')[0, 0]
+        out = plan.proj_apply(0, op, arg.to(dev)).cpu()
+        bad = (out - ref).abs() > 1e-5 * float(ref.abs().max())
+        assert not bool((bad & ~cover).any()), '%s differs from the oracle out of reach of every FOV tie' % op
 
 
 @pytest.mark.parametrize('trans,rot', GEOMS[:3])

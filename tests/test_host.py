@@ -293,3 +293,13 @@ def test_host_shares_and_pacer_without_a_gpu():
             p.step()
         p.drain()
         _host.wait_blocking()
+
+
+def test_objective_trace_from_the_ring():
+    """_plan._trace: all values while they fit the library's ring, else the last len(ring), oldest first
+    (budgets beyond 4 096 iterations)."""
+    from unires_amd._plan import _trace
+    ring = list(range(5))
+    assert _trace(ring, 2) == [0, 1, 2] and _trace(ring, 4) == [0, 1, 2, 3, 4]
+    assert _trace([5, 6, 2, 3, 4], 6) == [2, 3, 4, 5, 6]  # iteration k lives in slot k mod 5
+    assert _trace([10, 6, 7, 8, 9], 10) == [6, 7, 8, 9, 10]
