@@ -26,6 +26,8 @@ import time
 
 import torch
 
+import unires_amd  # noqa: F401  (first: its import sets ROC_SIGNAL_POOL_SIZE before anything initialises the HIP runtime)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -290,6 +290,22 @@ int unires_clean_fov(float *y, const int32_t dim_y[3], const float M[12], const 
 int unires_scaling_sums(const float *x, const float *ay, const int32_t dim[3], int32_t dim_thick,
                         double *out_dev, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Stream marks: following a stream from the host by reading memory.
+ * Not part of the reference (single process, unires/run.py); it serves the one-process-per-GPU batch
+ * mode, where eight ranks share one host: every hipEventQuery / hipStreamQuery on running
+ * work costs the runtime's signal thread CPU time (profiles/r05_host_profile.txt).  A mark is a 64-bit
+ * word in mapped host memory; unires_mark_signal enqueues a one-thread kernel that stores `value` into it
+ * once everything enqueued on `stream` before it has finished; unires_mark_read is a plain load (never
+ * blocks, no runtime call).  Seeing the value orders NOTHING else for the host: results are still read
+ * through a stream synchronisation / a blocking copy - the mark only tells when that will not wait.
+ * ---------------------------------------------------------------------- */
+typedef struct unires_mark unires_mark_t;
+int unires_mark_create(unires_mark_t **out);
+int unires_mark_destroy(unires_mark_t *mark);
+int unires_mark_signal(unires_mark_t *mark, uint64_t value, void *stream);
+int unires_mark_read(const unires_mark_t *mark, uint64_t *value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -303,3 +303,32 @@ def test_objective_trace_from_the_ring():
     assert _trace(ring, 2) == [0, 1, 2] and _trace(ring, 4) == [0, 1, 2, 3, 4]
     assert _trace([5, 6, 2, 3, 4], 6) == [2, 3, 4, 5, 6]  # iteration k lives in slot k mod 5
     assert _trace([10, 6, 7, 8, 9], 10) == [6, 7, 8, 9, 10]
+
+
+def test_blas_pools_are_capped_once_and_for_good():
+    """`cap_blas` (the Gauss-Newton steps' 4 x 4 / 6 x 6 algebra must not wake OpenBLAS worker pools that then
+    spin: 20 -> 5 ms of CPU per rigid step, profiles/r05_rigid_profile.txt): after a `light_host` section every
+    loaded BLAS - numpy's and scipy's copy - runs on one thread and stays there; UNIRES_BLAS_THREADS=0 leaves
+    the pools alone."""
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from threadpoolctl import threadpool_info\n"
+        "before = [i['num_threads'] for i in threadpool_info() if i['user_api'] == 'blas']\n"
+        "from unires_amd import _host\n"
+        "f = _host.light_host(lambda: np.linalg.solve(np.eye(6), np.ones(6)).sum())\n"
+        "assert f() == 6.0\n"
+        "n1 = [i['num_threads'] for i in threadpool_info() if i['user_api'] == 'blas']\n"
+        "f()\n"
+        "n2 = [i['num_threads'] for i in threadpool_info() if i['user_api'] == 'blas']\n"
+        "print(before, n1, n2)\n") % ROOT
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    before, n1, n2 = eval('(' + r.stdout.strip().replace('] [', '], [') + ')')
+    assert n1 and n1 == n2 and all(v == 1 for v in n1), (before, n1, n2)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, UNIRES_BLAS_THREADS='0'))
+    assert r.returncode == 0, r.stderr[-2000:]
+    before, n1, n2 = eval('(' + r.stdout.strip().replace('] [', '], [') + ')')
+    assert n1[:len(before)] == before and n2 == n1, (before, n1, n2)

@@ -12,6 +12,23 @@ import time
 import torch
 
 
+def tune_runtime():
+    """ROC_SIGNAL_POOL_SIZE=4096 in the environment unless the user set it (or UNIRES_NO_RUNTIME_TUNING=1) - to
+    take effect it must be there before the process's first HIP call, hence at import.
+
+    Why: the HIP runtime hands every packet that carries a completion signal (markers, cross-stream waits,
+    graph launches, read-backs) a signal from a ring of ROC_SIGNAL_POOL_SIZE (default 64) per hardware queue.
+    An ADMM iteration enqueues ~10^3 commands ahead of the device; with the ring that short the runtime's
+    signal thread spends its time - system time, almost no voluntary context switches - waiting on recycled
+    signals: 7.4 ms of CPU per 19.2 ms iteration with the reference's stopping rule at 256^3, 6.0 of 6.9 ms
+    with the three channels of a 181^3 subject on streams of their own (tools/host_profile.py,
+    profiles/r05_host_profile.txt).  With 4096 signals that thread is idle (0.1 - 0.3 ms), wall times and
+    results unchanged.  Nothing here is the reference's; it is what eight ranks sharing one host need."""
+    if os.environ.get('UNIRES_NO_RUNTIME_TUNING'):
+        return
+    os.environ.setdefault('ROC_SIGNAL_POOL_SIZE', '4096')
+
+
 def _parse_cpulist(text):
     cpus = []
     for part in text.strip().split(','):
@@ -99,47 +116,90 @@ def cap_threads(n=8):
         torch.set_num_threads(n)
 
 
-_blas_ctl = None
+_blas_limit = None
 
 
-def _blas_one_thread():
-    """Context: numpy / scipy BLAS (OpenBLAS / MKL pools, which spin after every call) on ONE thread - the 4 x 4
-    `expm` / `logm` / 6 x 6 solves of the Gauss-Newton steps would wake a pool of as many threads as the host has
-    cores.  threadpoolctl where it is installed
-    (the controller is made once: introspecting the loaded libraries costs milliseconds), else nothing."""
-    global _blas_ctl
-    if _blas_ctl is None:
-        try:
-            from threadpoolctl import ThreadpoolController
-            _blas_ctl = ThreadpoolController()
-        except Exception:
-            _blas_ctl = False
-    if _blas_ctl:
-        return _blas_ctl.limit(limits=1, user_api='blas')
-    import contextlib
-    return contextlib.nullcontext()
+def cap_blas(n=1):
+    """numpy / scipy BLAS (OpenBLAS pthread pools) on ``n`` threads, ONCE per process and for good
+    (UNIRES_BLAS_THREADS overrides, 0 = leave the pools alone).  The Gauss-Newton steps run 4 x 4 `expm` / `logm`
+    and 6 x 6 solves through numpy: on a 256-core host OpenBLAS keeps a pool of 64 workers per loaded copy, a few of
+    which it wakes even for these sizes - and a woken worker spins for ~100 ms before it sleeps again, i.e. for ever
+    when a step comes every 5 ms.  Measured on the MI355X box (tools/rigid_profile.py, profiles/r05_rigid_profile.txt):
+    three workers at 100 % next to the main thread, 20 ms of CPU for a 5 ms rigid step; 5.2 ms with the pools on one
+    thread.  Sticky on purpose: limiting around each call (threadpoolctl as a context manager, round 5's first
+    attempt) re-sizes the pools twice per step and left the workers spinning all the same."""
+    global _blas_limit
+    if _blas_limit is not None:
+        return
+    _blas_limit = False
+    if os.environ.get('UNIRES_BLAS_THREADS'):
+        n = int(os.environ['UNIRES_BLAS_THREADS'])
+    if n <= 0:
+        return
+    try:
+        import scipy.linalg  # noqa: F401  (its own OpenBLAS copy loads with it: limit that one too)
+        from threadpoolctl import threadpool_limits
+        _blas_limit = threadpool_limits(limits=n, user_api='blas')  # kept alive: never restored
+    except Exception:
+        _blas_limit = False
 
 
 def light_host(fn):
-    """Decorator: ``fn`` is a host section made of tiny matrices - see `cap_threads`, `_blas_one_thread`."""
+    """Decorator: ``fn`` is a host section made of tiny matrices - see `cap_threads`, `cap_blas`."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(*a, **k):
         cap_threads()
-        with _blas_one_thread():
-            return fn(*a, **k)
+        cap_blas()
+        return fn(*a, **k)
     return wrapped
 
 
-def _sleep_until(ev, dt=1e-4):
-    """Wait for a recorded event by polling it between SLEEPS.  Measured on the MI355X box (tools/wait_probe.py
-    -> profiles/r05_wait_probe.txt): `torch.cuda.synchronize()` and even `Event(blocking=True).synchronize()`
-    burn a core for as long as they wait unless the process called hipSetDeviceFlags(hipDeviceScheduleBlockingSync)
-    before its context existed (torch has none of that); query + sleep costs 1 % of a core whatever the flags
-    and ends within ``dt`` of the event."""
-    while not ev.query():
-        time.sleep(dt)
+class StreamMark:
+    """A word of mapped host memory that the device sets when a stream reaches the point of `signal()`
+    (``unires_mark_*``, include/unires_hip.h): the host follows its GPU by READING MEMORY.
+
+    Why not events: on this runtime `torch.cuda.synchronize()` and even `Event(blocking=True).synchronize()`
+    burn a core for as long as they wait (tools/wait_probe.py -> profiles/r05_wait_probe.txt), and every
+    `Event.query()` / stream query on running work makes the runtime submit a marker packet and wakes its
+    signal thread, which polls for a while before it sleeps again - a 0.5 ms event poll cost that helper thread
+    4.3 ms of CPU per 13.6 ms ADMM iteration (tools/host_profile.py -> profiles/r05_host_profile.txt)."""
+
+    def __init__(self):
+        import ctypes
+        from . import _lib
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        _lib.check(self._lib.unires_mark_create(ctypes.byref(self._h)))
+        self._val = ctypes.c_uint64(0)
+        self._ref = ctypes.byref(self._val)
+        self.count = 0  # value of the last signal
+
+    def signal(self, stream=None):
+        """Enqueue "set the word to the next value" on ``stream`` (default: the current one); returns it."""
+        from . import _lib
+        st = stream if stream is not None else torch.cuda.current_stream()
+        self.count += 1
+        _lib.check(self._lib.unires_mark_signal(self._h, self.count, st.cuda_stream))
+        return self.count
+
+    def reached(self, value):
+        self._lib.unires_mark_read(self._h, self._ref)
+        return self._val.value >= value
+
+    def wait(self, value, dt=1e-4):
+        """Sleep until the device has set the word to ``value`` or beyond (``dt`` seconds between looks)."""
+        while not self.reached(value):
+            time.sleep(dt)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.unires_mark_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 class Pacer:
@@ -150,28 +210,45 @@ class Pacer:
 
     def __init__(self, depth=2):
         self.depth = max(1, int(depth))
-        self._events = []
+        self._mark = None
+        self._stream = None
+        self._pending = []
 
     def step(self, stream=None):
         """Call once per enqueued step, after its last launch."""
         if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
             return
-        if len(self._events) >= self.depth:
-            _sleep_until(self._events.pop(0), 5e-4)  # (an event `depth` steps old: no hurry)
-        ev = torch.cuda.Event()
-        ev.record(stream if stream is not None else torch.cuda.current_stream())
-        self._events.append(ev)
+        st = stream if stream is not None else torch.cuda.current_stream()
+        if self._mark is None or self._stream != st:
+            # (a mark counts along ONE stream; a loop that moves to another stream starts a new one)
+            self.drain()
+            self._mark, self._stream = StreamMark(), st
+        if len(self._pending) >= self.depth:
+            self._mark.wait(self._pending.pop(0), 5e-4)  # (a step `depth` steps old: no hurry)
+        self._pending.append(self._mark.signal(st))
 
     def drain(self):
-        while self._events:
-            _sleep_until(self._events.pop(0))
+        while self._pending:
+            self._mark.wait(self._pending.pop(0))
+
+
+_wait_marks = {}
 
 
 def wait_blocking(device=None):
     """Wait for everything enqueued on the current stream WITHOUT spinning: what `tensor.cpu()` /
-    `torch.cuda.synchronize()` do by polling flat out."""
+    `torch.cuda.synchronize()` do by polling flat out.  (The caller still synchronises / copies afterwards -
+    that is what orders the results for the host; after this it no longer waits.)"""
     if not torch.cuda.is_available():
         return
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(device))
-    _sleep_until(ev, 5e-5)
+    st = torch.cuda.current_stream(device)
+    if torch.cuda.is_current_stream_capturing():
+        return
+    key = (st.device.index, st.cuda_stream)
+    with torch.cuda.device(st.device):
+        mark = _wait_marks.get(key)
+        if mark is None:
+            if len(_wait_marks) > 64:  # (streams come and go: do not collect marks for ever)
+                _wait_marks.clear()
+            mark = _wait_marks[key] = StreamMark()
+        mark.wait(mark.signal(st), 5e-5)

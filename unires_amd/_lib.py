@@ -85,6 +85,10 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p]),
     'unires_clean_fov': (C.c_int, [C.c_void_p, c_i32x3, c_f32x12, c_i32x3, C.c_void_p]),
     'unires_masked_sse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'unires_mark_create': (C.c_int, [C.POINTER(C.c_void_p)]),
+    'unires_mark_destroy': (C.c_int, [C.c_void_p]),
+    'unires_mark_signal': (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    'unires_mark_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

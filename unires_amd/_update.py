@@ -268,8 +268,8 @@ def _update_admm(x, y, z, w, rho, tmp, obj, n_iter, sett, info=None):
         obj[n_iter, 0], obj[n_iter, 1], obj[n_iter, 2] = _compute_nll(x, y, sett, rho)
     z, w, tmp = _update_zw(y, z, w, rho, tmp, sett)
     # An iteration is enqueue-only (no read-back): a host loop would run ahead until the hardware queue is
-    # full and then spin inside every launch call.  The pacer parks the thread - blocking-sync events -
-    # until the device is at most `host_pace` iterations behind (settings.host_pace; 0: off).
+    # full and then spin inside every launch call.  The pacer parks the thread - sleeping between looks at a
+    # stream mark (_host.StreamMark) - until the device is at most `host_pace` iterations behind (settings.host_pace; 0: off).
     depth = int(getattr(sett, 'host_pace', 2) or 0)
     if depth > 0 and y[0].dat.is_cuda:
         key = (y[0].dat.device.index, depth)

@@ -1624,7 +1624,10 @@ static int cg_runs_drive(std::vector<CgRun> &runs) {
       const struct timespec nap = {0, 50000};
       (void)nanosleep(&nap, nullptr);
     }
-    if ((spins & 0x3ff) == 0 || (spins > 256 && (spins & 0xf) == 0)) {
+    // (a watchdog, not the progress signal - the word is: every 512th nap, ~25 ms, catches a faulted stream as
+    // well as every 16th did, and a stream query on running work is not free: the runtime submits a marker
+    // packet for it and its signal thread handles the completion)
+    if ((spins <= 256 && (spins & 0xff) == 0) || (spins > 256 && (spins & 0x1ff) == 0)) {
       for (CgRun &R : runs) {
         if (R.finished) continue;
         const hipError_t q = hipStreamQuery(R.st);
@@ -1953,5 +1956,63 @@ extern "C" int unires_masked_sse(const float *x, const float *ay, int64_t n, dou
   if (int rc = reduce_scratch(st, (size_t)masked_sse_blocks((size_t)n), &part)) return rc;
   launch_masked_sse(x, ay, (size_t)n, part, out_dev, st);
   CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+// --------------------------------------------------------------------------
+// Stream marks (round 5): how a host thread follows its GPU WITHOUT runtime calls.
+// Every hipEventQuery / hipStreamQuery on work that is still running makes the runtime submit a marker
+// packet whose completion wakes its signal thread, which then polls for a while before it sleeps again:
+// measured on the MI355X box (tools/host_profile.py, profiles/r05_host_profile.txt) that helper thread
+// cost 4.3 ms of CPU per 13.6 ms ADMM iteration under a 0.5 ms event poll.  A mark is a word of mapped host
+// memory that a one-thread kernel sets when the stream gets there: the host reads memory, nothing else.
+// --------------------------------------------------------------------------
+struct unires_mark {
+  unsigned long long *host = nullptr;
+  unsigned long long *dev = nullptr;
+};
+
+__global__ void k_mark(unsigned long long *w, unsigned long long v) {
+  __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int unires_mark_create(unires_mark_t **out) {
+  if (!out) return fail(UNIRES_ERR_NULL, "null argument");
+  *out = nullptr;
+  unires_mark *m = new (std::nothrow) unires_mark;
+  if (!m) return fail(UNIRES_ERR_ALLOC, "out of host memory");
+  if (hipHostMalloc((void **)&m->host, 64, hipHostMallocMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    delete m;
+    return fail(UNIRES_ERR_ALLOC, "hipHostMalloc failed");
+  }
+  *m->host = 0ull;
+  if (hipHostGetDevicePointer((void **)&m->dev, (void *)m->host, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostFree(m->host);
+    delete m;
+    return fail(UNIRES_ERR_HIP, "hipHostGetDevicePointer failed");
+  }
+  *out = m;
+  return UNIRES_OK;
+}
+
+extern "C" int unires_mark_destroy(unires_mark_t *m) {
+  if (!m) return UNIRES_OK;
+  if (m->host) (void)hipHostFree(m->host);  // (waits for the device: no kernel writes it afterwards)
+  delete m;
+  return UNIRES_OK;
+}
+
+extern "C" int unires_mark_signal(unires_mark_t *m, uint64_t value, void *stream) {
+  if (!m) return fail(UNIRES_ERR_NULL, "null argument");
+  hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, (hipStream_t)stream, m->dev, (unsigned long long)value);
+  CHECK_LAUNCH();
+  return UNIRES_OK;
+}
+
+extern "C" int unires_mark_read(const unires_mark_t *m, uint64_t *value) {
+  if (!m || !value) return fail(UNIRES_ERR_NULL, "null argument");
+  *value = (uint64_t)__atomic_load_n(m->host, __ATOMIC_ACQUIRE);
   return UNIRES_OK;
 }

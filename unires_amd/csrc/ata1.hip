@@ -1,19 +1,20 @@
 // ata1.hip - single-pass A^T A = push_M . pull_M (+ stencil, + dot) for operators without a slice
 // profile (see ata1.hpp; unires/_project.py:180-188).
 //
-// Budget per wave (tile 4 x 4 x 30): p window 6 x 6 x 32 floats + accumulator 6 x 6 x 32 floats =
-// 9.2 KB of LDS, so a CU holds 16 waves (4 per SIMD - a wave alone issues one instruction every ~6.8
-// clocks, four of them one every ~2.1: profiles/r04_mb_valu2.txt; the 8 x 4 x 30 tile of the splat
-// with a window next to it would leave 2.5 waves per SIMD).  Per 64-lane instruction: one 16-byte
-// descriptor load per lane, ~40 VALU, 4 ds_read2 (gather), 4 + 4 ds_read2 / ds_write2 (two dense
-// read-add-write groups: lower z plane, then upper) - the x-space round trip, the second kernel's
-// decode / source loads and half of the coordinate arithmetic of the pull + splat pair are gone.
+// Budget per wave (tile 4 x 4 x 30): p window 6 x 6 x 32 floats + accumulator 6 x 6 x 32 floats + a ring of
+// 64 segment entries = 10 KB of LDS, so a CU holds 16 waves (4 per SIMD - a wave alone issues one instruction
+// every ~6.8 clocks, four of them one every ~2.1: profiles/r04_mb_valu2.txt; the 8 x 4 x 30 tile of the splat
+// with a window next to it would leave 2.5 waves per SIMD).  Per 64-lane instruction: one 16-byte header
+// (scalar), the lanes' segment entries from the LDS ring, ~55 VALU, 4 ds_read2 (gather), 4 + 4 ds_read2 /
+// ds_write2 (two dense read-add-write groups: lower z plane, then upper) - the x-space round trip, the second
+// kernel's decode / source loads and half of the coordinate arithmetic of the pull + splat pair are gone.
 //
-// Race freedom without atomics, as in splat2.hip: a tile is owned by ONE wave whose LDS operations
-// execute in order; the lanes of a segment sit in consecutive z planes (the build kernel cuts a row
-// wherever the plane does not advance by exactly one), a read-add-write group touches one plane per
-// lane, and the two segments of an instruction either come from rows >= row_sep apart or occupy
-// disjoint plane ranges.  The schedule is fixed: results are bit-reproducible.
+// Race freedom without atomics, as in splat2.hip: a tile is owned by ONE wave whose LDS operations execute in
+// order; the lanes of a segment sit in consecutive z planes (the build kernel cuts a row wherever the plane
+// does not advance by exactly one), a read-add-write group touches one plane per lane, and two segments that
+// share an instruction AND a z plane have footprints that cannot meet: rows >= row_sep apart (the quick rule,
+// rebuilds in set_repeat) or, point by point on the shared planes, cells >= 2 apart in x or y (the exact
+// rule, plan creation - k_f1_build).  The schedule is fixed: results are bit-reproducible.
 #include "ata1.hpp"
 #include "splat2.hpp"
 
