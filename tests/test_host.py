@@ -332,3 +332,17 @@ def test_blas_pools_are_capped_once_and_for_good():
     assert r.returncode == 0, r.stderr[-2000:]
     before, n1, n2 = eval('(' + r.stdout.strip().replace('] [', '], [') + ')')
     assert n1[:len(before)] == before and n2 == n1, (before, n1, n2)
+
+
+def test_import_sets_the_runtimes_signal_pool_unless_told_otherwise():
+    """`_host.tune_runtime`: ROC_SIGNAL_POOL_SIZE=4096 from the package import, a value the user set
+    is kept, UNIRES_NO_RUNTIME_TUNING=1 leaves the environment alone."""
+    import sys
+    code = "import sys, os; sys.path.insert(0, %r); import unires_amd; print(os.environ.get('ROC_SIGNAL_POOL_SIZE'))" % ROOT
+    base = {k: v for k, v in os.environ.items() if k not in ('ROC_SIGNAL_POOL_SIZE', 'UNIRES_NO_RUNTIME_TUNING')}
+    for extra, want in (({}, '4096'), ({'ROC_SIGNAL_POOL_SIZE': '128'}, '128'),
+                        ({'UNIRES_NO_RUNTIME_TUNING': '1'}, 'None')):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300,
+                           env=dict(base, **extra))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.strip().splitlines()[-1] == want, (extra, r.stdout)
