@@ -106,3 +106,16 @@ def test_admm_loop_runs_with_and_without_the_pacer(dev):
     for o in outs[1:]:
         for a, b in zip(o, outs[0]):
             assert torch.equal(a, b)
+
+
+def test_a_mark_that_cannot_come_raises_instead_of_hanging(dev):
+    """The wait's watchdog: a value nobody signalled, on a stream that has drained -> RuntimeError after ~1 s."""
+    from unires_amd._host import StreamMark
+    with torch.cuda.device(dev):
+        m = StreamMark()
+        v = m.signal()
+        m.wait(v)
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match='without reaching its mark'):
+            m.wait(v + 3)
+        assert 0.9 < time.perf_counter() - t0 < 5.0

@@ -175,6 +175,7 @@ class StreamMark:
         self._val = ctypes.c_uint64(0)
         self._ref = ctypes.byref(self._val)
         self.count = 0  # value of the last signal
+        self._last_stream = None
 
     def signal(self, stream=None):
         """Enqueue "set the word to the next value" on ``stream`` (default: the current one); returns it."""
@@ -182,16 +183,30 @@ class StreamMark:
         st = stream if stream is not None else torch.cuda.current_stream()
         self.count += 1
         _lib.check(self._lib.unires_mark_signal(self._h, self.count, st.cuda_stream))
+        self._last_stream = st
         return self.count
 
     def reached(self, value):
         self._lib.unires_mark_read(self._h, self._ref)
         return self._val.value >= value
 
-    def wait(self, value, dt=1e-4):
-        """Sleep until the device has set the word to ``value`` or beyond (``dt`` seconds between looks)."""
+    def wait(self, value, dt=1e-4, stream=None):
+        """Sleep until the device has set the word to ``value`` or beyond (``dt`` seconds between looks).
+        A wait that lasts longer than a second starts asking the stream itself twice a second (that call costs
+        the runtime something, hence not earlier): a faulted stream raises there, and a stream that has finished
+        without the mark being set - which cannot happen to a healthy one - raises here instead of hanging."""
+        t0 = t_ask = None
         while not self.reached(value):
             time.sleep(dt)
+            if t0 is None:
+                t0 = t_ask = time.monotonic()
+                continue
+            now = time.monotonic()
+            if now - t0 > 1.0 and now - t_ask > 0.5:
+                t_ask = now
+                st = stream if stream is not None else self._last_stream
+                if st is not None and st.query() and not self.reached(value):
+                    raise RuntimeError('unires_amd: the stream finished without reaching its mark (value %d)' % value)
 
     def __del__(self):
         try:
