@@ -1981,7 +1981,8 @@ extern "C" int unires_mark_create(unires_mark_t **out) {
   *out = nullptr;
   unires_mark *m = new (std::nothrow) unires_mark;
   if (!m) return fail(UNIRES_ERR_ALLOC, "out of host memory");
-  if (hipHostMalloc((void **)&m->host, 64, hipHostMallocMapped) != hipSuccess) {
+  // (portable: a process that drives several devices may signal the mark from any of them)
+  if (hipHostMalloc((void **)&m->host, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
     (void)hipGetLastError();
     delete m;
     return fail(UNIRES_ERR_ALLOC, "hipHostMalloc failed");
