@@ -110,9 +110,14 @@ __device__ __forceinline__ unsigned s2_rowcode(const S2BuildArgs &B, int ui, int
                                       : (unsigned)ui * (unsigned)B.rows_y + (unsigned)uj;
 }
 
-// One wave per tile.  FILL = false: counts[t] = {entries, instructions}; FILL = true: counts holds
-// the exclusive prefix sums and the entries / masks are written.
-template <bool FILL>
+// One wave per tile.  MODE 0: counts[t] = {entries, instructions}; MODE 1: counts holds the exclusive prefix
+// sums and the entries / masks are written where they belong (the two-pass build of rounds 2-4, kept as the
+// fallback); MODE 2 (round 5): ONE pass - counts[t] as in MODE 0 AND the tile's entries / masks into its staging
+// slot (kS2StageE entries, 64 masks per tile: entries, ext and masks point at the staging arrays), from where
+// k_splat2_compact moves them once the host has fixed the processing order.  A tile with more entries than a slot
+// holds raises bit 1 of *err: the caller falls back to MODE 1.
+constexpr int kS2StageE = 128;
+template <int MODE>
 __global__ void __launch_bounds__(kWave)
     k_splat2_build(S2BuildArgs B, uint2 *__restrict__ counts, const int *__restrict__ geom,
                    S2Entry *__restrict__ entries, S2Ext *__restrict__ ext, ulonglong2 *__restrict__ masks,
@@ -312,7 +317,7 @@ __global__ void __launch_bounds__(kWave)
     }
     const unsigned long long m = __ballot(ok0 || ok1);
     if (m == 0ull) {  // more than 64 instructions in one tile
-      if (lane == 0) atomicExch(err, 1);
+      if (lane == 0) atomicOr(err, 1);
       break;
     }
     const int chosen = __ffsll((long long)m) - 1;
@@ -336,11 +341,15 @@ __global__ void __launch_bounds__(kWave)
     if (lane >= off) incl += v;
   }
   const int total_ent = __shfl(incl, kWave - 1, kWave);
-  if (!FILL) {
+  if (MODE != 1) {
     if (lane == 0) counts[slot] = make_uint2((unsigned)total_ent, (unsigned)nbins);
-    return;
+    if (MODE == 0) return;
+    if (total_ent > kS2StageE) {
+      if (lane == 0) atomicOr(err, 2);
+      return;
+    }
   }
-  const uint2 base = counts[slot];
+  const uint2 base = MODE == 1 ? counts[slot] : make_uint2((unsigned)slot * (unsigned)kS2StageE, (unsigned)slot * 64u);
   unsigned long long pts = 0;
   if (lane < nbins) {
     S2Entry *out = entries + base.x + (incl - nent);
@@ -391,6 +400,77 @@ __global__ void __launch_bounds__(kWave)
       atomicAdd(stats + 1, (unsigned long long)nbins);
     }
   }
+}
+
+// Staging slot of tile geom[u] -> the schedule's arrays at processing slot u's offsets.
+__global__ void __launch_bounds__(kWave)
+    k_splat2_compact(const uint2 *__restrict__ stage_cnt, const S2Entry *__restrict__ stage_e,
+                     const S2Ext *__restrict__ stage_x, const ulonglong2 *__restrict__ stage_m,
+                     const int *__restrict__ geom, const uint2 *__restrict__ tile_off, S2Entry *__restrict__ entries,
+                     S2Ext *__restrict__ ext, ulonglong2 *__restrict__ masks) {
+  const int u = blockIdx.x, lane = threadIdx.x;
+  const int t = geom[u];
+  const uint2 c = stage_cnt[t], o = tile_off[u];
+  const uint4 *se = reinterpret_cast<const uint4 *>(stage_e) + (size_t)t * kS2StageE;
+  uint4 *de = reinterpret_cast<uint4 *>(entries) + o.x;
+  for (unsigned i = lane; i < c.x; i += kWave) de[i] = se[i];
+  if (stage_x) {
+    const uint4 *sx = reinterpret_cast<const uint4 *>(stage_x) + 2 * (size_t)t * kS2StageE;  // 32 bytes per entry
+    uint4 *dx = reinterpret_cast<uint4 *>(ext) + 2 * (size_t)o.x;
+    for (unsigned i = lane; i < 2u * c.x; i += kWave) dx[i] = sx[i];
+  }
+  if ((unsigned)lane < c.y) masks[o.y + lane] = stage_m[(size_t)t * 64 + lane];
+}
+
+// Staging arrays of the single-pass build: one set per device, grown on demand, shared by every schedule built on it
+// (a build holds the lock from its first kernel to its last: builds synchronise with the host anyway).
+struct S2Stage {
+  uint2 *cnt = nullptr;
+  S2Entry *e = nullptr;
+  S2Ext *x = nullptr;
+  ulonglong2 *m = nullptr;
+  size_t tiles = 0, tiles_x = 0;
+};
+static std::mutex g_stage_mu;
+static std::map<int, S2Stage> g_stage;
+
+static S2Stage *s2_stage(int nt, bool want_ext) {  // (call with g_stage_mu held) nullptr: use the two-pass build
+  static const bool two_pass = getenv("UNIRES_S2_BUILD_2PASS") != nullptr;
+  if (two_pass) return nullptr;
+  const size_t bytes = (size_t)nt * (kS2StageE * (sizeof(S2Entry) + (want_ext ? sizeof(S2Ext) : 0)) + 64 * sizeof(ulonglong2));
+  if (bytes > (512ull << 20)) return nullptr;  // (a 1 000^3 volume: two passes rather than half a gigabyte of staging)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  S2Stage &G = g_stage[dev];
+  if ((size_t)nt > G.tiles) {
+    if (G.cnt) (void)hipFree(G.cnt);
+    if (G.e) (void)hipFree(G.e);
+    if (G.m) (void)hipFree(G.m);
+    G.cnt = nullptr, G.e = nullptr, G.m = nullptr, G.tiles = 0;
+    const size_t n = (size_t)nt + nt / 8;
+    if (hipMalloc((void **)&G.cnt, n * sizeof(uint2)) != hipSuccess ||
+        hipMalloc((void **)&G.e, n * kS2StageE * sizeof(S2Entry)) != hipSuccess ||
+        hipMalloc((void **)&G.m, n * 64 * sizeof(ulonglong2)) != hipSuccess) {
+      (void)hipGetLastError();
+      if (G.cnt) (void)hipFree(G.cnt);
+      if (G.e) (void)hipFree(G.e);
+      if (G.m) (void)hipFree(G.m);
+      G.cnt = nullptr, G.e = nullptr, G.m = nullptr;
+      return nullptr;
+    }
+    G.tiles = n;
+  }
+  if (want_ext && (size_t)nt > G.tiles_x) {
+    if (G.x) (void)hipFree(G.x);
+    G.x = nullptr, G.tiles_x = 0;
+    const size_t n = (size_t)nt + nt / 8;
+    if (hipMalloc((void **)&G.x, n * kS2StageE * sizeof(S2Ext)) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    G.tiles_x = n;
+  }
+  return &G;
 }
 
 static thread_local bool t_thorough = true;
@@ -444,12 +524,30 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
   B.xtab = xtab, B.ytab = ytab, B.xd = xd;
   static const int exact = getenv("UNIRES_S2_EXACT") ? atoi(getenv("UNIRES_S2_EXACT")) : -1;  // (-1: as the plan asks)
   B.exact = exact >= 0 ? exact : (sched_thorough() ? 1 : 0);
-  hipLaunchKernelGGL(k_splat2_build<false>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off, (const int *)nullptr,
-                     (S2Entry *)nullptr, (S2Ext *)nullptr, (ulonglong2 *)nullptr, err_dev,
-                     (unsigned long long *)nullptr);
+  // One pass into per-tile staging slots + a compaction once the order is known (round 5; the schedule is the
+  // two-pass build's, bit for bit - tests/test_gpu_selection.py); two passes where there is no staging or a tile
+  // does not fit its slot.  unires_plan_set_repeat runs this for every channel after every rigid update.
+  std::lock_guard<std::mutex> stage_lock(g_stage_mu);
+  S2Stage *stage = s2_stage(nt, axis == 3);
   std::vector<uint2> cnt((size_t)nt), h((size_t)nt + 1);
-  if (hipMemcpy(cnt.data(), S.tile_off, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess)
-    return 1;
+  if (stage) {
+    hipLaunchKernelGGL(k_splat2_build<2>, dim3(nt), dim3(kWave), 0, 0, B, stage->cnt, (const int *)nullptr, stage->e,
+                       axis == 3 ? stage->x : (S2Ext *)nullptr, stage->m, err_dev, stats_dev);
+    int e0 = 0;
+    if (hipMemcpy(cnt.data(), stage->cnt, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    if (hipMemcpy(&e0, err_dev, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    if (e0 & 2) {  // a tile overflowed its slot: two passes (the counts are good)
+      stage = nullptr;
+      (void)hipMemset(S.scratch, 0, 4 * sizeof(unsigned long long));
+      if (e0 & 1) (void)hipMemset(err_dev, 1, 1);
+    }
+  } else {
+    hipLaunchKernelGGL(k_splat2_build<0>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off, (const int *)nullptr,
+                       (S2Entry *)nullptr, (S2Ext *)nullptr, (ulonglong2 *)nullptr, err_dev,
+                       (unsigned long long *)nullptr);
+    if (hipMemcpy(cnt.data(), S.tile_off, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess)
+      return 1;
+  }
   // Processing order.  (1) Contiguous runs of tiles per XCD with equal cost: a tile costs its
   // instructions + 11 for the epilogue (~5 us against ~0.45 us per instruction, tools/s2_timeline.py);
   // with equal tile COUNTS the XCD that holds the volume's first x slabs had a third less to do.
@@ -548,13 +646,18 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
     return 1;
   (void)hipMemset(S.entries + re, 0xff, kPad * sizeof(S2Entry));
   (void)hipMemset(S.masks + ri, 0, 8 * sizeof(ulonglong2));
-  hipLaunchKernelGGL(k_splat2_build<true>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off, (const int *)S.tile_geom,
-                     S.entries, S.ext, S.masks, err_dev, stats_dev);
+  if (stage)
+    hipLaunchKernelGGL(k_splat2_compact, dim3(nt), dim3(kWave), 0, 0, (const uint2 *)stage->cnt, (const S2Entry *)stage->e,
+                       axis == 3 ? (const S2Ext *)stage->x : (const S2Ext *)nullptr, (const ulonglong2 *)stage->m,
+                       (const int *)S.tile_geom, (const uint2 *)S.tile_off, S.entries, S.ext, S.masks);
+  else
+    hipLaunchKernelGGL(k_splat2_build<1>, dim3(nt), dim3(kWave), 0, 0, B, S.tile_off, (const int *)S.tile_geom,
+                       S.entries, S.ext, S.masks, err_dev, stats_dev);
   int herr = 0;
   unsigned long long hs[2] = {0, 0};
   if (hipMemcpy(&herr, err_dev, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 1;
   if (hipMemcpy(hs, stats_dev, sizeof(hs), hipMemcpyDeviceToHost) != hipSuccess) return 1;
-  if (herr) {
+  if (herr & 1) {
     if (verbose) fprintf(stderr, "[splat2] a tile exceeds the segment / instruction lists: general kernel used\n");
     return 1;
   }
