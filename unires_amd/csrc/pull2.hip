@@ -664,7 +664,10 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
   P.dbg = dbg;
   // the window, or the conv scratch that aliases it (64 rows x 65 floats) if that is larger
   const size_t scratch = gen ? (size_t)kP2Rows * (kWave + 1) : (size_t)(kP2TI * kP2TJ) * kP2Scr;
-  const size_t lds = std::max((size_t)W * H * kP2SZ, scratch) * sizeof(float);
+  // (UNIRES_P2_LDS_PAD=<bytes>: extra dynamic LDS per workgroup = fewer workgroups per CU - measurement of how the
+  // kernel shares a CU with other channels' kernels)
+  static const size_t lds_pad = getenv("UNIRES_P2_LDS_PAD") ? (size_t)atol(getenv("UNIRES_P2_LDS_PAD")) : 0;
+  const size_t lds = std::max((size_t)W * H * kP2SZ, scratch) * sizeof(float) + lds_pad;
   const dim3 grid((unsigned)p2_blocks(P.G, xd)), block(kBlock);
   {
     const long long nbi = (long long)grid.x / ((long long)P.G.nbc * P.G.nbj);
