@@ -11,5 +11,5 @@ ch=int(os.environ.get("CH","0"))
 plan=_channel_plan(x[ch],y[ch],sett.method,sett.do_proj)
 print("rigid", x[ch][0].po.rigid)
 p=torch.rand(y[ch].dim,device=dev); q=torch.empty_like(p)
-for _ in range(20): plan.matvec(p,rho,y[ch].lam,out=q)
+for _ in range(int(os.environ.get("NMV", "20"))): plan.matvec(p,rho,y[ch].lam,out=q)
 torch.cuda.synchronize()

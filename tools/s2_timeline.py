@@ -1,4 +1,6 @@
 # per-wave timeline of k_splat2 (-DUNIRES_S2_PROF build, UNIRES_S2_PROF_OUT=<file>): where a wave's life goes
+# per wave: [0] start, [1] end, [2] tiles, then per tile (first five): header arrived, stream end, p window arrived,
+# tile end (stores drained), instructions  (100 MHz ticks)
 import sys
 import numpy as np
 a = np.loadtxt(sys.argv[1], dtype=np.float64)
@@ -8,21 +10,19 @@ start, end, nt = us(a[:, 0]), us(a[:, 1]), a[:, 2].astype(int)
 print('waves %d  start: min %.1f med %.1f max %.1f us   end: min %.1f med %.1f p90 %.1f max %.1f us' % (
     len(a), start.min(), np.median(start), start.max(), end.min(), np.median(end), np.percentile(end, 90), end.max()))
 print('tiles per wave: ', np.bincount(nt))
-for k in sorted(set(nt)):
-    m = nt == k
-    print('  %d tiles: %5d waves, life med %.1f us, end med %.1f max %.1f' % (k, m.sum(), np.median(end[m] - start[m]), np.median(end[m]), end[m].max()))
-st, ep, ni = [], [], []
+ph = {k: [] for k in ('header', 'stream', 'pload', 'arith', 'ninstr')}
 for w in range(len(a)):
     prev = a[w, 0]
-    for i in range(min(nt[w], 9)):
-        ts, te, n = a[w, 3 + 3 * i], a[w, 4 + 3 * i], a[w, 5 + 3 * i]
-        st.append((ts - prev) / 100.0); ep.append((te - ts) / 100.0); ni.append(n)
+    for i in range(min(nt[w], 5)):
+        th, ts, tp, te, n = a[w, 3 + 5 * i: 8 + 5 * i]
+        if tp == 0:  # generic epilogue (no p-window stamp)
+            tp = ts
+        ph['header'].append((th - prev) / 100.0); ph['stream'].append((ts - th) / 100.0)
+        ph['pload'].append((tp - ts) / 100.0); ph['arith'].append((te - tp) / 100.0); ph['ninstr'].append(n)
         prev = te
-st, ep, ni = np.array(st), np.array(ep), np.array(ni)
-print('tiles %d  instr/tile med %.0f  stream: med %.2f mean %.2f us (%.3f us / instr)   epilogue: med %.2f mean %.2f p90 %.2f us' % (
-    len(st), np.median(ni), np.median(st), st.mean(), st.sum() / max(ni.sum(), 1), np.median(ep), ep.mean(), np.percentile(ep, 90)))
-# by tile ordinal
-for i in range(6):
-    s_i = [(a[w, 3 + 3 * i] - (a[w, 0] if i == 0 else a[w, 4 + 3 * (i - 1)])) / 100.0 for w in range(len(a)) if nt[w] > i]
-    e_i = [(a[w, 4 + 3 * i] - a[w, 3 + 3 * i]) / 100.0 for w in range(len(a)) if nt[w] > i]
-    if s_i: print('  tile #%d: n %5d  stream med %.2f  epilogue med %.2f us' % (i, len(s_i), np.median(s_i), np.median(e_i)))
+for k in ('header', 'stream', 'pload', 'arith'):
+    v = np.array(ph[k])
+    print('  %-7s med %.2f mean %.2f p90 %.2f us' % (k, np.median(v), v.mean(), np.percentile(v, 90)))
+ni = np.array(ph['ninstr']); st = np.array(ph['stream'])
+print('  tiles %d  instr/tile med %.0f  stream %.3f us / instr;  tile total mean %.2f us' % (
+    len(ni), np.median(ni), st.sum() / max(ni.sum(), 1), sum(np.array(ph[k]).mean() for k in ('header', 'stream', 'pload', 'arith'))))

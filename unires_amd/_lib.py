@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libunires_hip.so')
+# (UNIRES_LIB: another build of the SAME library - A/B measurements of kernel changes on one box; never a fallback)
+LIB_PATH = os.environ.get('UNIRES_LIB') or os.path.join(_HERE, 'libunires_hip.so')
 
 UNIRES_MAX_TAPS = 32
 OP = {'A': 0, 'At': 1, 'AtA': 2}

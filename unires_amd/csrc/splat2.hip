@@ -229,6 +229,30 @@ __global__ void __launch_bounds__(kWave)
   }
   S2_FENCE();
   __syncthreads();
+  // (r6) the slice of the conv_up table this tile needs: 64 consecutive entries from `kb` on - the tile's first grid
+  // index along the table's axis (grid z for axis 2 / 3, ui / uj for axis 0 / 1).  The splat keeps one slice per wave in
+  // LDS instead of the whole table per workgroup (6 - 8 KB: config 4's 385 entries pushed four 4-wave workgroups over
+  // a CU's 160 KB).  Axis 2 / 3 entries carry k0 relative to kb.  A tile that spans more than 64: general kernels.
+  int kb = 0;
+  if (B.axis >= 0) {
+    int lo = 1 << 30, hi = -(1 << 30);
+    for (int s0 = 0; s0 < nseg; s0 += kWave) {
+      const int s = s0 + lane;
+      if (s < nseg) {
+        const S2Seg q = segs[s];
+        const int a = B.axis == 0 ? (int)q.ui : (B.axis == 1 ? (int)q.uj : (int)q.k0);
+        const int b = (B.axis == 0 || B.axis == 1) ? a : a + (int)q.len - 1;
+        lo = min(lo, a), hi = max(hi, b);
+      }
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) lo = min(lo, __shfl_xor(lo, off, kWave)), hi = max(hi, __shfl_xor(hi, off, kWave));
+    if (nseg > 0) {
+      kb = lo;
+      if (hi - lo >= kWave && lane == 0) atomicOr(err, 1);
+    }
+  }
+  const int kb_k = (B.axis == 2 || B.axis == 3) ? kb : 0;  // what the entries' k field is relative to
   // ---- packing into 64-lane instructions: lane b is instruction b of the tile ----
   // ALIGNED mode (every segment walks one z plane per point, i.e. |dz/dk| <= 1): within each
   // 32-lane half, lane position = z plane (31 - plane when z decreases along the row).  The
@@ -342,7 +366,7 @@ __global__ void __launch_bounds__(kWave)
   }
   const int total_ent = __shfl(incl, kWave - 1, kWave);
   if (MODE != 1) {
-    if (lane == 0) counts[slot] = make_uint2((unsigned)total_ent, (unsigned)nbins);
+    if (lane == 0) counts[slot] = make_uint2((unsigned)total_ent, (unsigned)nbins | ((unsigned)kb << 8));
     if (MODE == 0) return;
     if (total_ent > kS2StageE) {
       if (lane == 0) atomicOr(err, 2);
@@ -375,7 +399,7 @@ __global__ void __launch_bounds__(kWave)
       const RowBase rb = affine_row(B.A, (float)q.ui, (float)q.uj);
       S2Entry e;
       e.rx = rb.x, e.ry = rb.y, e.rz = rb.z;
-      e.pk = s2_rowcode(B, q.ui, q.uj) | ((unsigned)(q.k0 - start + 64) << kS2RowBits);
+      e.pk = s2_rowcode(B, q.ui, q.uj) | ((unsigned)(q.k0 - kb_k - start + 64) << kS2RowBits);
       out[j] = e;
       if (B.axis == 3) {  // x / y part of the conv_up of this row: 2 x 2 x-space columns
         const float4 tx = B.xtab[q.ui], ty = B.ytab[q.uj];
@@ -419,7 +443,7 @@ __global__ void __launch_bounds__(kWave)
     uint4 *dx = reinterpret_cast<uint4 *>(ext) + 2 * (size_t)o.x;
     for (unsigned i = lane; i < 2u * c.x; i += kWave) dx[i] = sx[i];
   }
-  if ((unsigned)lane < c.y) masks[o.y + lane] = stage_m[(size_t)t * 64 + lane];
+  if ((unsigned)lane < (c.y & 0xffu)) masks[o.y + lane] = stage_m[(size_t)t * 64 + lane];  // (.y: instructions | table base << 8)
 }
 
 // Staging arrays of the single-pass build: one set per device, grown on demand, shared by every schedule built on it
@@ -473,6 +497,7 @@ static S2Stage *s2_stage(int nt, bool want_ext) {  // (call with g_stage_mu held
   return &G;
 }
 
+static int s2_active(int axis, int grid);
 static thread_local bool t_thorough = true;
 void sched_set_thorough(bool on) { t_thorough = on; }
 bool sched_thorough() { return t_thorough; }
@@ -483,6 +508,7 @@ void splat2_free(SplatSched &S) {
   if (S.masks) (void)hipFree(S.masks);
   if (S.tile_off) (void)hipFree(S.tile_off);
   if (S.tile_geom) (void)hipFree(S.tile_geom);
+  if (S.recs) (void)hipFree(S.recs);
   if (S.scratch) (void)hipFree(S.scratch);
   S = SplatSched();
 }
@@ -548,6 +574,9 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
     if (hipMemcpy(cnt.data(), S.tile_off, (size_t)nt * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess)
       return 1;
   }
+  // (the build kernel packs the tile's table base above its instruction count)
+  std::vector<int> kbv((size_t)nt);
+  for (int i = 0; i < nt; ++i) kbv[i] = (int)(cnt[i].y >> 8), cnt[i].y &= 0xffu;
   // Processing order.  (1) Contiguous runs of tiles per XCD with equal cost: a tile costs its
   // instructions + 11 for the epilogue (~5 us against ~0.45 us per instruction, tools/s2_timeline.py);
   // with equal tile COUNTS the XCD that holds the volume's first x slabs had a third less to do.
@@ -558,18 +587,23 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
   // order (neighbours share halos and schedule lines in the XCD's L2).
   constexpr double kEpilogueCost = 11.0;
   std::vector<int> geom((size_t)nt + 1);
+  // the launch this schedule is laid out for: `nwg` workgroups take tiles, partition x (an XCD when there are >= 8)
+  // is served by the workgroups b with b % np == x
+  const int nwg = s2_active(axis, s2_grid(dd));
+  const int np = std::min(8, std::max(nwg, 1));
+  std::vector<int> part_lo((size_t)np + 1, nt);
   {
     double total = 0.0;
     unsigned imax = 0;
     for (int i = 0; i < nt; ++i) total += (double)cnt[i].y + kEpilogueCost, imax = std::max(imax, cnt[i].y);
     int x = 1;
     double cum = 0.0;
-    S.xcd_lo[0] = 0;
-    for (int i = 0; i < nt && x < 8; ++i) {
+    part_lo[0] = 0;
+    for (int i = 0; i < nt && x < np; ++i) {
       cum += (double)cnt[i].y + kEpilogueCost;
-      while (x < 8 && cum >= total * x / 8.0) S.xcd_lo[x++] = i + 1;
+      while (x < np && cum >= total * x / (double)np) part_lo[x++] = i + 1;
     }
-    for (; x <= 8; ++x) S.xcd_lo[x] = nt;
+    for (; x <= np; ++x) part_lo[x] = nt;
     static const bool keep_order = getenv("UNIRES_SPLAT2_INDEX_ORDER") != nullptr;
     const unsigned cheap = keep_order ? 0u : imax / 2u;
     // (3) y strips.  In index order (z fastest, then y, then x) a tile's x neighbour comes a whole yz slab of
@@ -586,8 +620,8 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
     int strip = strip_env >= 0 ? strip_env
                                : (int)std::max<long long>(4, (1ll << 20) / ((long long)T::TX * T::TY * dd.z * 8));
     if (strip <= 0 || strip >= nty || keep_order) strip = nty;  // (= index order)
-    for (int xc = 0; xc < 8; ++xc) {
-      const int lo = S.xcd_lo[xc], hi = S.xcd_lo[xc + 1];
+    for (int xc = 0; xc < np; ++xc) {
+      const int lo = part_lo[xc], hi = part_lo[xc + 1];
       int u = lo;
       if (strip < nty && hi > lo) {
         // (generated, not sorted: this runs inside every unires_plan_set_repeat - a rigid update per channel and
@@ -612,13 +646,43 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
     }
     geom[nt] = 0;
   }
+  // (4) Who takes which tile: wave slot s of a partition (S slots) walks positions s, s + S, s + 2 S, ... of the order
+  // above - waves sweep the run together, and a wave knows its next tile a tile ahead (its header is prefetched).
+  // Round 6 measured two ways of levelling the waves' ends (4.33 tiles per wave at config 3: a third of the waves have a
+  // fifth 14 us tile, the rest end at 59 of 72 us, and a wave's end follows the predicted sum of its tiles' costs,
+  // correlation 0.94 over 4 096 waves - tools/s2_timeline.py) and dropped both:
+  //  * dealing the last (partial, or also the last whole) round AT BUILD TIME to the slots with the least predicted
+  //    work, longest first: 72.2 us where round-robin has 70.2 on the unrotated channel, no change on the rotated ones;
+  //  * a ticket queue for the tiles that do not fill a round (one L2 atomic per draw, 16 counters per XCD - atomics on
+  //    ONE address are served ~30 ns apart: 512 waves drawing from one counter cost the kernel 17 - 50 us): 72.1 / 72.4 us
+  //    against 71.2 / 68.7 static.
+  // A CU's 16 waves share its issue slots: what a wave does not use the others get, so what counts is the work per CU -
+  // which round-robin over workgroups that the dispatcher deals over the CUs levels by itself.
+  std::vector<int> pos_tile(geom.begin(), geom.begin() + nt);  // position -> tile
+  for (int xc = 0; xc <= 8; ++xc) S.pos_lo[xc] = part_lo[(size_t)std::min(xc, np)];
+  S.nwg = nwg;
+  // offsets in position order (geom: the u-th tile in that order, for the compaction / fill kernels)
+  std::vector<uint4> recs(pos_tile.size() + 1, make_uint4(0xffffffffu, 0u, 0u, 0u));
   unsigned re = 0, ri = 0;
-  for (int u = 0; u < nt; ++u) {
-    const uint2 c = cnt[geom[u]];
-    h[u] = make_uint2(re, ri);
-    re += c.x, ri += c.y;
+  {
+    using T = S2Tile;
+    const int nty = (dd.y + T::TY - 1) / T::TY, ntz = (dd.z + T::TZ - 1) / T::TZ;
+    int u = 0;
+    for (size_t pp = 0; pp < pos_tile.size(); ++pp) {
+      const int g = pos_tile[pp];
+      if (g < 0) continue;
+      const uint2 cg = cnt[g];
+      const unsigned tzi = (unsigned)(g % ntz), tyi = (unsigned)((g / ntz) % nty), txi = (unsigned)(g / (ntz * nty));
+      recs[pp] = make_uint4(txi | (tyi << 10) | (tzi << 20), re, ri, cg.y | ((unsigned)kbv[g] << 8));
+      geom[u] = g;
+      h[u] = make_uint2(re, ri);
+      re += cg.x, ri += cg.y;
+      ++u;
+    }
+    if (u != nt) return 1;  // (every tile exactly once)
+    h[nt] = make_uint2(re, ri);
+    geom[nt] = 0;
   }
-  h[nt] = make_uint2(re, ri);
   constexpr size_t kPad = 160;  // entries read (never used) past the end by the ring prefetch
   if ((size_t)re + kPad > S.cap_entries) {
     if (S.entries) (void)hipFree(S.entries);
@@ -644,6 +708,14 @@ int splat2_build(SplatSched &S, const Affine &A, const Affine &Ainv, Dim3i gd, D
     return 1;
   if (hipMemcpy(S.tile_geom, geom.data(), ((size_t)nt + 1) * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
     return 1;
+  if (recs.size() > S.cap_recs) {
+    if (S.recs) (void)hipFree(S.recs);
+    S.recs = nullptr;
+    const size_t cap = recs.size() + recs.size() / 8;
+    if (hipMalloc((void **)&S.recs, cap * sizeof(uint4)) != hipSuccess) return 1;
+    S.cap_recs = cap;
+  }
+  if (hipMemcpy(S.recs, recs.data(), recs.size() * sizeof(uint4), hipMemcpyHostToDevice) != hipSuccess) return 1;
   (void)hipMemset(S.entries + re, 0xff, kPad * sizeof(S2Entry));
   (void)hipMemset(S.masks + ri, 0, 8 * sizeof(ulonglong2));
   if (stage)
@@ -702,15 +774,14 @@ struct S2Args {
   size_t src_bytes;
   const float4 *tab;     // conv_up table (AXIS >= 0)
   int gn;                // entries in it
-  int tabn;              // LDS table length (padded with zeros: idle lanes index past gn)
   unsigned row_stride4;  // bytes per unit of the row code (see launch_splat2)
   unsigned tab_step4;    // bytes between the two x-space values of a grid voxel
   const S2Entry *entries;
+  size_t ent_bytes;      // (bytes behind it: LDS-DMA goes through a buffer resource)
   const S2Ext *ext;      // AXIS 3
   unsigned xs_sy4, xs_sx4;  // AXIS 3: bytes between x-space rows / slabs
   const ulonglong2 *masks;  // per instruction: {segment starts, active lanes}
-  const uint2 *tile_off;
-  const int *tile_geom;  // output tile of processing slot u
+  const uint4 *recs;     // per position of the walk: {tile, entry offset, instruction offset, instructions | table base << 8}
   int ntiles;
   Affine A;
   float alpha;
@@ -723,13 +794,13 @@ struct S2Args {
   const float *objb;
   int dbg;  // UNIRES_S2_DBG ablation bits (read only by -DUNIRES_ABLATE builds)
   int prio_rot;  // rotate the waves' issue priority per tile (UNIRES_S2_PRIO=0 switches it off)
-  int xlo[9];  // tile range [xlo[x], xlo[x + 1]) of partition x (an XCD when the grid has >= 8 workgroups)
+  int xlo[9];  // position range [xlo[x], xlo[x + 1]) of partition x (an XCD when the grid has >= 8 workgroups)
   int active;  // workgroups that take tiles (the rest of the grid only clears its partials)
   unsigned long long *prof;  // -DUNIRES_S2_PROF builds: per-wave timeline (100 MHz ticks)
 };
 
 template <int AXIS, int NW>
-__global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__restrict__ done) {
+__global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(4, 4))) k_splat2(S2Args P, const int *__restrict__ done) {
   if (done && *done) return;
   using T = S2Tile;
   constexpr int TX = T::TX, TY = T::TY, L = T::L, G = kWave / L;
@@ -738,28 +809,18 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
   __shared__ __align__(16) float acc_all[NW][N];
   __shared__ __align__(16) uint4 ring_all[NW][kWave];  // 2 chunks of 32 segment entries
   __shared__ __align__(16) uint4 ring2_all[AXIS == 3 ? NW : 1][AXIS == 3 ? 2 * kWave : 1];  // their S2Ext
-  extern __shared__ float4 tabs[];  // CONV: {byte offset, alpha w0, alpha w1, -}, tabn entries
+  // CONV: the 64 entries of the conv_up table from the tile's base on, {byte offset, alpha w0, alpha w1, grid
+  // coordinate as a float}, one slice per wave, refilled per tile (r6; was the whole table per workgroup)
+  __shared__ __align__(16) float4 tabs_all[CONV ? NW : 1][CONV ? kWave : 1];
   const int lane = threadIdx.x & (kWave - 1), grp = lane / L, gl = lane & (L - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *acc = acc_all[wave];
   uint4 *ring = ring_all[wave];
   uint4 *ring2 = ring2_all[AXIS == 3 ? wave : 0];
+  float4 *tabs = tabs_all[CONV ? wave : 0];
   const Dim3i dd = P.dd;
   const float *__restrict__ pin = P.p;
   float *__restrict__ dst = P.dst;
-  if (CONV) {
-    const unsigned step4 = (AXIS == 2 || AXIS == 3) ? 4u : P.tab_step4;  // the per-lane table runs along z
-    for (int i = threadIdx.x; i < P.tabn; i += kWave * NW) {
-      float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i >= 64 && i - 64 < P.gn) e = P.tab[i - 64];
-      // (.w = the grid coordinate the entry belongs to, as a float: the z-profile kernels take k from
-      // the table instead of converting it, and the 16-byte read costs the LDS 4 cycles where the 12-byte
-      // one costs 8)
-      tabs[i] = make_float4(__int_as_float((int)(step4 * (unsigned)__float_as_int(e.x))), P.alpha * e.y,
-                            P.alpha * e.z, (float)(i - 64));
-    }
-    __syncthreads();
-  }
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(P.src, P.src_bytes);
   // XCD-aware persistent schedule: workgroup b sits on XCD b % 8; each XCD walks one contiguous
   // run of tiles so that neighbouring tiles (shared stencil halos, schedule lines) share an L2.
@@ -797,7 +858,39 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
   // the fixed ranking that unbalances.)
   const int hw_slot = (int)(__builtin_amdgcn_s_getreg(6148) & 3u);  // HW_ID.wave_id
   int round = 0;
-  for (int t = t_lo + slot; t < t_hi; t += slots, ++round) {
+  // (r6) The walk.  A tile's 16-byte record comes by SCALAR load (constant address space: the schedule is read-only),
+  // the next tile's one is requested as a tile starts and travels under its stream.  What a tile needs per LANE before
+  // its first instruction - the masks of instruction `lane`, the first 64 segment entries, its slice of the conv_up
+  // table - is requested at the head of the PREVIOUS tile's epilogue and lands under it: three dependent trips to
+  // memory (tile -> offsets -> masks / entries) stood at the head of every tile, 1.6 of its 14 us.
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  const __attribute__((address_space(4))) u4v *recs = (const __attribute__((address_space(4))) u4v *)P.recs;
+  const u4v rec_none = {0xffffffffu, 0u, 0u, 0u};
+  int t = t_lo + slot;
+  u4v rec = t < t_hi ? recs[t] : rec_none;
+  // The entries and the table slice go straight into LDS (LDS-DMA: lane l's 16 bytes land on bytes 16 l of the ring /
+  // the slice - no register carried through the epilogue); the masks' load is issued AFTER them, so that the wait
+  // the compiler puts in front of the masks' first use covers both (loads return in order).
+  ulonglong2 h_mk = make_ulonglong2(0ull, 0ull);
+  auto issue_header = [&](const u4v &rc, int ln) {
+    const int ni = (int)(rc.w & 0xffu);
+    const __amdgpu_buffer_rsrc_t rs_ent = make_rsrc(P.entries, P.ent_bytes);
+    S2_FENCE();
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ent, (__attribute__((address_space(3))) void *)ring, 16,
+                                             16u * (rc.y + (unsigned)ln), 0, 0, 0);
+    if (CONV) {
+      const __amdgpu_buffer_rsrc_t rs_tab = make_rsrc(P.tab, (size_t)P.gn * sizeof(float4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_tab, (__attribute__((address_space(3))) void *)tabs, 16,
+                                               16u * (unsigned)min(max((int)(rc.w >> 8) + ln, 0), P.gn - 1), 0, 0, 0);
+    }
+    S2_FENCE();
+    // (every lane loads - lanes past the tile's last instruction read the zero padding or a later tile's masks, never
+    // used: an unconditional load is always issued, and the wait on it is what orders the DMA above)
+    h_mk = P.masks[rc.z + (unsigned)min(ln, max(ni - 1, 0))];
+    (void)ni;
+  };
+  if (rec.x != 0xffffffffu) issue_header(rec, lane);
+  for (; rec.x != 0xffffffffu; ++round) {
     if (P.prio_rot) {
       switch ((hw_slot + round) & 3) {
         case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -806,29 +899,53 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
         default: __builtin_amdgcn_s_setprio(3); break;
       }
     }
-    const S2TileGeom g = s2_tile(P.tile_geom[t], dd);
-    const int x0 = g.x0, y0 = g.y0, z0 = g.z0, ex = g.ex, ey = g.ey, ez = g.ez;
-    const uint2 off0 = P.tile_off[t], off1 = P.tile_off[t + 1];
-    const int ninstr = (int)(off1.y - off0.y);
-    const uint4 *E = reinterpret_cast<const uint4 *>(P.entries) + off0.x;
+    const int x0 = (int)(rec.x & 1023u) * TX, y0 = (int)((rec.x >> 10) & 1023u) * TY, z0 = (int)(rec.x >> 20) * T::TZ;
+    const int ex = min(TX, dd.x - x0), ey = min(TY, dd.y - y0), ez = min(T::TZ, dd.z - z0);
+    const int ninstr = (int)(rec.w & 0xffu);
+    const int tab_base = (int)(rec.w >> 8);
+    const unsigned ent0 = rec.y;
+    const uint4 *E = reinterpret_cast<const uint4 *>(P.entries) + ent0;
+    const int t_next = t + slots;
+    const u4v rec_next = t_next < t_hi ? recs[t_next] : rec_none;
     // lane l keeps the segment-start mask of instruction l (a tile has at most 64 of them)
-    const ulonglong2 mymask = lane < ninstr ? P.masks[off0.y + lane] : make_ulonglong2(0ull, 0ull);
+    int lp = lane;  // (laundered per tile, as in the epilogue: the prologue's addresses are not held through the stream)
+    asm volatile("" : "+v"(lp));
+    const ulonglong2 mymask = h_mk;
     const int mlo_v = (int)(unsigned)mymask.x, mhi_v = (int)(unsigned)(mymask.x >> 32);
     const int alo_v = (int)(unsigned)mymask.y, ahi_v = (int)(unsigned)(mymask.y >> 32);
-    S2_FENCE();
-    // segment ring: chunks 0 and 1 now, chunk 2 in flight in registers
-    ring[lane] = E[lane];
+    // the masks are here => so are the ring's chunks 0 and 1 and the table slice (issued before them)
+    asm volatile("" ::"v"(mlo_v), "v"(mhi_v), "v"(alo_v), "v"(ahi_v) : "memory");
+    // segment ring: chunk 2 in flight in registers
     uint4 pre = make_uint4(0u, 0u, 0u, 0u);
-    if (lane < 32) pre = E[64 + lane];
-    const uint4 *X = reinterpret_cast<const uint4 *>(P.ext) + 2 * (size_t)off0.x;  // AXIS 3: 2 uint4 per entry
+    if (lp < 32) pre = E[64 + lp];
+    if (CONV) {
+      // (.w = the grid coordinate the entry belongs to, as a float: the z-profile kernels take k from the table
+      // instead of converting it, and the 16-byte read costs the LDS 4 cycles where the 12-byte one costs 8)
+      const unsigned step4 = (AXIS == 2 || AXIS == 3) ? 4u : P.tab_step4;  // the per-lane table runs along z
+      const float4 raw = tabs[lp];
+      tabs[lp] = make_float4(__int_as_float((int)(step4 * (unsigned)__float_as_int(raw.x))), P.alpha * raw.y,
+                             P.alpha * raw.z, (float)(tab_base + lp));
+    }
+#ifdef UNIRES_S2_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // per tile: {header here, stream end, p window here, end, instructions}
+    if (pw && lane == 0 && ptile < 5) pw[3 + 5 * ptile] = wall_clock64();
+#endif
+    const uint4 *X = reinterpret_cast<const uint4 *>(P.ext) + 2 * (size_t)ent0;  // AXIS 3: 2 uint4 per entry
     uint4 pre2 = make_uint4(0u, 0u, 0u, 0u);
     if (AXIS == 3) {
       ring2[lane] = X[lane], ring2[kWave + lane] = X[kWave + lane];
       pre2 = X[2 * kWave + lane];  // chunk 2 = 32 entries = 64 uint4
     }
-    for (int i = lane; i < N / 4; i += kWave)
-      reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float xb = (float)(x0 - 1), yb = (float)(y0 - 1), zb = (float)(z0 - 1);
+    {
+      // (the zeros and the lane's address are made HERE, per tile: kept live across the instruction stream as loop
+      // invariants they cost five of its 128 registers, and the allocator parked them in scratch memory)
+      int lz = lane;
+      float zr = 0.f;
+      asm volatile("" : "+v"(lz), "+v"(zr));
+      for (int i = lz; i < N / 4; i += kWave) reinterpret_cast<float4 *>(acc)[i] = make_float4(zr, zr, zr, zr);
+    }
+    // accumulator cell of global floor cell (fx, fy, fz): acc_t[(fx * SY + fy) * SZ + fz]
+    float *acc_t = acc - (((x0 - 1) * SY + (y0 - 1)) * SZ + (z0 - 1));
     int chunk_lo = 0;  // the ring holds chunks chunk_lo and chunk_lo + 1 (32 entries each)
     int eb = 0;        // first entry of the next instruction, relative to the tile
     S2_FENCE();
@@ -842,7 +959,7 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
     // splat(): coordinates, weights and the two LDS update groups.  Two batches are in flight: the
     // source loads of batch b + 1 travel while batch b is splatted.
     struct Batch {
-      float w0[kU], w1[kU], s0[kU], s1[kU], kf[kU], rx[kU], ry[kU], rz[kU];
+      float w0[kU], w1[kU], s0[kU], s1[kU], gx[kU], gy[kU], gz[kU];  // (coordinates, not their four ingredients: a register less per slot)
       unsigned long long amask[kU];
     };
     auto fetch = [&](Batch &Bt, int p0) {
@@ -875,18 +992,20 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
       for (int u = 0; u < kU; ++u) {
         const int sl = (int)__builtin_amdgcn_mbcnt_hi(mhi[u], __builtin_amdgcn_mbcnt_lo(mlo[u], 0u));
         const uint4 e = ring[(ebu[u] + sl) & 63];
-        Bt.rx[u] = __uint_as_float(e.x), Bt.ry[u] = __uint_as_float(e.y), Bt.rz[u] = __uint_as_float(e.z);
+        const float rx = __uint_as_float(e.x), ry = __uint_as_float(e.y), rz = __uint_as_float(e.z);
+        float kf;
         const unsigned code = e.w & kS2RowIdle;
         // (idle lanes in front of an instruction's first segment see k < its k0: the tables carry 64
         // zero entries in front for them)
+        // (axis 2 / 3: k relative to the tile's table base - the index into its slice for every active lane)
         const int k = (int)(e.w >> kS2RowBits) + lane_m64;
-        Bt.kf[u] = (float)k;
+        kf = (float)k;
         Bt.w0[u] = P.alpha, Bt.w1[u] = 0.f, Bt.s0[u] = 1.f, Bt.s1[u] = 0.f;
         if (S2_ABL(8)) {
         } else if (AXIS == 3) {
           // conv_up along x, y and z: 2 x 2 x-space columns (per segment) x the z pair (per lane)
           const uint4 xa = ring2[2 * ((ebu[u] + sl) & 63)], xb = ring2[2 * ((ebu[u] + sl) & 63) + 1];
-          const float4 tb = tabs[k + 64];
+          const float4 tb = tabs[k & 63];
           const unsigned a = xa.x + (unsigned)__float_as_int(tb.x);
           const uint2 p00 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a, 0, 0));
           const uint2 p01 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a + P.xs_sy4, 0, 0));
@@ -898,18 +1017,19 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
           const float z10 = tb.y * __uint_as_float(p10.x) + tb.z * __uint_as_float(p10.y);
           const float z11 = tb.y * __uint_as_float(p11.x) + tb.z * __uint_as_float(p11.y);
           Bt.w0[u] = 1.f;
+          kf = tb.w;
           Bt.s0[u] = __uint_as_float(xa.y) * z00 + __uint_as_float(xa.z) * z01 + __uint_as_float(xa.w) * z10 +
                      __uint_as_float(xb.x) * z11;
           (void)code;
         } else if (AXIS == 2) {
-          const float4 tb = tabs[k + 64];
-          Bt.kf[u] = tb.w;
+          const float4 tb = tabs[k & 63];
+          kf = tb.w;
           const unsigned a = __umul24(code, P.row_stride4) + (unsigned)__float_as_int(tb.x);
           const uint2 pr = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a, 0, 0));
           Bt.w0[u] = tb.y, Bt.w1[u] = tb.z, Bt.s0[u] = __uint_as_float(pr.x), Bt.s1[u] = __uint_as_float(pr.y);
         } else if (AXIS == 0 || AXIS == 1) {
           const unsigned ui = code >> 9, uj = code & 511u;
-          const float4 tb = tabs[(AXIS == 0 ? ui : uj) + 64];
+          const float4 tb = tabs[((int)(AXIS == 0 ? ui : uj) - tab_base) & 63];
           const unsigned a = __umul24(AXIS == 0 ? uj : ui, P.row_stride4) + (unsigned)__float_as_int(tb.x) +
                              4u * (unsigned)k;
           Bt.w0[u] = tb.y, Bt.w1[u] = tb.z;
@@ -917,6 +1037,9 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
         } else {
           Bt.s0[u] = buf_load(rsrc, __umul24(code, P.row_stride4) + 4u * (unsigned)k, 0);
         }
+        Bt.gx[u] = fmaf(c0, kf, rx) + t0;
+        Bt.gy[u] = fmaf(c1, kf, ry) + t1;
+        Bt.gz[u] = fmaf(c2, kf, rz) + t2;
       }
     };
     // (Tried and dropped: the four weight products and the eight accumulate FMAs as v_pk_mul_f32 /
@@ -925,16 +1048,16 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
     auto splat = [&](const Batch &Bt) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        const float gx = fmaf(c0, Bt.kf[u], Bt.rx[u]) + t0;
-        const float gy = fmaf(c1, Bt.kf[u], Bt.ry[u]) + t1;
-        const float gz = fmaf(c2, Bt.kf[u], Bt.rz[u]) + t2;
-        // local coordinates: the subtraction of the (integer) tile base is exact
-        const float lxf = gx - xb, lyf = gy - yb, lzf = gz - zb;
-        const float wx1 = __builtin_amdgcn_fractf(lxf), wy1 = __builtin_amdgcn_fractf(lyf),
-                    wz1 = __builtin_amdgcn_fractf(lzf);
+        const float gx = Bt.gx[u], gy = Bt.gy[u], gz = Bt.gz[u];
+        // floor cell and weights exactly as the pull computes them (floor, then g - floor: the build kernel's
+        // collision tests floor the same global coordinate); the tile's base enters once, as an integer offset of
+        // the accumulator pointer (r6: was a subtraction per coordinate in front of v_fract - three instructions
+        // more, and exact only for tiles off the volume's low faces)
+        const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+        const float wx1 = gx - fx, wy1 = gy - fy, wz1 = gz - fz;
         const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
-        // cell index in float (exact: small integers), one conversion
-        const float cf = fmaf(lxf - wx1, (float)XS, fmaf(lyf - wy1, (float)YS, lzf - wz1));
+        // cell index in float (exact: integers below 2^24), one conversion
+        const float cf = fmaf(fx, (float)XS, fmaf(fy, (float)YS, fz));
         const int cell = (int)cf;
         const float v = Bt.w0[u] * Bt.s0[u] + Bt.w1[u] * Bt.s1[u];
         const float vx0 = v * wx0, vx1 = v * wx1;
@@ -942,13 +1065,16 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
         S2_FENCE();
         if (S2_ABL(4)) dot += (double)(a00 + a01 + a10 + a11 + (float)cell);
         if (__builtin_amdgcn_inverse_ballot_w64(Bt.amask[u]) && !S2_ABL(4)) {
-          float *q = acc + cell;
+          float *q = acc_t + cell;
           {
             const float o00 = q[0], o01 = q[YS], o10 = q[XS], o11 = q[XS + YS];
             q[0] = o00 + a00 * wz0, q[YS] = o01 + a01 * wz0, q[XS] = o10 + a10 * wz0,
             q[XS + YS] = o11 + a11 * wz0;
           }
           S2_FENCE();
+#ifdef S2_EXP_MASKB
+          if ((lane & (S2_EXP_MASKB - 1)) == 0)  // (measurement only, wrong results: what a mostly-masked second group costs)
+#endif
           {
             const float o00 = q[1], o01 = q[YS + 1], o10 = q[XS + 1], o11 = q[XS + YS + 1];
             q[1] = o00 + a00 * wz1, q[YS + 1] = o01 + a01 * wz1, q[XS + 1] = o10 + a10 * wz1,
@@ -981,11 +1107,21 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
     }
     S2_FENCE();
 #ifdef UNIRES_S2_PROF
-    if (pw && lane == 0 && ptile < 9) pw[3 + 3 * ptile] = wall_clock64(), pw[5 + 3 * ptile] = (unsigned long long)ninstr;
+    if (pw && lane == 0 && ptile < 5) pw[4 + 5 * ptile] = wall_clock64(), pw[7 + 5 * ptile] = (unsigned long long)ninstr;
 #endif
     // ---- epilogue: q = [q +] acc + a0 p + c DtD p ; dot += p*q  (one row per lane group) ----
-    if (S2_ABL(2)) continue;
-    const bool fast_xy = pin != nullptr && !P.accumulate && ex == TX && ey == TY && dd.numel() < (1ull << 29);
+    // the next tile's per-lane header: requested now, it lands under this epilogue
+    {
+      // (the ring's chunk in flight may never have been used: let it land NOW, or the compiler waits for everything -
+      // the header included - the first time the epilogue writes one of its registers)
+      asm volatile("" ::"v"(pre.x), "v"(pre.y), "v"(pre.z), "v"(pre.w));
+      if (AXIS == 3) asm volatile("" ::"v"(pre2.x), "v"(pre2.y), "v"(pre2.z), "v"(pre2.w));
+      int lh = lane;
+      asm volatile("" : "+v"(lh));
+      if (rec_next.x != 0xffffffffu) issue_header(rec_next, lh);
+    }
+    double dtile = 0.0;  // this tile's part of the dot
+    const bool fast_xy = !S2_ABL(2) && pin != nullptr && !P.accumulate && ex == TX && ey == TY && dd.numel() < (1ull << 29);
     if (fast_xy) {
       // Whole tiles, wherever they lie: x / y stencil neighbours outside the volume read as zeros
       // through an out-of-range buffer offset (the volume's first and last x slabs are a quarter of
@@ -997,16 +1133,31 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
       // the other registers.  Buffer addressing: a per-lane byte offset computed once per tile +
       // scalar row offsets.
       static_assert(TX == 8 && TY == 4 && G == 2, "epilogue register window is written for 8 x 4 tiles");
+      // (r6) Instruction count is what this kernel runs out of, so the epilogue is written to be short:
+      //  * no selects for the volume's faces: a neighbour that the reference's forward differences do not see is
+      //    loaded from the CENTRE's own address (c - c = 0: the absent backward term of the first slab / row / plane),
+      //    a neighbour beyond the last slab / row / plane from an out-of-range offset (0: the zero bound);
+      //  * every difference once: p[s + 1] - p[s] is the forward term of s and the backward term of s + 1; along z the
+      //    difference of adjacent lanes is one DPP subtraction, and (backward - forward) a second one;
+      //  * the 16 accumulator reads issued together, ahead of the arithmetic; no branch per output row (lanes of the
+      //    z apron store to an out-of-range offset and add nothing to the dot).
+      // (lane-dependent values of the epilogue are derived from a laundered copy of the lane index, so that none of
+      // them is hoisted out of the tile loop and held in a register through the instruction stream)
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      const int gl = le & (L - 1), grp = le / L;
       const int kz = z0 - 1 + gl;
-      const bool out_z = gl >= 1 && gl <= ez, lz_ok = kz > 0, hz_ok = kz + 1 < dd.z;
+      const bool out_z = gl >= 1 && gl <= ez;
       const unsigned sxb = 4u * (unsigned)(dd.y * dd.z), syb = 4u * (unsigned)dd.z;
-      // byte offset of (first owned slab, first owned row, plane kz); the slab / row below and above
-      // the owned 4 x 4 get their own offsets so that they can point out of range
       constexpr unsigned kOob = 0x80000000u;
       const int xg = x0 + 4 * grp;
-      const unsigned e1 = 4u * (unsigned)((xg * dd.y + y0) * dd.z + kz);
-      const unsigned elo = xg > 0 ? e1 - sxb : kOob, ehi = xg + 4 < dd.x ? e1 : kOob;
-      const unsigned eyl = y0 > 0 ? e1 - syb : kOob, eyh = y0 + TY < dd.y ? e1 : kOob;
+      // byte offset of (first owned slab, first owned row, plane kz): plane -1 reads plane 0 (so that the backward
+      // difference of plane 0 comes out as zero), planes >= dd.z read zeros
+      const unsigned e0 = 4u * (unsigned)((xg * dd.y + y0) * dd.z + max(kz, 0));
+      const unsigned e1 = kz < dd.z ? e0 : kOob;
+      const unsigned elo = xg > 0 ? e1 - sxb : e1, ehi = xg + 4 < dd.x ? e1 : kOob;
+      const unsigned eyl = y0 > 0 ? e1 - syb : e1, eyh = y0 + TY < dd.y ? e1 : kOob;
+      const unsigned est = out_z ? e0 : kOob;
       const __amdgpu_buffer_rsrc_t rp = make_rsrc(pin, dd.numel() * 4),
                                    rd = make_rsrc(dst, dd.numel() * 4),
                                    rb = make_rsrc(P.objb ? P.objb : pin, dd.numel() * 4);
@@ -1017,6 +1168,7 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
 #pragma unroll
         for (int la = 0; la < 6; ++la) {
           const bool halo_x = sa == 0 || sa == 5, halo_y = la == 0 || la == 5;
+          // (the low halos sit at the centre's own row offsets when they alias it: first slab / first row)
           pv[sa][la] = (halo_x && halo_y) ? 0.f
                        : sa == 0 ? buf_load(rp, elo, (unsigned)(la - 1) * syb)
                        : sa == 5 ? buf_load(rp, ehi, 4u * sxb + (unsigned)(la - 1) * syb)
@@ -1024,44 +1176,62 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
                        : la == 5 ? buf_load(rp, eyh, (unsigned)(sa - 1) * sxb + 4u * syb)
                                  : buf_load(rp, e1, (unsigned)(sa - 1) * sxb + (unsigned)(la - 1) * syb);
         }
+#ifdef UNIRES_S2_PROF
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (pw && lane == 0 && ptile < 5) pw[5 + 5 * ptile] = wall_clock64();
+#endif
       auto rows = [&](auto obj_tag) {
         constexpr bool OBJ = decltype(obj_tag)::value;
+        float ob[4][4];
+        if (OBJ) {
+#pragma unroll
+          for (int sa = 1; sa <= 4; ++sa)
+#pragma unroll
+            for (int la = 1; la <= 4; ++la)
+              ob[sa - 1][la - 1] = buf_load(rb, e1, (unsigned)(sa - 1) * sxb + (unsigned)(la - 1) * syb);
+        }
+        // x and y differences, each once: p[s + 1][l] - p[s][l] is the forward term of slab s and the backward term of s + 1
+        float dxp[4];
+#pragma unroll
+        for (int la = 1; la <= 4; ++la) dxp[la - 1] = pv[1][la] - pv[0][la];
+        double dt = 0.0;
 #pragma unroll
         for (int sa = 1; sa <= 4; ++sa) {
-          float ob[4];
-          if (OBJ) {
+          float dy[5], av[4];  // (the slab's four accumulator reads issued together, ahead of its arithmetic)
 #pragma unroll
-            for (int la = 1; la <= 4; ++la) ob[la - 1] = buf_load(rb, e1, (unsigned)(sa - 1) * sxb + (unsigned)(la - 1) * syb);
-          }
+          for (int la = 1; la <= 4; ++la) av[la - 1] = arow[((sa - 1) * SY + (la - 1)) * SZ];
+#pragma unroll
+          for (int la = 0; la <= 4; ++la) dy[la] = pv[sa][la + 1] - pv[sa][la];
 #pragma unroll
           for (int la = 1; la <= 4; ++la) {
             const float c = pv[sa][la];
-            const float vzm = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), 0x138, 0xf, 0xf, false));
-            const float vzp = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), 0x130, 0xf, 0xf, false));
-            float q = arow[((sa - 1) * SY + (la - 1)) * SZ];
-            // (forward differences with a zero bound: the backward term of the volume's first
-            // slab is absent, the forward term of its last slab sees a zero neighbour)
-            const float xf = pv[sa + 1][la] - c, xbk = (sa == 1 && xg == 0) ? 0.f : c - pv[sa - 1][la];
-            const float yf = pv[sa][la + 1] - c, ybk = (la == 1 && y0 == 0) ? 0.f : c - pv[sa][la - 1];
-            const float zf = (hz_ok ? vzp : 0.f) - c, zbk = lz_ok ? c - vzm : 0.f;
+            // zf = p[k + 1] - p[k] (lane + 1 minus this lane); zbk = the same difference one lane down
+            const float vzp = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), 0x130, 0xf, 0xf, true));
+            const float zf = vzp - c;
+            const float zbk = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(zf), 0x138, 0xf, 0xf, true));
+            const float xf = pv[sa + 1][la] - c, xbk = dxp[la - 1];
+            dxp[la - 1] = xf;
+            const float yf = dy[la], ybk = dy[la - 1];
             const float st = P.cx * (xbk - xf) + P.cy * (ybk - yf) + P.cz * (zbk - zf);
-            q += P.a0 * c + st;
-            if (out_z) {
-              if (OBJ) {
-                dot += (double)obj_term(q, ob[la - 1], c);
-              } else {
-                buf_store(q, rd, e1, (unsigned)(sa - 1) * sxb + (unsigned)(la - 1) * syb);
-                dot += (double)__fmul_rn(c, q);
-              }
+            const float q = av[la - 1] + (P.a0 * c + st);
+            if (OBJ) {
+              dt += (double)obj_term(q, ob[sa - 1][la - 1], c);
+            } else {
+              buf_store(q, rd, est, (unsigned)(sa - 1) * sxb + (unsigned)(la - 1) * syb);
+              dt += (double)__fmul_rn(c, q);
             }
           }
         }
+        dtile = out_z ? dt : 0.0;
       };
       if (P.objb)
         rows(std::true_type{});
       else
         rows(std::false_type{});
-    } else {
+    } else if (!S2_ABL(2)) {
+      int lg = lane;  // (laundered: see the fast form)
+      asm volatile("" : "+v"(lg));
+      const int gl = lg & (L - 1), grp = lg / L;
 #pragma unroll 4
       for (int r = grp; r < TX * TY; r += G) {
         const int lx = r / TY, ly = r % TY, lz = gl;
@@ -1075,14 +1245,16 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
           q += P.a0 * pc + st;
         }
         if (P.accumulate) q += dst[idx];
-        matvec_emit(dst, idx, q, pc, P.objb, P.partials != nullptr, dot);
+        matvec_emit(dst, idx, q, pc, P.objb, P.partials != nullptr, dtile);
       }
     }
 #ifdef UNIRES_S2_PROF
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (pw && lane == 0 && ptile < 9) pw[4 + 3 * ptile] = wall_clock64();
+    if (pw && lane == 0 && ptile < 5) pw[6 + 5 * ptile] = wall_clock64();
     ++ptile;
 #endif
+    dot += dtile;
+    t = t_next, rec = rec_next;
   }
 #ifdef UNIRES_S2_PROF
   if (pw && lane == 0) pw[1] = wall_clock64(), pw[2] = (unsigned long long)ptile;
@@ -1095,14 +1267,14 @@ __global__ void __launch_bounds__(kWave *NW) k_splat2(S2Args P, const int *__res
 
 int splat2_blocks(Dim3i dd) { return s2_grid(dd) * kS2Waves; }  // partials written
 
-// Workgroups of k_splat2<axis> the device holds at once with `lds` bytes of table (asked of the
-// runtime once per kernel and table size), rounded down to whole rounds over the 8 XCDs.
-static int s2_active(int axis, size_t lds, int grid) {
-  static std::map<std::pair<int, size_t>, int> cache;
+// Workgroups of k_splat2<axis> that take tiles: as many of the grid as the device holds at once (asked of the
+// runtime once per kernel), rounded down to whole rounds over the 8 XCDs.  (All LDS is static since r6: four
+// 4-wave workgroups per CU for every axis but 3, whose per-segment x / y tables make it three.)
+static int s2_active(int axis, int grid) {
+  static std::map<int, int> cache;
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
-  const auto key = std::make_pair(axis, lds);
-  auto it = cache.find(key);
+  auto it = cache.find(axis);
   if (it == cache.end()) {
     int per_cu = 0, dev = 0, ncu = 0;
     const void *fn = axis == 0   ? (const void *)k_splat2<0, kS2Waves>
@@ -1111,12 +1283,12 @@ static int s2_active(int axis, size_t lds, int grid) {
                      : axis == 3 ? (const void *)k_splat2<3, kS2Waves>
                                  : (const void *)k_splat2<-1, kS2Waves>;
     static const int force = getenv("UNIRES_SPLAT2_RESIDENT") ? atoi(getenv("UNIRES_SPLAT2_RESIDENT")) : 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave * kS2Waves, lds) != hipSuccess) per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave * kS2Waves, 0) != hipSuccess) per_cu = 0;
     if (force > 0) per_cu = force;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 0;
     const int n = per_cu > 0 && ncu > 0 ? per_cu * ncu : 1 << 30;
-    it = cache.emplace(key, n).first;
+    it = cache.emplace(axis, n).first;
   }
   int n = std::min(grid, it->second);
   if (n >= 8) n -= n % 8;
@@ -1127,8 +1299,8 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
                   unsigned row_stride, unsigned tab_step, unsigned xs_sy, unsigned xs_sx, const Affine &A,
                   float alpha,
                   const PushEpilogue &ep, float *dst, Dim3i dd, const int *done, hipStream_t st) {
-  if (!S.valid || S.ntiles != s2_ntiles(dd)) return 1;
-  if (S.axis >= 0 && !tab_dev) return 1;
+  if (!S.valid || S.ntiles != s2_ntiles(dd) || !S.recs) return 1;
+  if (S.axis >= 0 && (!tab_dev || gn < 1)) return 1;
   if (S.axis == 3 && !S.ext) return 1;
   if (src_numel >= (1ull << 30)) return 1;  // 32-bit byte offsets into the source
   if ((unsigned long long)row_stride * 4ull >= (1ull << 24)) return 1;  // 24-bit multiply
@@ -1136,20 +1308,17 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
   P.src = src;
   P.src_bytes = src_numel * sizeof(float);  // buffer range check: idle lanes may point anywhere
   P.tab = tab_dev, P.gn = gn;
-  P.tabn = S.axis >= 0 ? gn + 2 * kWave : 0;
   P.row_stride4 = 4u * row_stride, P.tab_step4 = 4u * tab_step;
-  P.entries = S.entries, P.ext = S.ext, P.xs_sy4 = 4u * xs_sy, P.xs_sx4 = 4u * xs_sx, P.masks = S.masks, P.tile_off = S.tile_off, P.tile_geom = S.tile_geom, P.ntiles = S.ntiles;
+  P.entries = S.entries, P.ent_bytes = S.cap_entries * sizeof(S2Entry), P.ext = S.ext, P.xs_sy4 = 4u * xs_sy, P.xs_sx4 = 4u * xs_sx, P.masks = S.masks, P.recs = S.recs, P.ntiles = S.ntiles;
   P.A = A, P.alpha = alpha;
   P.p = ep.p, P.a0 = ep.a0, P.cx = ep.cx, P.cy = ep.cy, P.cz = ep.cz;
   P.dst = dst, P.dd = dd, P.accumulate = ep.accumulate, P.partials = ep.partials, P.objb = ep.objb;
   static const int dbg = getenv("UNIRES_S2_DBG") ? atoi(getenv("UNIRES_S2_DBG")) : 0;
   P.dbg = dbg;
   const dim3 grid(s2_grid(dd)), block(kWave * kS2Waves);
-  if (grid.x >= 8) {
-    for (int x = 0; x <= 8; ++x) P.xlo[x] = S.xcd_lo[x];
-  } else {  // fewer workgroups than XCDs: one equal share per workgroup
-    for (int x = 0; x <= 8; ++x) P.xlo[x] = (int)std::min<long long>(S.ntiles, ((long long)S.ntiles * x + grid.x - 1) / grid.x);
-  }
+  P.active = s2_active(S.axis, (int)grid.x);
+  if (P.active != S.nwg) return 1;  // (the walk was laid out for another launch shape)
+  for (int x = 0; x <= 8; ++x) P.xlo[x] = S.pos_lo[x];
   static const int prio_rot = getenv("UNIRES_S2_PRIO") ? atoi(getenv("UNIRES_S2_PRIO")) : 1;
   P.prio_rot = prio_rot;
   P.prof = nullptr;
@@ -1160,31 +1329,12 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
   (void)hipMemsetAsync(prof_dev, 0, nprof * sizeof(unsigned long long), st);
   P.prof = prof_dev;
 #endif
-  const size_t lds = S.axis >= 0 ? (size_t)P.tabn * sizeof(float4) : 0;
-  if (lds > 24 * 1024) return 1;
-  P.active = s2_active(S.axis, lds, (int)grid.x);
-  // A table too long for four 4-wave workgroups per CU (each carries its own copy): ONE 16-wave
-  // workgroup per CU shares a single copy - the same 16 waves and the same wave -> tile walk.
-  // (UNIRES_SPLAT2_WIDE: 0 never, 2 wherever the grid allows it - the tests' way to reach the form on small volumes)
-  static const int wide_env = getenv("UNIRES_SPLAT2_WIDE") ? atoi(getenv("UNIRES_SPLAT2_WIDE")) : 1;
-  constexpr int kWide = 16, kRatio = kWide / kS2Waves;
-  if (wide_env != 0 && (P.active < (int)grid.x || wide_env == 2) && S.axis >= 0 && S.axis <= 2 &&
-      grid.x % kRatio == 0 && grid.x / kRatio >= 8) {
-    const dim3 gridw(grid.x / kRatio), blockw(kWave * kWide);
-    P.active = (int)gridw.x;
-    switch (S.axis) {
-      case 0: hipLaunchKernelGGL((k_splat2<0, kWide>), gridw, blockw, lds, st, P, done); break;
-      case 1: hipLaunchKernelGGL((k_splat2<1, kWide>), gridw, blockw, lds, st, P, done); break;
-      default: hipLaunchKernelGGL((k_splat2<2, kWide>), gridw, blockw, lds, st, P, done); break;
-    }
-    return 0;
-  }
   switch (S.axis) {
-    case 0: hipLaunchKernelGGL((k_splat2<0, kS2Waves>), grid, block, lds, st, P, done); break;
-    case 1: hipLaunchKernelGGL((k_splat2<1, kS2Waves>), grid, block, lds, st, P, done); break;
-    case 2: hipLaunchKernelGGL((k_splat2<2, kS2Waves>), grid, block, lds, st, P, done); break;
-    case 3: hipLaunchKernelGGL((k_splat2<3, kS2Waves>), grid, block, lds, st, P, done); break;
-    default: hipLaunchKernelGGL((k_splat2<-1, kS2Waves>), grid, block, lds, st, P, done); break;
+    case 0: hipLaunchKernelGGL((k_splat2<0, kS2Waves>), grid, block, 0, st, P, done); break;
+    case 1: hipLaunchKernelGGL((k_splat2<1, kS2Waves>), grid, block, 0, st, P, done); break;
+    case 2: hipLaunchKernelGGL((k_splat2<2, kS2Waves>), grid, block, 0, st, P, done); break;
+    case 3: hipLaunchKernelGGL((k_splat2<3, kS2Waves>), grid, block, 0, st, P, done); break;
+    default: hipLaunchKernelGGL((k_splat2<-1, kS2Waves>), grid, block, 0, st, P, done); break;
   }
 #ifdef UNIRES_S2_PROF
   {

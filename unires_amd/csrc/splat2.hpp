@@ -22,7 +22,7 @@ constexpr unsigned kS2RowBits = 19, kS2RowIdle = (1u << kS2RowBits) - 1u;
 
 struct S2Entry {     // one segment of an instruction (16 bytes)
   float rx, ry, rz;  // affine_row(A, ui, uj): the row part of the coordinate arithmetic
-  unsigned pk;       // row code (19 bits) | (k0 - first lane + 64) << 19
+  unsigned pk;       // row code (19 bits) | (k0 - first lane + 64) << 19; axis 2 / 3: k0 relative to the tile's table base
 };
 
 struct S2Ext {  // axis 3 (conv_up along all three axes): per-segment x / y part of the conv_up
@@ -35,12 +35,17 @@ struct SplatSched {
   S2Entry *entries = nullptr;            // device
   S2Ext *ext = nullptr;                  // device, axis 3 only (same indexing as entries)
   ulonglong2 *masks = nullptr;           // device, per instruction: {bit l-1 set <=> a segment starts at lane l, active lanes}
-  uint2 *tile_off = nullptr;             // device, ntiles + 1 {entry offset, instruction offset}, in PROCESSING order
-  int *tile_geom = nullptr;              // device, ntiles: the output tile of processing slot u (cheap tiles last, see splat2_build)
+  uint2 *tile_off = nullptr;             // device, ntiles + 1 {entry offset, instruction offset}, in PROCESSING order (build kernels)
+  int *tile_geom = nullptr;              // device, ntiles: the output tile of processing slot u (build kernels)
+  // device, one 16-byte record per position of the walk (splat2_build (4)): {tile index x | y << 10 | z << 20,
+  // entry offset, instruction offset, instructions | conv_up table base << 8}
+  uint4 *recs = nullptr;
+  size_t cap_recs = 0;
+  int pos_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // position range of each partition (XCD): contiguous tiles of equal COST
+  int nwg = 0;                            // workgroups the layout was made for (the launch must use as many)
   unsigned long long *scratch = nullptr; // device: {error flag, points, instructions} of a build
   size_t cap_entries = 0, cap_instr = 0, cap_tiles = 0;
   int ntiles = 0;
-  int xcd_lo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // tile range of each XCD: contiguous, equal COST (instructions + epilogue)
   bool valid = false;
   int axis = -1;      // -1 direct source; 0..2 conv_up along that axis; 3 along all three
   double fill = 0.0;  // active lanes / issued lanes (diagnostic)
