@@ -246,8 +246,12 @@ __device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, uns
 // L2.  For kernels whose neighbouring blocks share halo lines, renumber so that every XCD
 // works on ONE contiguous chunk of the volume: halos are then re-read from that XCD's L2
 // instead of crossing the fabric (measured on k_ata_aligned: fetch 98 MB -> see DESIGN 4).
+// (r6: for ANY grid size - XCD x takes nb / 8 blocks, one more if x < nb % 8.  The first form did this for multiples
+// of 8 only and left every other grid dealt round-robin: config 4's pull, 28 518 workgroups, had each window column
+// fetched by every XCD that met it - 643 MB for a 226 MB volume.)
 __device__ __forceinline__ int xcd_chunked_block(int b, int nb) {
-  return (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+  const int x = b & 7, r = nb & 7;
+  return x * (nb >> 3) + (x < r ? x : r) + (b >> 3);
 }
 
 // One term of the CG objective sum x (Ax - 2b): A(x).sub_(2*b).mul_(x), nitorch

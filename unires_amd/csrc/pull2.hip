@@ -82,7 +82,8 @@ struct P2Geom {
 constexpr int kP2Rec = 4 + 3 * kP2SZ4 + 2;
 constexpr unsigned kP2OobBase = 0x80000000u;  // + any in-window offset (< 2^31) stays out of range
 
-__global__ void k_pull2_plan(P2Geom G, int nblk, float tol, int W, int H, int *__restrict__ rec) {
+__global__ void k_pull2_plan(P2Geom G, int nblk, float tol, int W, int H, int *__restrict__ rec,
+                             unsigned char *__restrict__ cls) {
   const int blk = blockIdx.x * blockDim.x + threadIdx.x;
   if (blk >= nblk) return;
   constexpr int SZ4 = kP2SZ4;
@@ -143,11 +144,15 @@ __global__ void k_pull2_plan(P2Geom G, int nblk, float tol, int W, int H, int *_
   r[3] = (empty ? 1 : 0) | (xyin ? 2 : 0) | (partial ? 4 : 0);
   r[4 + 3 * SZ4] = (int)kP2OobBase;  // slot the padding items of the table point at
   r[5 + 3 * SZ4] = 0;
+  // what the workgroup will cost (pull2_build deals the workgroups over the XCDs by it): 0 all outside the field of
+  // view (it writes zeros), 1 plain, 2 with the FOV mask and / or range tests on its staging items
+  cls[blk] = empty ? 0 : ((inside && xyin) ? 1 : 2);
 }
 
 struct P2Args {
   const float *src;
   const int *rec;
+  const int *wtab;   // dispatch index -> position of the walk (pull2_build: equal COST per XCD); nullptr: by formula
   const int2 *itab;  // per staging item: {4 * plane group, byte offset inside the window} ...
   const int *itab2;  // ... and cxl | cyl << 16 (column inside the window; read by workgroups at the volume's x / y faces)
   float inv_m;       // 1 / G.m
@@ -197,7 +202,8 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   // 508 MB for a 226 MB volume there (profiles/r03_traffic_other_configs.jsonl), and HBM is what bounds
   // it at that size.  (Where one block row's windows DO fit - config 3: 3.2 MB - the plain order is kept:
   // bands cut by the XCD runs' ends fetched 79 MB instead of 72 there.)
-  const int blk0 = xcd_chunked_block((int)blockIdx.x, (int)gridDim.x);
+  const int blk0 = P.wtab ? ((const __attribute__((address_space(4))) int *)P.wtab)[blockIdx.x]
+                          : xcd_chunked_block((int)blockIdx.x, (int)gridDim.x);
   const int bc = blk0 % G.nbc, pair = blk0 / G.nbc;
   const int nbi = (int)gridDim.x / (G.nbc * G.nbj);
   const int bandh = P.band;  // kP2Band, or nbi (= plain row-major order) where a block row's windows fit the L2
@@ -484,6 +490,7 @@ static bool same_geom(const P2Geom &a, const P2Geom &b) { return memcmp(&a, &b, 
 void pull2_free(PullPlan &Q) {
   if (Q.rec) (void)hipFree(Q.rec);
   if (Q.itab) (void)hipFree(Q.itab);
+  if (Q.wtab) (void)hipFree(Q.wtab);
   Q = PullPlan();
 }
 
@@ -568,6 +575,22 @@ static long long p2_blocks(const P2Geom &G, Dim3i xd) {
   return (long long)((xd.x + G.oi - 1) / G.oi) * G.nbj * G.nbc;
 }
 
+// dynamic LDS of a workgroup: the window, or the conv scratch that aliases it (64 rows x 65 floats) if that is larger
+static size_t p2_lds(int W, int H, bool gen) {
+  const size_t scratch = gen ? (size_t)kP2Rows * (kWave + 1) : (size_t)(kP2TI * kP2TJ) * kP2Scr;
+  return std::max((size_t)W * H * kP2SZ, scratch) * sizeof(float);
+}
+
+// block rows walked together (see the kernel's block mapping): all of them where a block row's windows fit the L2
+static int p2_band(const P2Geom &G, long long nblk, size_t lds) {
+  const long long nbi = nblk / ((long long)G.nbc * G.nbj);
+  const bool row_fits_l2 = (double)G.nbj * G.nbc * (double)lds < 3.5e6;
+  int band = (int)(row_fits_l2 ? std::max<long long>(nbi, 1) : kP2Band);
+  static const int band_env = getenv("UNIRES_P2_BAND") ? atoi(getenv("UNIRES_P2_BAND")) : 0;  // (measurement)
+  if (band_env > 0) band = (int)std::min<long long>(band_env, std::max<long long>(nbi, 1));
+  return band;
+}
+
 int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd, Dim3i gd, float tol) {
   Q.valid = false;
   static const bool off = getenv("UNIRES_NO_PULL2") != nullptr;
@@ -603,10 +626,78 @@ int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd,
     }
     if (hipMemcpy(Q.itab, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return 1;
   }
+  if ((size_t)nblk > Q.wtab_cap) {
+    if (Q.wtab) (void)hipFree(Q.wtab);
+    Q.wtab = nullptr;
+    // (the table, then one class byte per workgroup)
+    if (hipMalloc((void **)&Q.wtab, (size_t)nblk * (sizeof(int) + 1)) != hipSuccess) return 1;
+    Q.wtab_cap = (size_t)nblk;
+  }
+  unsigned char *cls_dev = reinterpret_cast<unsigned char *>(Q.wtab + Q.wtab_cap);
   hipLaunchKernelGGL(k_pull2_plan, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, G, (int)nblk, tol, W, H,
-                     Q.rec);
+                     Q.rec, cls_dev);
   Q.tol = tol;
-  if (hipStreamSynchronize(nullptr) != hipSuccess) return 1;  // (the plan kernel ran on the NULL stream; other streams are not waited for)
+  // Who runs where (r6).  Workgroup b runs on XCD b % 8, so every XCD gets the same NUMBER of workgroups; walking the
+  // volume in one contiguous run per XCD (shared window columns stay in its L2) gave the XCDs at the volume's ends
+  // the workgroups that see nothing - config 4: XCD 7 done at 114 of 168 us - and those at its faces the expensive
+  // ones (FOV mask, range tests on staging: config 3: XCD 0 / 1 done at 45 us, the others at 40.5;
+  // tools/p2_timeline.py).  Here the non-empty workgroups are cut into 8 contiguous runs of equal COST (plain 8,
+  // masked / range-tested 10), and each XCD's count is made up with empty ones.
+  Q.use_wtab = false;
+  {
+    std::vector<unsigned char> cls((size_t)nblk);
+    if (hipMemcpy(cls.data(), cls_dev, (size_t)nblk, hipMemcpyDeviceToHost) != hipSuccess) return 1;  // (synchronises)
+    static const bool off_tab = getenv("UNIRES_P2_WTAB") && atoi(getenv("UNIRES_P2_WTAB")) == 0;
+    const bool gen = !(T.n[0] == 1 && T.s[0] == 1 && T.n[1] == 1 && T.s[1] == 1);
+    const int bandh = p2_band(G, nblk, p2_lds(W, H, gen));
+    const long long nbi = nblk / ((long long)G.nbc * G.nbj);
+    if (!off_tab && nblk >= 64) {
+      // the walk: position w -> workgroup record (the kernel's own mapping)
+      auto blk_of = [&](long long w) {
+        const long long bc = w % G.nbc, pair = w / G.nbc;
+        const long long band = pair / ((long long)bandh * G.nbj), rem = pair - band * ((long long)bandh * G.nbj);
+        const long long bh = std::min<long long>(bandh, nbi - band * bandh);
+        const long long bj = rem / bh, bi = band * bandh + (rem - bj * bh);
+        return (bi * G.nbj + bj) * G.nbc + bc;
+      };
+      std::vector<int> ne, em;
+      ne.reserve((size_t)nblk);
+      long long cost_all = 0;
+      std::vector<unsigned char> wc((size_t)nblk);
+      for (long long w = 0; w < nblk; ++w) {
+        const unsigned char c = cls[(size_t)blk_of(w)];
+        wc[(size_t)w] = c;
+        if (c == 0) em.push_back((int)w); else ne.push_back((int)w), cost_all += c == 1 ? 8 : 10;
+      }
+      std::vector<int> tab((size_t)nblk, 0);
+      size_t in = 0, ie = 0;
+      long long cum = 0;
+      bool ok = true;
+      for (int x = 0; x < 8 && ok; ++x) {
+        const long long cnt = nblk / 8 + (x < (int)(nblk % 8) ? 1 : 0);
+        // what the XCDs after this one can still take bounds how few this one may take
+        long long later = 0;
+        for (int y = x + 1; y < 8; ++y) later += nblk / 8 + (y < (int)(nblk % 8) ? 1 : 0);
+        long long i = 0;
+        const long long target = cost_all * (x + 1) / 8;
+        while (i < cnt && in < ne.size() && (cum < target || (long long)(ne.size() - in) > later || x == 7)) {
+          const int w = ne[in++];
+          cum += wc[(size_t)w] == 1 ? 8 : 10;
+          tab[(size_t)(x + 8 * i++)] = w;
+        }
+        while (i < cnt && ie < em.size()) tab[(size_t)(x + 8 * i++)] = em[ie++];
+        while (i < cnt && in < ne.size()) {  // (no empty one left: non-empty ones after all)
+          const int w = ne[in++];
+          cum += wc[(size_t)w] == 1 ? 8 : 10;
+          tab[(size_t)(x + 8 * i++)] = w;
+        }
+        ok = i == cnt;
+      }
+      ok = ok && in == ne.size() && ie == em.size();
+      if (ok && hipMemcpy(Q.wtab, tab.data(), (size_t)nblk * sizeof(int), hipMemcpyHostToDevice) == hipSuccess)
+        Q.use_wtab = true;
+    }
+  }
   static const bool verbose = getenv("UNIRES_PULL2_VERBOSE") != nullptr;
   if (verbose) {  // one line per plan: what the workgroups of this operator look like
     std::vector<int> rec((size_t)nblk * kP2Rec);
@@ -662,20 +753,13 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
   P.dst = dst, P.xd = xd, P.tol = tol, P.W = W;
   static const int dbg = getenv("UNIRES_P2_DBG") ? atoi(getenv("UNIRES_P2_DBG")) : 0;
   P.dbg = dbg;
-  // the window, or the conv scratch that aliases it (64 rows x 65 floats) if that is larger
-  const size_t scratch = gen ? (size_t)kP2Rows * (kWave + 1) : (size_t)(kP2TI * kP2TJ) * kP2Scr;
   // (UNIRES_P2_LDS_PAD=<bytes>: extra dynamic LDS per workgroup = fewer workgroups per CU - measurement of how the
   // kernel shares a CU with other channels' kernels)
   static const size_t lds_pad = getenv("UNIRES_P2_LDS_PAD") ? (size_t)atol(getenv("UNIRES_P2_LDS_PAD")) : 0;
-  const size_t lds = std::max((size_t)W * H * kP2SZ, scratch) * sizeof(float) + lds_pad;
+  const size_t lds = p2_lds(W, H, gen) + lds_pad;
   const dim3 grid((unsigned)p2_blocks(P.G, xd)), block(kBlock);
-  {
-    const long long nbi = (long long)grid.x / ((long long)P.G.nbc * P.G.nbj);
-    const bool row_fits_l2 = (double)P.G.nbj * P.G.nbc * (double)lds < 3.5e6;
-    P.band = (int)(row_fits_l2 ? std::max<long long>(nbi, 1) : kP2Band);
-    static const int band_env = getenv("UNIRES_P2_BAND") ? atoi(getenv("UNIRES_P2_BAND")) : 0;  // (measurement)
-    if (band_env > 0) P.band = (int)std::min<long long>(band_env, std::max<long long>(nbi, 1));
-  }
+  P.band = p2_band(P.G, (long long)grid.x, p2_lds(W, H, gen));
+  P.wtab = Q.use_wtab ? Q.wtab : nullptr;
   P.prof = nullptr;
 #ifdef UNIRES_P2_PROF
   static unsigned long long *prof_dev = nullptr;

@@ -12,6 +12,9 @@ struct PullPlan {
   size_t cap = 0;      // workgroup records allocated
   int *itab = nullptr; // device: per staging item {plane group * 4, byte offset inside the window, cxl | cyl << 16, 0}
   size_t itab_cap = 0; // items allocated
+  int *wtab = nullptr; // device: dispatch index -> position of the kernel's walk (equal cost per XCD), then a class byte per workgroup
+  size_t wtab_cap = 0;
+  bool use_wtab = false;
   bool valid = false;
   float tol = 0.f;               // in-FOV tolerance the all-outside flags were computed for
   unsigned char key[192] = {0};  // the geometry it was built for
