@@ -55,8 +55,11 @@ enum unires_cg_stop {
   UNIRES_STOP_MAXGAIN = 1,        /* anything else, e.g. 'max_gain' as UniRes passes
                                      (_update.py:145): obj = 0.5*sum(x*(A(x)-2b)),
                                      one extra A(x) per iteration (reference-faithful)     */
-  UNIRES_STOP_MAXGAIN_RECURRED = 2 /* same objective from the recurred residual,
+  UNIRES_STOP_MAXGAIN_RECURRED = 2, /* same objective from the recurred residual,
                                      obj = -0.5*sum(x*(b+r)): no extra A(x) (build-side)   */
+  UNIRES_STOP_MAXGAIN_GUARDED = 3  /* the recurred objective while its gain is >= 4 tol, the fresh one
+                                     (mode 1's) from there on: mode 1's decisions - both values of a close
+                                     gain are fresh ones - at about mode 2's cost                          */
 };
 
 enum unires_precond {

@@ -13,7 +13,11 @@ LIB_PATH = os.environ.get('UNIRES_LIB') or os.path.join(_HERE, 'libunires_hip.so
 UNIRES_MAX_TAPS = 32
 OP = {'A': 0, 'At': 1, 'AtA': 2}
 REGIME_IDENTITY, REGIME_DENOISE, REGIME_SUPERRES = 0, 1, 2
-STOP = {'e': 0, 'max_gain': 1, 'max_gain_recurred': 2}
+# nitorch cg(stop=...): 'e' = residual norm; anything else = the objective 0.5 sum x (A(x) - 2b) (UniRes passes 'max_gain').
+# 'max_gain' runs GUARDED (C ABI mode 3): the objective comes from the recurred residual while its gain is >= 4 x tolerance
+# and is evaluated afresh - a second A(x), nitorch's own arithmetic - from there on, so close decisions are nitorch's;
+# 'max_gain_fresh' evaluates it afresh after every iteration (mode 1), 'max_gain_recurred' never (mode 2).
+STOP = {'e': 0, 'max_gain': 3, 'max_gain_guarded': 3, 'max_gain_fresh': 1, 'max_gain_recurred': 2}
 PRECOND = {'none': 0, 'identity': 0, 'jacobi': 1, 'fft': 2}
 
 c_i32x3 = C.c_int32 * 3

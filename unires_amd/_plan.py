@@ -249,7 +249,7 @@ class ChannelPlan:
             raise ValueError('unires_amd: cg updates x in place and needs it contiguous')
         self._y(x, 'x')
         s = stop if stop in _lib.STOP else stop[0].lower()
-        mode = _lib.STOP[s] if s in _lib.STOP else (0 if s == 'e' else 1)
+        mode = _lib.STOP[s] if s in _lib.STOP else (0 if s == 'e' else 3)
         max_iter = int(max_iter)
         if sync:
             it = C.c_int32(0)
@@ -286,7 +286,7 @@ def cg_many(plans, bs, xs, rho, lams, streams, max_iter=20, tolerance=1e-3, stop
     n = len(plans)
     lib = plans[0].lib
     s = stop if stop in _lib.STOP else stop[0].lower()
-    mode = _lib.STOP[s] if s in _lib.STOP else (0 if s == 'e' else 1)
+    mode = _lib.STOP[s] if s in _lib.STOP else (0 if s == 'e' else 3)
     for pl, b, x in zip(plans, bs, xs):
         pl._y(b, 'b')
         if not x.is_contiguous():

@@ -1409,7 +1409,8 @@ static int cg_enqueue_iters(unires_plan *pl, float rho, float lam, const float *
       }
       pl->tev.emplace_back(ev0, ev1);
     }
-    const bool recur = check && stop_mode == UNIRES_STOP_MAXGAIN_RECURRED;
+    const bool guarded = check && stop_mode == UNIRES_STOP_MAXGAIN_GUARDED;
+    const bool recur = check && (stop_mode == UNIRES_STOP_MAXGAIN_RECURRED || guarded);
     int obj_kind = 0;
     if (check && stop_mode == UNIRES_STOP_RESIDUAL) obj_kind = 1;
     if (recur) obj_kind = 2;
@@ -1428,13 +1429,21 @@ static int cg_enqueue_iters(unires_plan *pl, float rho, float lam, const float *
         if (fftpre_apply(pl->fft, pl->r, pl->fft.z, st)) return fail(UNIRES_ERR_HIP, "hipFFT execution failed");
         launch_dot(pl->r, pl->fft.z, ny, pl->part0, done, st);
       }
-      launch_sc_beta(S, pl->part0, pl->part1, gv, kk, obj_kind, tol, obj_kind ? hostw : nullptr, st);
+      if (guarded)
+        launch_sc_beta_guarded(S, pl->part0, pl->part1, gv, kk, tol, hostw, st);
+      else
+        launch_sc_beta(S, pl->part0, pl->part1, gv, kk, obj_kind, tol, obj_kind ? hostw : nullptr, st);
       launch_update_p(S, fft ? pl->fft.z : pl->r, pl->p, ny, M, lazy_x ? x : nullptr, st);
     }
     if (check && stop_mode == UNIRES_STOP_MAXGAIN) {
       // objective sum x (Ax - 2b) folded into the matvec epilogue: A(x) is never stored
       const int go = matvec(pl, rho, lam, x, pl->ax, pl->part1, done, st, b);
       launch_sc_obj(S, pl->part1, go, kk, tol, hostw, st);
+    }
+    if (guarded) {
+      // ... the same, but its kernels return at entry unless k_sc_beta_guarded asked for it (cg.hip)
+      const int go = matvec(pl, rho, lam, x, pl->ax, pl->part1, &S->skip_fresh, st, b);
+      launch_sc_obj_guarded(S, pl->part1, go, kk, tol, hostw, st);
     }
   }
   return UNIRES_OK;
@@ -1655,7 +1664,7 @@ static int cg_check_args(unires_plan *plan, float rho, float lam, const float *b
   if (max_iter < 0) return fail(UNIRES_ERR_ARG, "max_iter out of range");
   if (max_iter > kMaxCgIter && !(tol > 0.0))
     return fail(UNIRES_ERR_ARG, "max_iter beyond 4096 needs a tolerance (the solve is then enqueued in chunks)");
-  if (stop_mode < 0 || stop_mode > 2) return fail(UNIRES_ERR_ARG, "bad stop mode");
+  if (stop_mode < 0 || stop_mode > 3) return fail(UNIRES_ERR_ARG, "bad stop mode");
   if (precond_mode < UNIRES_PRECOND_IDENTITY || precond_mode > UNIRES_PRECOND_FFT)
     return fail(UNIRES_ERR_UNSUPPORTED, "preconditioner modes: identity (0), Jacobi (1), FFT (2)");
   if (precond_mode != UNIRES_PRECOND_IDENTITY &&

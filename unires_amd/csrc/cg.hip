@@ -422,6 +422,8 @@ __global__ void __launch_bounds__(kBlock)
     st->beta = 0.0;
     st->gen += 1u;
     if (check) record_obj(st, 0, mode == UNIRES_STOP_RESIDUAL ? sqrt(rr) : 0.5 * ob, 0.0);
+    // (the objective of the start is a fresh one: r = b - A(x) was just computed)
+    st->skip_fresh = 1, st->fresh_prev_ok = 1, st->rec_prev = 0.5 * ob, st->fresh_prev = 0.5 * ob, st->gain_rec = 0.0;
     publish(st, hostw);
   }
 }
@@ -463,6 +465,61 @@ __global__ void __launch_bounds__(kBlock)
   const double ob = sum_partials(part_obj, g);
   if (threadIdx.x == 0) {
     record_obj(st, k, 0.5 * ob, tol);
+    publish(st, hostw);
+  }
+}
+
+// Guarded 'max_gain' (UNIRES_STOP_MAXGAIN_GUARDED).  nitorch decides |gain| < tol on the objective 0.5 sum x (A(x) - 2b):
+// a second A(x) per iteration.  The same objective follows from the recurred residual, -0.5 sum x (b + r), for free;
+// the two differ by 0.5 x.(r_recurred - r_true), rounding drift.  Far from the threshold the drift cannot change the
+// decision: while the recurred gain is >= kGuardHi x tol the solve goes on without the second A(x).  Below that the
+// fresh objective is computed every iteration, so that by the time a decision is close BOTH values in the gain are
+// fresh ones - nitorch's own arithmetic; where the previous fresh value is missing (the gain fell through the band in
+// one step, short solves) the consistent recurred pair decides.  A solve's LAST iteration always costs the second A(x).
+constexpr double kGuardHi = 4.0;
+__global__ void __launch_bounds__(kBlock)
+    k_sc_beta_guarded(CgState *st, const double *part_rr, const double *part_obj, int g, int k, double tol,
+                      unsigned long long *hostw) {
+  if (st->done) return;
+  if (k < 0) k = st->iters + 1;
+  const double rr = sum_partials(part_rr, g);
+  const double ob = sum_partials(part_obj, g);
+  if (threadIdx.x == 0) {
+    constexpr int kRing = kMaxCgIter + 1;
+    const double rz0 = st->rz;
+    st->rz = rr;
+    st->rzpp[k & 1] = rr;
+    st->beta = rr / rz0;
+    st->iters = k;
+    const double rec = -0.5 * ob;
+    st->obj[k % kRing] = rec;  // (replaced by the fresh value if that is computed)
+    st->obj_max = fmax(st->obj_max, rec);
+    st->obj_min = fmin(st->obj_min, rec);
+    const double gain = (st->rec_prev - rec) / (st->obj_max - st->obj_min);
+    st->gain_rec = gain;
+    st->rec_prev = rec;
+    const bool far = fabs(gain) >= kGuardHi * tol;  // (NaN: not far - the fresh objective decides, as in nitorch)
+    st->skip_fresh = far ? 1 : 0;
+    if (far) st->fresh_prev_ok = 0;
+    if (!isfinite(rec)) st->done = 1, st->skip_fresh = 1;
+    publish(st, hostw);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_sc_obj_guarded(CgState *st, const double *part_obj, int g, int k, double tol, unsigned long long *hostw) {
+  if (st->done || st->skip_fresh) return;
+  if (k < 0) k = st->iters;
+  const double ob = sum_partials(part_obj, g);
+  if (threadIdx.x == 0) {
+    constexpr int kRing = kMaxCgIter + 1;
+    const double fresh = 0.5 * ob;
+    st->obj[k % kRing] = fresh;
+    st->obj_max = fmax(st->obj_max, fresh);
+    st->obj_min = fmin(st->obj_min, fresh);
+    const double gain = st->fresh_prev_ok ? (st->fresh_prev - fresh) / (st->obj_max - st->obj_min) : st->gain_rec;
+    st->fresh_prev = fresh, st->fresh_prev_ok = 1;
+    if (fabs(gain) < tol || !isfinite(fresh)) st->done = 1, st->skip_fresh = 1;
     publish(st, hostw);
   }
 }
@@ -561,6 +618,14 @@ void launch_sc_beta(CgState *s, const double *part_rr, const double *part_obj, i
 void launch_sc_obj(CgState *s, const double *part, int g, int k, double tol, unsigned long long *hostw,
                    hipStream_t st) {
   hipLaunchKernelGGL(k_sc_obj, dim3(1), dim3(kBlock), 0, st, s, part, g, k, tol, hostw);
+}
+void launch_sc_beta_guarded(CgState *s, const double *part_rr, const double *part_obj, int g, int k, double tol,
+                            unsigned long long *hostw, hipStream_t st) {
+  hipLaunchKernelGGL(k_sc_beta_guarded, dim3(1), dim3(kBlock), 0, st, s, part_rr, part_obj, g, k, tol, hostw);
+}
+void launch_sc_obj_guarded(CgState *s, const double *part, int g, int k, double tol, unsigned long long *hostw,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(k_sc_obj_guarded, dim3(1), dim3(kBlock), 0, st, s, part, g, k, tol, hostw);
 }
 void launch_sum_to(const double *part, int g, double *out, hipStream_t st) {
   hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(kBlock), 0, st, part, g, out);

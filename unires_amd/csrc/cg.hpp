@@ -13,6 +13,10 @@ struct CgState {  // lives in device memory, owned by the plan
   double rzpp[2];  // r.z of iterations k (slot k & 1) and k - 1: the folded kernels read one slot while
                    // workgroup 0 of the same launch writes the other
   double obj[kMaxCgIter + 1];  // objective trace; iteration k at slot k % (kMaxCgIter + 1)
+  // UNIRES_STOP_MAXGAIN_GUARDED (k_sc_beta_guarded / k_sc_obj_guarded)
+  int skip_fresh;        // 1: this iteration's fresh objective (a second A(x)) is not needed - its kernels return at entry
+  int fresh_prev_ok;     // fresh_prev holds the FRESH objective of the previous iteration
+  double rec_prev, fresh_prev, gain_rec;  // recurred objective of the previous iteration; this iteration's recurred gain
 };
 
 // Progress word of a solve, published by its scalar kernels to host-mapped memory (chunked solves,
@@ -49,6 +53,12 @@ void launch_sc_beta(CgState *s, const double *part_rr, const double *part_obj, i
                     int obj_kind, double tol, unsigned long long *hostw, hipStream_t st);
 void launch_sc_obj(CgState *s, const double *part, int g, int k, double tol, unsigned long long *hostw,
                    hipStream_t st);
+// guarded 'max_gain' (api.hip: cg_enqueue_iters): sc_beta with the recurred objective decides whether the fresh one is
+// needed; sc_obj, if it runs, decides with it
+void launch_sc_beta_guarded(CgState *s, const double *part_rr, const double *part_obj, int g, int k, double tol,
+                            unsigned long long *hostw, hipStream_t st);
+void launch_sc_obj_guarded(CgState *s, const double *part, int g, int k, double tol, unsigned long long *hostw,
+                           hipStream_t st);
 void launch_sum_to(const double *part, int g, double *out, hipStream_t st);
 // Folded forms (no scalar kernels between the matvec and the vector updates): EVERY workgroup
 // re-reduces the producer's partial sums in a fixed order in its prologue - visibility comes from
