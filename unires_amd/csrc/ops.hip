@@ -722,7 +722,7 @@ __global__ void __launch_bounds__(kBlock) k_conv1d_downup2_m(const float4 *__res
 
 static bool march2_ok(const Taps &T, int ax) {
   static const bool off = getenv("UNIRES_CONV_MARCH") && atoi(getenv("UNIRES_CONV_MARCH")) == 0;
-  return !off && ax != 2 && T.s[ax] == 2 && (T.n[ax] == 11 || T.n[ax] == 5 || T.n[ax] == 3);  // (Gaussian, triangle, trimmed rect at ratio 2)
+  return !off && ax != 2 && T.s[ax] == 2 && (T.n[ax] == 11 || T.n[ax] == 9 || T.n[ax] == 5 || T.n[ax] == 3);  // (Gaussian as built / as trimmed by the plan, triangle, trimmed rect at ratio 2)
 }
 
 // geometry shared by the two marching passes along `ax` (0 or 1) between volumes sd -> dd (float4 along z)
@@ -756,6 +756,8 @@ int launch_conv_downup2(const float *src, Dim3i sd, const Taps &T, const Scaling
   const dim3 grid((unsigned)(((long long)M.na * M.z4 + kBlock - 1) / kBlock), (unsigned)((nm + M.run - 1) / M.run));
   if (T.n[ax] == 11)
     hipLaunchKernelGGL((k_conv1d_downup2_m<11, 6>), grid, vol_block(), 0, st, (const float4 *)src, (float4 *)dst, M, n_mid, done);
+  else if (T.n[ax] == 9)
+    hipLaunchKernelGGL((k_conv1d_downup2_m<9, 5>), grid, vol_block(), 0, st, (const float4 *)src, (float4 *)dst, M, n_mid, done);
   else if (T.n[ax] == 5)
     hipLaunchKernelGGL((k_conv1d_downup2_m<5, 3>), grid, vol_block(), 0, st, (const float4 *)src, (float4 *)dst, M, n_mid, done);
   else
@@ -961,6 +963,7 @@ int launch_conv_ydown_xdownup2(const float *src, Dim3i sd, const Taps &T, const 
   }
   YX_CASE(11, 3, 2) YX_CASE(11, 5, 3) YX_CASE(11, 11, 6) YX_CASE(5, 3, 2) YX_CASE(5, 5, 3) YX_CASE(5, 11, 6)
   YX_CASE(3, 3, 2) YX_CASE(3, 5, 3) YX_CASE(3, 11, 6)
+  YX_CASE(9, 3, 2) YX_CASE(9, 5, 3) YX_CASE(9, 9, 5) YX_CASE(5, 9, 5) YX_CASE(3, 9, 5)  // (the Gaussian as the plan trims it)
 #undef YX_CASE
   return 1;
 }
@@ -1001,6 +1004,8 @@ void launch_conv_down_sep(const float *g, Dim3i gd, const Taps &T, const Scaling
       const dim3 grid((unsigned)(((long long)M.na * M.z4 + kBlock - 1) / kBlock), (unsigned)((n_out + M.run - 1) / M.run));
       if (T.n[ax] == 11)
         hipLaunchKernelGGL((k_conv1d_down2_m<11>), grid, vol_block(), 0, st, (const float4 *)cur, (float4 *)out, M, done);
+      else if (T.n[ax] == 9)
+        hipLaunchKernelGGL((k_conv1d_down2_m<9>), grid, vol_block(), 0, st, (const float4 *)cur, (float4 *)out, M, done);
       else if (T.n[ax] == 5)
         hipLaunchKernelGGL((k_conv1d_down2_m<5>), grid, vol_block(), 0, st, (const float4 *)cur, (float4 *)out, M, done);
       else
@@ -1255,6 +1260,8 @@ float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scalin
       const float sez = S.dim == 2 ? S.e : 1.f, soz = S.dim == 2 ? S.o : 1.f;
       if (fy == 6)
         hipLaunchKernelGGL((k_conv_up_yz2<6>), grid, vol_block(), lds, st, cur, cd, Z, sez, soz, out, oz, Y, nyb);
+      else if (fy == 5)
+        hipLaunchKernelGGL((k_conv_up_yz2<5>), grid, vol_block(), lds, st, cur, cd, Z, sez, soz, out, oz, Y, nyb);
       else if (fy == 3)
         hipLaunchKernelGGL((k_conv_up_yz2<3>), grid, vol_block(), lds, st, cur, cd, Z, sez, soz, out, oz, Y, nyb);
       else
@@ -1297,6 +1304,8 @@ float *launch_conv_up_sep(const float *xs, Dim3i xd, const Taps &T, const Scalin
       const dim3 grid((unsigned)(((long long)M.na * M.z4 + kBlock - 1) / kBlock), (unsigned)((nm + M.run - 1) / M.run));
       if (T.n[ax] == 11)
         hipLaunchKernelGGL((k_conv1d_up2_m<6>), grid, vol_block(), 0, st, (const float4 *)cur, (float4 *)out, M);
+      else if (T.n[ax] == 9)
+        hipLaunchKernelGGL((k_conv1d_up2_m<5>), grid, vol_block(), 0, st, (const float4 *)cur, (float4 *)out, M);
       else if (T.n[ax] == 5)
         hipLaunchKernelGGL((k_conv1d_up2_m<3>), grid, vol_block(), 0, st, (const float4 *)cur, (float4 *)out, M);
       else

@@ -772,7 +772,8 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
 #endif
   const bool k76 = T.n[2] == 7 && T.s[2] == 6;
   static const bool no_k112 = getenv("UNIRES_P2_K112") && atoi(getenv("UNIRES_P2_K112")) == 0;
-  const bool k112 = !no_k112 && T.n[2] == 11 && T.s[2] == 2;  // the default Gaussian profile at ratio 2 (BASELINE config 4)
+  const bool k112 = !no_k112 && T.n[2] == 11 && T.s[2] == 2;  // the default Gaussian profile at ratio 2 (BASELINE config 4) ...
+  const bool k92 = !no_k112 && T.n[2] == 9 && T.s[2] == 2;    // ... and as the plan trims it (its +-5 taps are 3e-8 of the sum)
   const bool k32 = !no_k112 && T.n[2] == 3 && T.s[2] == 2;     // the (trimmed) rect profile at ratio 2
 #define P2_LAUNCH(HH)                                                                        \
   do {                                                                                       \
@@ -782,6 +783,8 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
       hipLaunchKernelGGL((k_pull_conv2<HH, 7, 6, false>), grid, block, lds, st, P, done);    \
     else if (k112)                                                                           \
       hipLaunchKernelGGL((k_pull_conv2<HH, 11, 2, false>), grid, block, lds, st, P, done);   \
+    else if (k92)                                                                            \
+      hipLaunchKernelGGL((k_pull_conv2<HH, 9, 2, false>), grid, block, lds, st, P, done);    \
     else if (k32)                                                                            \
       hipLaunchKernelGGL((k_pull_conv2<HH, 3, 2, false>), grid, block, lds, st, P, done);    \
     else                                                                                     \
