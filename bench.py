@@ -33,125 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy
 
-WORKLOADS = {
-    # name: dim_y, channels, thick ratio, thick axis per channel
-    'cfg3_256c3_thick6z': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 2, 2)),
-    'cfg3_256c3_thick6z_aligned': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 2, 2), rigid='identity'),
-    # the same subject translated by a fraction of a voxel per channel, no rotation (shift.hip)
-    'cfg3_256c3_thick6z_shift': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 2, 2), rigid='shift'),
-    'cfg3_256c3_thick6xyz': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(0, 1, 2)),
-    # multi-orientation thick-slice scans as files carry them (the reference's motivating case; it takes
-    # mat_x as read, unires/_util.py:134-197): channel 0 axial, RAS order; channel 1 thick along world x,
-    # STORED sagittally (voxel axes = world y, z, x); channel 2 thick along world y, stored coronally with
-    # the first axis reversed (voxel axes = -x, z, y: LAS, det < 0).  orient[c] = (perm, flip): stored
-    # voxel axis a is axis perm[a] of the axis-aligned acquisition, reversed where flip[a]
-    'cfg3_256c3_thick6_orient': dict(dim_y=(256, 256, 256), C=3, thick=6, axes=(2, 0, 1),
-                                     orient=(((0, 1, 2), (0, 0, 0)), ((1, 2, 0), (0, 0, 0)), ((0, 2, 1), (1, 0, 0)))),
-    'cfg4_384c4_iso2': dict(dim_y=(384, 384, 384), C=4, thick=2, axes=None),
-    # the same with the reference's default in-plane profile (Gaussian, struct.py:95; fan-in > 2)
-    'cfg4_384c4_iso2_gauss': dict(dim_y=(384, 384, 384), C=4, thick=2, axes=None, prof_ip=2),
-    'small_96c3_thick3': dict(dim_y=(96, 96, 96), C=3, thick=3, axes=(2, 2, 2)),
-    # launch-bound: the device finishes every kernel before the host has enqueued the next (tools/host_time.py)
-    'tiny_32c3_thick2': dict(dim_y=(32, 32, 32), C=3, thick=2, axes=(2, 2, 2)),
-    # the shape of the reference's multi-channel demo (demos/demo_multi_channel.ipynb:109-113):
-    # 181x217x181, three contrasts, 4 mm slices along x, y and z
-    'demo_181c3_thick4xyz': dict(dim_y=(181, 217, 181), C=3, thick=4, axes=(0, 1, 2)),
-    # BASELINE configs[0] / [1] shapes (BrainWeb 1 mm, 181x217x181) on the synthetic phantom:
-    # single-channel denoising with A = I (R0), 3-channel 1 mm recon after coregistration (R1)
-    'cfg1_181c1_denoise': dict(dim_y=(181, 217, 181), C=1, thick=1, axes=(2,), regime='id'),
-    'cfg2_181c3_1mm': dict(dim_y=(181, 217, 181), C=3, thick=1, axes=(2, 2, 2), regime='dn'),
-    # the pull / push operator of config 2 at the headline's size (what the single-pass kernel does at 256^3)
-    'dn_256c3_1mm': dict(dim_y=(256, 256, 256), C=3, thick=1, axes=(2, 2, 2), regime='dn'),
-}
-
-
-def rigid_matrix(t, r):
-    cx, sx, cy, sy, cz, sz = (math.cos(r[0]), math.sin(r[0]), math.cos(r[1]), math.sin(r[1]),
-                              math.cos(r[2]), math.sin(r[2]))
-    Rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=torch.float64)
-    Ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=torch.float64)
-    Rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=torch.float64)
-    M = torch.eye(4, dtype=torch.float64)
-    M[:3, :3] = Rz @ Ry @ Rx
-    M[:3, 3] = torch.tensor(t, dtype=torch.float64)
-    return M
-
-
-def orient_axes(dim, mat, perm, flip):
-    """Dims and affine of the same acquisition stored with voxel axis a = old axis perm[a], reversed
-    where flip[a] (mat @ Q, Q mapping stored to old voxel coordinates)."""
-    Q = torch.zeros((4, 4), dtype=torch.float64)
-    Q[3, 3] = 1.0
-    for a in range(3):
-        Q[perm[a], a] = -1.0 if flip[a] else 1.0
-        if flip[a]:
-            Q[perm[a], 3] = dim[perm[a]] - 1
-    return tuple(int(dim[perm[a]]) for a in range(3)), mat @ Q
-
-
-def phantom(dim, gen, device):
-    """Sum of random ellipsoids on a zero background, built on device."""
-    ax = [torch.linspace(-1, 1, d, device=device) for d in dim]
-    X, Y, Z = torch.meshgrid(*ax, indexing='ij')
-    vol = torch.zeros(dim, device=device)
-    for _ in range(8):
-        c = (torch.rand(3, generator=gen) - 0.5).tolist()
-        r = (0.2 + 0.5 * torch.rand(3, generator=gen)).tolist()
-        a = float(torch.rand(1, generator=gen))
-        vol += a * (((X - c[0]) / r[0]) ** 2 + ((Y - c[1]) / r[1]) ** 2
-                    + ((Z - c[2]) / r[2]) ** 2 < 1).float()
-    return vol
-
-
-def build_subject(wl, device, seed):
-    """Synthetic subject: ground truth -> x = A y* + N(0, 75^2) via the HIP A
-    (the demos' recipe, demos/demo_multi_channel.ipynb:173,193-202); fixed
-    hyper-parameters tau = 1/75^2, lam = 4 sqrt(1/C)/mu_c, rho = sqrt(mean tau)/mean lam."""
-    import unires_amd as U
-    gen = torch.Generator().manual_seed(seed)
-    dim_y, C, thick = wl['dim_y'], wl['C'], wl['thick']
-    mat_y = torch.eye(4, dtype=torch.float64)
-    if wl['axes'] is None:  # config 4: 0.5 mm recon of 1 mm isotropic inputs
-        mat_y = torch.diag(torch.tensor([0.5, 0.5, 0.5, 1.0], dtype=torch.float64))
-    mus = (400.0, 2000.0, 4300.0, 1000.0)
-    sd = 75.0
-    x, y = [], []
-    for c in range(C):
-        truth = phantom(dim_y, gen, device) * mus[c]
-        scale = [1.0, 1.0, 1.0]
-        if wl['axes'] is None:
-            scale = [float(thick)] * 3
-        else:
-            scale[wl['axes'][c]] = float(thick)
-        mat_x = mat_y @ torch.diag(torch.tensor(scale + [1.0], dtype=torch.float64))
-        dim_x = tuple(int(math.floor(d / s)) for d, s in zip(dim_y, scale))
-        if wl.get('orient'):
-            dim_x, mat_x = orient_axes(dim_x, mat_x, *wl['orient'][c])
-        u = torch.rand(6, generator=gen) * 2 - 1
-        rigid = rigid_matrix((u[:3] * 5.0).tolist(), (u[3:] * 0.1).tolist())
-        if wl.get('rigid') == 'identity':  # grid-aligned observations (no motion between scans)
-            rigid = torch.eye(4, dtype=torch.float64)
-        if wl.get('rigid') == 'shift':  # translated (+-5 mm, fractions of a voxel), not rotated
-            rigid = rigid_matrix((u[:3] * 5.0).tolist(), [0.0, 0.0, 0.0])
-        regime = wl.get('regime', 'sr')
-        method = 'super-resolution' if regime == 'sr' else 'denoising'
-        if regime == 'id':
-            rigid = torch.eye(4, dtype=torch.float64)
-        po = U._proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=wl.get('prof_ip', 0),
-                          prof_tp=0, device=device)
-        clean = truth if regime == 'id' else U._proj_apply('A', truth[None, None], po, method=method)[0, 0]
-        noise = torch.randn(clean.shape, generator=gen).to(device) * sd
-        x.append([U._input(clean + noise, mat_x, 1.0 / sd ** 2, po)])
-        lam = 4.0 * math.sqrt(1.0 / C) / mus[c]
-        y.append(U._output(torch.zeros(dim_y, device=device), mat_y, lam))
-        del truth
-    sett = U.settings()
-    sett.device, sett.method, sett.do_proj = device, method, wl.get('regime', 'sr') != 'id'
-    sett.cgs_max_iter, sett.cgs_tol = 20, 0.0  # fixed-iteration mode
-    sett.cache_atx = False  # every step re-assembles the full RHS (no work skipped in the timed region)
-    rho = float(U._step_size(x, y, sett))
-    z, w = U._admm_aux(y, sett)
-    return x, y, z, w, rho, sett
+from workloads import WORKLOADS, build_subject, orient_axes, phantom, rigid_matrix  # noqa: E402,F401
 
 
 def alg_bytes_matvec(x_c, dim_y, do_proj=True):
@@ -280,100 +162,6 @@ def host_cpu_model():
     return 'unknown'
 
 
-def oracle_channel(wl, dim_y, seed=0, channel=None):
-    """One channel of workload ``wl`` at size ``dim_y`` as oracle structs (+ the raw pieces).
-    ``channel`` picks that channel's thick axis (default: z, the headline configuration's)."""
-    from oracle import unires_restated as O
-    thick = wl['thick']
-    gen = torch.Generator().manual_seed(seed)
-    mat_y = torch.eye(4, dtype=torch.float64)
-    scale = [1.0, 1.0, 1.0]
-    if wl['axes'] is None:
-        scale = [float(thick)] * 3
-    else:
-        scale[2 if channel is None else wl['axes'][channel]] = float(thick)
-    if wl['axes'] is None:
-        mat_y = torch.diag(torch.tensor([0.5, 0.5, 0.5, 1.0], dtype=torch.float64))
-    mat_x = mat_y @ torch.diag(torch.tensor(scale + [1.0], dtype=torch.float64))
-    dim_x = tuple(int(math.floor(d / s)) for d, s in zip(dim_y, scale))
-    if wl.get('orient') and channel is not None:  # the channel's stored voxel order (sagittal / coronal / reflected)
-        dim_x, mat_x = orient_axes(dim_x, mat_x, *wl['orient'][channel])
-    u = torch.rand(6, generator=gen) * 2 - 1
-    rigid = rigid_matrix((u[:3] * 5.0).tolist(), (u[3:] * 0.1).tolist())
-    po = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=wl.get('prof_ip', 0), prof_tp=0)
-    dat_x = torch.rand(dim_x, generator=gen) * 400
-    tau, lam = 1 / 75.0 ** 2, 4.0 * math.sqrt(1 / 3.0) / 400.0
-    xc = [O.make_input(dat_x, mat_x, torch.tensor(tau), po)]
-    yc = O.make_output(torch.zeros(dim_y), mat_y, torch.tensor(lam))
-    b = torch.rand(dim_y, generator=gen)
-    return dict(mat_y=mat_y, mat_x=mat_x, dim_x=dim_x, rigid=rigid, xc=xc, yc=yc, b=b, tau=tau, lam=lam,
-                dat_x=dat_x, po=po)
-
-
-def oracle_lhs(wl, P, rho=0.9):
-    from oracle import nitorch_restated as N
-    from oracle import unires_restated as O
-    regime = wl.get('regime', 'sr')
-    method = 'super-resolution' if regime == 'sr' else 'denoising'
-    vx = N.voxel_size(P['mat_y']).float()
-    return lambda d: O.proj('AtA', d, P['xc'], P['yc'], method=method, do=regime != 'id',
-                            rho=torch.tensor(rho), vx_y=vx)
-
-
-def fov_tie_voxels(wl, P, eps=1e-4, reach=2):
-    """Output voxels that a grid point within ``eps`` of an in-FOV threshold can reach.  The
-    reference's mask is discontinuous there: which side a float32 coordinate falls on depends on
-    the last-ulp rounding of the coordinate arithmetic (torch-CPU matmul vs FMA chain), so the
-    matvec legitimately differs by one grid point's worth in these voxels."""
-    from oracle import nitorch_restated as N
-    from oracle import unires_restated as O
-    regime = wl.get('regime', 'sr')
-    method = 'super-resolution' if regime == 'sr' else 'denoising'
-    mat, dim = O.proj_matrix(P['po'], method)
-    g = N.affine_grid(mat.float(), dim)
-    dim_y = tuple(P['b'].shape)
-    near = torch.zeros(g.shape[:3], dtype=torch.bool)
-    for d, n in enumerate(dim_y):
-        for thr in (-5e-2, n - 1 + 5e-2):
-            near |= (g[..., d] - thr).abs() < eps
-    pts = g[near]
-    bad = torch.zeros(dim_y, dtype=torch.bool)
-    for pt in pts:
-        lo = [int(max(0, math.floor(float(v)) - reach + 1)) for v in pt]
-        hi = [int(min(n, math.floor(float(v)) + reach + 1)) for v, n in zip(pt, dim_y)]
-        if all(h > l for l, h in zip(lo, hi)):
-            bad[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = True
-    return bad, int(near.sum())
-
-
-def matvec_parity(wl, P, q_cpu, device, rho=0.9):
-    """float32 agreement of the HIP matvec with the oracle on the same operator and input
-    (relative L2 error, gate 1e-4, and max-abs error)."""
-    import unires_amd as U
-    from unires_amd._project import _channel_plan
-    regime = wl.get('regime', 'sr')
-    method = 'super-resolution' if regime == 'sr' else 'denoising'
-    dim_y = tuple(P['b'].shape)
-    po_g = U._proj_info(dim_y, P['mat_y'], P['dim_x'], P['mat_x'], rigid=P['rigid'],
-                        prof_ip=wl.get('prof_ip', 0), prof_tp=0, device=device)
-    xg = [U._input(P['dat_x'].to(device), P['mat_x'], P['tau'], po_g)]
-    yg = U._output(torch.zeros(dim_y, device=device), P['mat_y'], P['lam'])
-    plan = _channel_plan(xg, yg, method, regime != 'id')
-    q_gpu = plan.matvec(P['b'].to(device), rho, P['lam']).cpu()
-    diff = (q_gpu.double() - q_cpu.double())
-    ties, n_near = fov_tie_voxels(wl, P)
-    keep = ~ties
-    return {'rel_err': float(diff.norm() / q_cpu.double().norm()),
-            'max_abs': float(diff.abs().max()), 'ref_max_abs': float(q_cpu.abs().max()),
-            'rel_err_away_from_fov_ties': float(diff[keep].norm() / q_cpu.double()[keep].norm()),
-            'max_abs_away_from_fov_ties': float(diff[keep].abs().max()),
-            'fov_tie_grid_points': n_near, 'fov_tie_voxels_excluded': int(ties.sum()),
-            'what': 'HIP ata_matvec vs oracle _proj(AtA) on the same %dx%dx%d operator and input; '
-                    '"away from ties" leaves out the output voxels within reach of grid points whose '
-                    'coordinate lies within 1e-4 of an in-FOV threshold (the reference mask is '
-                    'discontinuous there)' % dim_y}
-
-
 def cpu_baseline(wl, seconds_budget=25.0, device=None):
     """CPU oracle ("port" of the reference composition) on one channel of the same
     workload: fixed-iteration CG, as many iterations as fit the budget (>= 1).
@@ -388,6 +176,7 @@ def cpu_baseline(wl, seconds_budget=25.0, device=None):
     runs on the SAME operator and the SAME input and the float32 relative / max-abs error is
     reported next to the timing (gate 1e-4)."""
     from oracle import nitorch_restated as N
+    from tests.helpers import matvec_parity, oracle_channel, oracle_lhs  # (test infrastructure, like oracle/)
     dim_y = wl['dim_y']
     keep_threads = torch.get_num_threads()  # (batch.init_from_env caps the rank's threads: the baseline gets the host)
     all_threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)

@@ -216,3 +216,99 @@ def run_gpu_update_y(prob, device='cuda:0', max_iter=20, tol=1e-3, stop='max_gai
     U._update_y(x, y, z, w, prob['rho'], tmp, sett, info=info)
     torch.cuda.synchronize()
     return [yc.dat for yc in y], info
+
+
+# ---- full-size parity helpers (one channel of a bench workload as oracle structs; moved here from bench.py in
+# round 6 so that the benchmark and the parity assertions do not share editable code) ----
+def oracle_channel(wl, dim_y, seed=0, channel=None):
+    """One channel of workload ``wl`` at size ``dim_y`` as oracle structs (+ the raw pieces).
+    ``channel`` picks that channel's thick axis (default: z, the headline configuration's)."""
+    from oracle import unires_restated as O
+    thick = wl['thick']
+    gen = torch.Generator().manual_seed(seed)
+    mat_y = torch.eye(4, dtype=torch.float64)
+    scale = [1.0, 1.0, 1.0]
+    if wl['axes'] is None:
+        scale = [float(thick)] * 3
+    else:
+        scale[2 if channel is None else wl['axes'][channel]] = float(thick)
+    if wl['axes'] is None:
+        mat_y = torch.diag(torch.tensor([0.5, 0.5, 0.5, 1.0], dtype=torch.float64))
+    mat_x = mat_y @ torch.diag(torch.tensor(scale + [1.0], dtype=torch.float64))
+    dim_x = tuple(int(math.floor(d / s)) for d, s in zip(dim_y, scale))
+    if wl.get('orient') and channel is not None:  # the channel's stored voxel order (sagittal / coronal / reflected)
+        dim_x, mat_x = orient_axes(dim_x, mat_x, *wl['orient'][channel])
+    u = torch.rand(6, generator=gen) * 2 - 1
+    rigid = rigid_matrix((u[:3] * 5.0).tolist(), (u[3:] * 0.1).tolist())
+    po = O.proj_info(dim_y, mat_y, dim_x, mat_x, rigid=rigid, prof_ip=wl.get('prof_ip', 0), prof_tp=0)
+    dat_x = torch.rand(dim_x, generator=gen) * 400
+    tau, lam = 1 / 75.0 ** 2, 4.0 * math.sqrt(1 / 3.0) / 400.0
+    xc = [O.make_input(dat_x, mat_x, torch.tensor(tau), po)]
+    yc = O.make_output(torch.zeros(dim_y), mat_y, torch.tensor(lam))
+    b = torch.rand(dim_y, generator=gen)
+    return dict(mat_y=mat_y, mat_x=mat_x, dim_x=dim_x, rigid=rigid, xc=xc, yc=yc, b=b, tau=tau, lam=lam,
+                dat_x=dat_x, po=po)
+
+
+def oracle_lhs(wl, P, rho=0.9):
+    from oracle import nitorch_restated as N
+    from oracle import unires_restated as O
+    regime = wl.get('regime', 'sr')
+    method = 'super-resolution' if regime == 'sr' else 'denoising'
+    vx = N.voxel_size(P['mat_y']).float()
+    return lambda d: O.proj('AtA', d, P['xc'], P['yc'], method=method, do=regime != 'id',
+                            rho=torch.tensor(rho), vx_y=vx)
+
+
+def fov_tie_voxels(wl, P, eps=1e-4, reach=2):
+    """Output voxels that a grid point within ``eps`` of an in-FOV threshold can reach.  The
+    reference's mask is discontinuous there: which side a float32 coordinate falls on depends on
+    the last-ulp rounding of the coordinate arithmetic (torch-CPU matmul vs FMA chain), so the
+    matvec legitimately differs by one grid point's worth in these voxels."""
+    from oracle import nitorch_restated as N
+    from oracle import unires_restated as O
+    regime = wl.get('regime', 'sr')
+    method = 'super-resolution' if regime == 'sr' else 'denoising'
+    mat, dim = O.proj_matrix(P['po'], method)
+    g = N.affine_grid(mat.float(), dim)
+    dim_y = tuple(P['b'].shape)
+    near = torch.zeros(g.shape[:3], dtype=torch.bool)
+    for d, n in enumerate(dim_y):
+        for thr in (-5e-2, n - 1 + 5e-2):
+            near |= (g[..., d] - thr).abs() < eps
+    pts = g[near]
+    bad = torch.zeros(dim_y, dtype=torch.bool)
+    for pt in pts:
+        lo = [int(max(0, math.floor(float(v)) - reach + 1)) for v in pt]
+        hi = [int(min(n, math.floor(float(v)) + reach + 1)) for v, n in zip(pt, dim_y)]
+        if all(h > l for l, h in zip(lo, hi)):
+            bad[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = True
+    return bad, int(near.sum())
+
+
+def matvec_parity(wl, P, q_cpu, device, rho=0.9):
+    """float32 agreement of the HIP matvec with the oracle on the same operator and input
+    (relative L2 error, gate 1e-4, and max-abs error)."""
+    import unires_amd as U
+    from unires_amd._project import _channel_plan
+    regime = wl.get('regime', 'sr')
+    method = 'super-resolution' if regime == 'sr' else 'denoising'
+    dim_y = tuple(P['b'].shape)
+    po_g = U._proj_info(dim_y, P['mat_y'], P['dim_x'], P['mat_x'], rigid=P['rigid'],
+                        prof_ip=wl.get('prof_ip', 0), prof_tp=0, device=device)
+    xg = [U._input(P['dat_x'].to(device), P['mat_x'], P['tau'], po_g)]
+    yg = U._output(torch.zeros(dim_y, device=device), P['mat_y'], P['lam'])
+    plan = _channel_plan(xg, yg, method, regime != 'id')
+    q_gpu = plan.matvec(P['b'].to(device), rho, P['lam']).cpu()
+    diff = (q_gpu.double() - q_cpu.double())
+    ties, n_near = fov_tie_voxels(wl, P)
+    keep = ~ties
+    return {'rel_err': float(diff.norm() / q_cpu.double().norm()),
+            'max_abs': float(diff.abs().max()), 'ref_max_abs': float(q_cpu.abs().max()),
+            'rel_err_away_from_fov_ties': float(diff[keep].norm() / q_cpu.double()[keep].norm()),
+            'max_abs_away_from_fov_ties': float(diff[keep].abs().max()),
+            'fov_tie_grid_points': n_near, 'fov_tie_voxels_excluded': int(ties.sum()),
+            'what': 'HIP ata_matvec vs oracle _proj(AtA) on the same %dx%dx%d operator and input; '
+                    '"away from ties" leaves out the output voxels within reach of grid points whose '
+                    'coordinate lies within 1e-4 of an in-FOV threshold (the reference mask is '
+                    'discontinuous there)' % dim_y}

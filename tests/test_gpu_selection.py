@@ -7,7 +7,7 @@ their bit fields, more than 64 instructions per tile)."""
 import pytest
 import torch
 
-import bench
+import workloads
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +26,7 @@ EXPECT = {
 @pytest.mark.parametrize('name', list(EXPECT))
 def test_baseline_configurations_never_reach_the_round1_kernels(dev, name):
     from unires_amd._project import _channel_plan
-    x, y, z, w, rho, sett = bench.build_subject(bench.WORKLOADS[name], dev, seed=1234)
+    x, y, z, w, rho, sett = workloads.build_subject(workloads.WORKLOADS[name], dev, seed=1234)
     for c in range(len(x)):
         plan = _channel_plan(x[c], y[c], sett.method, sett.do_proj)
         for n in range(len(x[c])):
@@ -37,7 +37,7 @@ def test_baseline_configurations_never_reach_the_round1_kernels(dev, name):
 
 
 def test_config1_is_the_identity_regime(dev):
-    x, y, z, w, rho, sett = bench.build_subject(bench.WORKLOADS['cfg1_181c1_denoise'], dev, seed=1234)
+    x, y, z, w, rho, sett = workloads.build_subject(workloads.WORKLOADS['cfg1_181c1_denoise'], dev, seed=1234)
     assert sett.do_proj is False  # (A = I: the flat stencil kernel, no operator kernels at all)
 
 

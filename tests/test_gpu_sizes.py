@@ -15,7 +15,8 @@ import math
 import pytest
 import torch
 
-import bench
+import workloads
+from tests import helpers as H
 from oracle import nitorch_restated as N
 from oracle import unires_restated as O
 from tests.helpers import rel_err
@@ -28,10 +29,10 @@ GATE = 1e-4
 def _check(dev, wlname, dim_y, seed, rhs=True, channel=None):
     from unires_amd._project import _channel_plan
     import unires_amd as U
-    wl = dict(bench.WORKLOADS[wlname])
-    P = bench.oracle_channel(wl, dim_y, seed=seed, channel=channel)
-    q_cpu = bench.oracle_lhs(wl, P)(P['b'])
-    par = bench.matvec_parity(wl, P, q_cpu, dev)
+    wl = dict(workloads.WORKLOADS[wlname])
+    P = H.oracle_channel(wl, dim_y, seed=seed, channel=channel)
+    q_cpu = H.oracle_lhs(wl, P)(P['b'])
+    par = H.matvec_parity(wl, P, q_cpu, dev)
     assert par['rel_err_away_from_fov_ties'] < GATE, par
     # a tie point flips one grid sample: all-voxel error stays tiny, bounded by their number
     n_vox = dim_y[0] * dim_y[1] * dim_y[2]
@@ -52,7 +53,7 @@ def _check(dev, wlname, dim_y, seed, rhs=True, channel=None):
     yg = U._output(torch.zeros(dim_y, device=dev), P['mat_y'], P['lam'])
     plan = _channel_plan(xg, yg, method, regime != 'id')
     b = plan.rhs([xg[0].dat], w.to(dev), z.to(dev), 0.9, P['lam']).cpu()
-    ties, _ = bench.fov_tie_voxels(wl, P)
+    ties, _ = H.fov_tie_voxels(wl, P)
     keep = ~ties
     assert rel_err(b[keep], ref_b[keep]) < GATE
     return par
@@ -100,8 +101,8 @@ def test_full_size_stored_orientations_properties(dev):
         sc = [1.0, 1.0, 1.0, 1.0]
         sc[thick_axis] = 6.0
         dim_x0 = tuple(256 // int(v) for v in sc[:3])
-        dim_x, mat_x = bench.orient_axes(dim_x0, eye @ torch.diag(torch.tensor(sc, dtype=torch.float64)),
-                                         *bench.WORKLOADS['cfg3_256c3_thick6_orient']['orient'][ch])
+        dim_x, mat_x = workloads.orient_axes(dim_x0, eye @ torch.diag(torch.tensor(sc, dtype=torch.float64)),
+                                         *workloads.WORKLOADS['cfg3_256c3_thick6_orient']['orient'][ch])
         po = U._proj_info(dim_y, eye, dim_x, mat_x, rigid=rigid_matrix([2.0, -3.0, 1.0], [0.05, -0.08, 0.03]), device=dev)
         assert int(po.dim_thick) == 2 and tuple(po.ratio) == (1, 1, 6)  # the slice axis is the LAST stored axis in both
         x = [U._input(torch.rand(dim_x, generator=g).to(dev), mat_x, 1.8e-4, po)]
@@ -176,7 +177,7 @@ def _solve_both(dev, wl, dim_y, seed, max_iter, tolerance, threads=16):
     on the HIP path: RHS assembled by each side from the same observation / z / w, zero start."""
     from unires_amd._project import _channel_plan
     import unires_amd as U
-    P = bench.oracle_channel(wl, dim_y, seed=seed)
+    P = H.oracle_channel(wl, dim_y, seed=seed)
     regime = wl.get('regime', 'sr')
     method = 'super-resolution' if regime == 'sr' else 'denoising'
     g = torch.Generator().manual_seed(seed + 100)
@@ -188,7 +189,7 @@ def _solve_both(dev, wl, dim_y, seed, max_iter, tolerance, threads=16):
     torch.set_num_threads(min(threads, all_threads))  # (the oracle's index_add_ passes anti-scale beyond ~16)
     try:
         b_ref = O.y_rhs(P['xc'], P['yc'], z, w, torch.tensor(rho), vx, method, regime != 'id')
-        lhs = bench.oracle_lhs(wl, P, rho=rho)
+        lhs = H.oracle_lhs(wl, P, rho=rho)
         y_ref, it_ref, obj_ref = N.cg(lhs, b_ref, torch.zeros(dim_y), max_iter=max_iter, tolerance=tolerance,
                                       stop='max_gain', return_info=True)
     finally:
@@ -201,7 +202,7 @@ def _solve_both(dev, wl, dim_y, seed, max_iter, tolerance, threads=16):
     b = plan.rhs([xg[0].dat], w.to(dev), z.to(dev), rho, P['lam'])
     x = torch.zeros(dim_y, device=dev)
     it, obj = plan.cg(b, x, rho, P['lam'], max_iter=max_iter, tolerance=tolerance, stop='max_gain')
-    ties, _ = bench.fov_tie_voxels(wl, P)
+    ties, _ = H.fov_tie_voxels(wl, P)
     return dict(y_ref=y_ref, it_ref=it_ref, obj_ref=obj_ref, y=x.cpu(), it=it, obj=obj, keep=~ties)
 
 
@@ -210,7 +211,7 @@ def test_full_size_config3_cg_iterations_match_oracle(dev):
     """BASELINE configs[2] geometry at FULL size (256^3, one channel): the RHS and three iterations of
     the reference-faithful CG (stop='max_gain': the objective 0.5 sum x (Ax - 2b) after every iteration,
     one extra A(x) each) - iterate and objective trace against the oracle.  ~1 minute of CPU oracle."""
-    wl = dict(bench.WORKLOADS['cfg3_256c3_thick6z'])
+    wl = dict(workloads.WORKLOADS['cfg3_256c3_thick6z'])
     r = _solve_both(dev, wl, (256, 256, 256), seed=0, max_iter=3, tolerance=1e-30)
     assert r['it'] == r['it_ref'] == 3
     assert torch.allclose(torch.tensor(r['obj'], dtype=torch.float64), r['obj_ref'].double(), rtol=1e-5, atol=0)
@@ -226,7 +227,7 @@ def test_max_gain_iteration_counts_at_128(dev, seed):
     on the configuration-3 geometry at 128^3: the realised iteration count is the oracle's and so are the
     iterate and the objective trace.  (At 256^3 the bench's three channels stop after 10 / 2 / 3
     iterations, `variants.cg_tol1e-3_max_gain` of the bench line.)"""
-    wl = dict(bench.WORKLOADS['cfg3_256c3_thick6z'])
+    wl = dict(workloads.WORKLOADS['cfg3_256c3_thick6z'])
     r = _solve_both(dev, wl, (128, 128, 128), seed=seed, max_iter=20, tolerance=1e-3)
     assert r['it'] == r['it_ref'], (r['it'], r['it_ref'])
     assert torch.allclose(torch.tensor(r['obj'], dtype=torch.float64), r['obj_ref'].double(), rtol=1e-5, atol=0)

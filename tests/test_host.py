@@ -284,7 +284,9 @@ def test_host_shares_and_pacer_without_a_gpu():
     keep = torch.get_num_threads()
     try:
         cfg = _host.configure_host(local_rank=0, world=1)
-        assert 1 <= cfg['threads'] <= 8 and cfg['cpus'] is None  # one rank: no pinning
+        # one rank: no pinning, the process keeps its thread pool, no sticky caps in host sections
+        assert cfg['threads'] == keep and cfg['cpus'] is None and torch.get_num_threads() == keep
+        assert _host.batch_mode == (os.environ.get('UNIRES_LIGHT_HOST', '0') == '1')
     finally:
         torch.set_num_threads(keep)
     if not torch.cuda.is_available():
@@ -307,9 +309,10 @@ def test_objective_trace_from_the_ring():
 
 def test_blas_pools_are_capped_once_and_for_good():
     """`cap_blas` (the Gauss-Newton steps' 4 x 4 / 6 x 6 algebra must not wake OpenBLAS worker pools that then
-    spin: 20 -> 5 ms of CPU per rigid step, profiles/r05_rigid_profile.txt): after a `light_host` section every
-    loaded BLAS - numpy's and scipy's copy - runs on one thread and stays there; UNIRES_BLAS_THREADS=0 leaves
-    the pools alone."""
+    spin: 20 -> 5 ms of CPU per rigid step, profiles/r05_rigid_profile.txt): in batch mode (several ranks on the
+    host, or UNIRES_LIGHT_HOST=1) after a `light_host` section every loaded BLAS - numpy's and scipy's copy - runs
+    on one thread and stays there; UNIRES_BLAS_THREADS=0 leaves the pools alone - and so does a lone process
+    (no process-wide side effect of a library call outside batch mode)."""
     import sys
     code = (
         "import sys; sys.path.insert(0, %r)\n"
@@ -317,12 +320,23 @@ def test_blas_pools_are_capped_once_and_for_good():
         "from threadpoolctl import threadpool_info\n"
         "before = [i['num_threads'] for i in threadpool_info() if i['user_api'] == 'blas']\n"
         "from unires_amd import _host\n"
+        "_host.batch_mode = _host.batch_mode or %r\n"
         "f = _host.light_host(lambda: np.linalg.solve(np.eye(6), np.ones(6)).sum())\n"
         "assert f() == 6.0\n"
         "n1 = [i['num_threads'] for i in threadpool_info() if i['user_api'] == 'blas']\n"
         "f()\n"
         "n2 = [i['num_threads'] for i in threadpool_info() if i['user_api'] == 'blas']\n"
-        "print(before, n1, n2)\n") % ROOT
+        "print(before, n1, n2)\n")
+    lone, code = code % (ROOT, False), code % (ROOT, True)
+    r = subprocess.run([sys.executable, '-c', lone], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    before, n1, n2 = eval('(' + r.stdout.strip().replace('] [', '], [') + ')')
+    assert n1[:len(before)] == before and n2 == n1, (before, n1, n2)  # a lone process: pools untouched
+    r = subprocess.run([sys.executable, '-c', lone], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, UNIRES_LIGHT_HOST='1'))
+    assert r.returncode == 0, r.stderr[-2000:]
+    before, n1, n2 = eval('(' + r.stdout.strip().replace('] [', '], [') + ')')
+    assert n1 and n1 == n2 and all(v == 1 for v in n1), (before, n1, n2)
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     before, n1, n2 = eval('(' + r.stdout.strip().replace('] [', '], [') + ')')
@@ -346,3 +360,30 @@ def test_import_sets_the_runtimes_signal_pool_unless_told_otherwise():
                            env=dict(base, **extra))
         assert r.returncode == 0, r.stderr[-2000:]
         assert r.stdout.strip().splitlines()[-1] == want, (extra, r.stdout)
+
+
+def test_import_sets_the_signal_pool_only_when_it_can():
+    """`import unires_amd` exports ROC_SIGNAL_POOL_SIZE=4096 unless the user set it (or opted out); the variable is
+    read once, when the HIP runtime starts - so an import that comes AFTER the first CUDA/HIP call (an embedding
+    application) warns once, with the measured cost, instead of silently doing nothing
+    (VERDICT r5 weak 9).  `torch.cuda.is_initialized()` stands in for "the runtime is up" here (no GPU needed)."""
+    import sys
+    code = (
+        "import sys, os, warnings; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "if %r: torch.cuda.is_initialized = lambda: True\n"
+        "with warnings.catch_warnings(record=True) as w:\n"
+        "    warnings.simplefilter('always')\n"
+        "    import unires_amd\n"
+        "print(os.environ.get('ROC_SIGNAL_POOL_SIZE'), sum('ROC_SIGNAL_POOL_SIZE' in str(x.message) for x in w))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ('ROC_SIGNAL_POOL_SIZE', 'UNIRES_NO_RUNTIME_TUNING')}
+
+    def run(late, **extra):
+        r = subprocess.run([sys.executable, '-c', code % (ROOT, late)], capture_output=True, text=True, timeout=300,
+                           env=dict(env, **extra))
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout.split()
+    assert run(False) == ['4096', '0']                                 # first: set, silent
+    assert run(True) == ['4096', '1']                                  # late: one warning
+    assert run(True, ROC_SIGNAL_POOL_SIZE='256') == ['256', '0']       # the user's value wins, nothing to say
+    assert run(True, UNIRES_NO_RUNTIME_TUNING='1') == ['None', '0']    # opted out

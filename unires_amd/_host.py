@@ -24,9 +24,19 @@ def tune_runtime():
     with the three channels of a 181^3 subject on streams of their own (tools/host_profile.py,
     profiles/r05_host_profile.txt).  With 4096 signals that thread is idle (0.1 - 0.3 ms), wall times and
     results unchanged.  Nothing here is the reference's; it is what eight ranks sharing one host need."""
-    if os.environ.get('UNIRES_NO_RUNTIME_TUNING'):
+    if os.environ.get('UNIRES_NO_RUNTIME_TUNING') or 'ROC_SIGNAL_POOL_SIZE' in os.environ:
         return
-    os.environ.setdefault('ROC_SIGNAL_POOL_SIZE', '4096')
+    os.environ['ROC_SIGNAL_POOL_SIZE'] = '4096'
+    if torch.cuda.is_initialized():
+        # (an embedding application that touched the GPU first: the variable is read once, at the runtime's start)
+        import warnings
+        warnings.warn(
+            'unires_amd was imported after the HIP runtime was initialised: ROC_SIGNAL_POOL_SIZE=4096 cannot take '
+            'effect in this process.  Results are unaffected; the runtime\'s signal thread then costs ~6-7 ms of host '
+            'CPU per ADMM iteration and channel streams lose ~7 % at 256^3 (profiles/r05_host_profile.txt, '
+            'r05_overlap_scan.txt).  Export ROC_SIGNAL_POOL_SIZE=4096 before the process starts, or import unires_amd '
+            'before the first CUDA/HIP call (INTEGRATION.md 2); UNIRES_NO_RUNTIME_TUNING=1 silences this.',
+            RuntimeWarning, stacklevel=3)
 
 
 def _parse_cpulist(text):
@@ -73,16 +83,20 @@ def configure_host(local_rank=0, world=1, gpu_numa=True):
         avail = sorted(os.sched_getaffinity(0))
     except AttributeError:  # not Linux
         avail = list(range(os.cpu_count() or 1))
+    global batch_mode
     share = max(1, len(avail) // max(1, world))
-    threads = min(share, 8)
+    threads = min(share, 8) if world > 1 else torch.get_num_threads()  # (a lone process keeps its pool)
     if os.environ.get('UNIRES_HOST_THREADS'):
         threads = max(1, int(os.environ['UNIRES_HOST_THREADS']))
-    torch.set_num_threads(threads)
+    if threads != torch.get_num_threads():
+        torch.set_num_threads(threads)
+    batch_mode = batch_mode or world > 1
     cpus = None
     if world > 1 and os.environ.get('UNIRES_CPU_AFFINITY', '1') != '0' and hasattr(os, 'sched_setaffinity'):
         pool = avail
         if gpu_numa and torch.cuda.is_available():
-            local = _gpu_local_cpus(local_rank)
+            # (the rank's device: LOCAL_RANK, or device 0 when HIP_VISIBLE_DEVICES gives every rank one GPU)
+            local = _gpu_local_cpus(local_rank if local_rank < torch.cuda.device_count() else 0)
             if local:
                 local = [c for c in local if c in set(avail)]
                 # the ranks whose GPUs share this node split it; without knowing them, split by world
@@ -90,10 +104,31 @@ def configure_host(local_rank=0, world=1, gpu_numa=True):
                     pool = local
         cpus = core_share(pool, world, local_rank)
         try:
-            os.sched_setaffinity(0, set(cpus))
+            _pin_all_threads(set(cpus))
         except OSError:
             cpus = None
     return dict(threads=threads, cpus=cpus)
+
+
+def _pin_all_threads(cpus):
+    """`sched_setaffinity` on EVERY thread of the process: reading the GPU's PCI address above started the HIP
+    runtime, whose helper threads (the ones the host profiles blame for CPU burn) exist by now and would keep the
+    old mask - `sched_setaffinity(0, ...)` pins the calling thread and those created after it only."""
+    os.sched_setaffinity(0, cpus)
+    try:
+        tids = [int(t) for t in os.listdir('/proc/self/task')]
+    except OSError:
+        return
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, cpus)
+        except OSError:  # (a thread that ended meanwhile)
+            pass
+
+
+# True once this process is one rank of several on the host (configure_host with world > 1) or when
+# UNIRES_LIGHT_HOST=1: only then do the host sections below shrink the process-wide thread pools for good
+batch_mode = os.environ.get('UNIRES_LIGHT_HOST', '0') == '1'
 
 
 _capped = False
@@ -145,13 +180,17 @@ def cap_blas(n=1):
 
 
 def light_host(fn):
-    """Decorator: ``fn`` is a host section made of tiny matrices - see `cap_threads`, `cap_blas`."""
+    """Decorator: ``fn`` is a host section made of tiny matrices - see `cap_threads`, `cap_blas` - applied in batch
+    mode (`configure_host(world > 1)` / `batch.init_from_env`) or with UNIRES_LIGHT_HOST=1."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(*a, **k):
-        cap_threads()
-        cap_blas()
+        # (sticky, process-wide: only where ranks share a host - a lone process keeps its pools; the caps save
+        # CPU time there, not wall time: tools/rigid_profile.py)
+        if batch_mode:
+            cap_threads()
+            cap_blas()
         return fn(*a, **k)
     return wrapped
 

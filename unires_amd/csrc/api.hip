@@ -112,12 +112,14 @@ static void trim_taps(const Taps &T, const Affine &A, const Dim3i &gd, Taps &Tt,
   At = A;
   int g[3] = {gd.x, gd.y, gd.z};
   for (int d = 0; d < 3; ++d) {
-    // (r6) ... and end taps below half an ulp of the accumulated value, |t| < 2^-24 sum |t|: the +-5 taps of the default
-    // Gaussian profile at ratio 2 (3e-8 of the sum; the +-4 ones, 1.5e-5, stay) - 11 taps become 9, whatever
-    // nitorch's truncation of the Gaussian is (three recollections of it, 11 / 9 / 7 taps, all within 1e-4)
+    // (r6) ... and end taps below two ulps of the accumulated value, |t| < 2^-22 sum |t|: the +-5 taps of the default
+    // Gaussian profile at ratio 2 (2.1e-7 of the sum each; the +-4 ones, 4.3e-5, stay) - 11 taps become 9: the operator
+    // changes by <= 4.2e-7 relative, 250 x below the 1e-4 parity bar and below the disagreement of the three recollections
+    // of nitorch's truncation of that Gaussian (11 / 9 / 7 taps).  UNIRES_TRIM_TINY=0 keeps every non-zero tap.
+    static const bool tiny_on = !(getenv("UNIRES_TRIM_TINY") && atoi(getenv("UNIRES_TRIM_TINY")) == 0);
     double sum = 0.0;
     for (int i = 0; i < T.n[d]; ++i) sum += fabs((double)T.t[d][i]);
-    const double eps = sum * 5.9604644775390625e-8;
+    const double eps = tiny_on ? sum * 2.384185791015625e-7 : 1e-300;
     int lead = 0, trail = 0;
     while (lead < T.n[d] - 1 && fabs((double)T.t[d][lead]) < eps) ++lead;
     while (trail < T.n[d] - 1 - lead && fabs((double)T.t[d][T.n[d] - 1 - trail]) < eps) ++trail;
