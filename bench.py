@@ -116,7 +116,7 @@ def time_matvec(x, y, rho, sett, reps=16, ring=2, graph=True, channels=None):
     return e0.elapsed_time(e1) * 1e-3 / (reps * C)
 
 
-def time_matvec_in_solve(x, y, z, w, rho, tmp, sett):
+def time_matvec_in_solve(x, y, z, w, rho, tmp, sett, serial=True):
     """Average duration of one operator application A(p) INSIDE the CG solves of one y-update: the
     library brackets each of them with HIP events on the stream it launches on
     (unires_plan_time_matvecs; the solves then run as plain launches - a dependent kernel boundary costs
@@ -126,10 +126,12 @@ def time_matvec_in_solve(x, y, z, w, rho, tmp, sett):
     import unires_amd as U
     from unires_amd._project import _channel_plan
     plans = [_channel_plan(x[c], y[c], sett.method, sett.do_proj) for c in range(len(x))]
-    # one channel after the other, whatever the setting: with the channels on separate streams (small
-    # volumes) three kernels share the chip and a launch's wall time is not the kernel's own
+    # serial: one channel after the other, whatever the setting - with the channels on separate streams several
+    # kernels share the chip and a launch's wall time is not the kernel's own (that figure, `serial=False`, is
+    # reported beside it: a launch takes LONGER under sharing while the job as a whole gets faster)
     keep = getattr(sett, 'channel_streams', 'auto')
-    sett.channel_streams = False
+    if serial:
+        sett.channel_streams = False
     for yc in y:
         yc.dat.zero_()
     U._update_y(x, y, z, w, rho, tmp, sett)  # (warm: plans, caches, allocator)
@@ -150,6 +152,46 @@ def time_matvec_in_solve(x, y, z, w, rho, tmp, sett):
             pl.time_matvecs(False)
         sett.channel_streams = keep
     return us * 1e-6 / max(n, 1), n
+
+
+def time_matvec_in_graph(x, y, z, w, rho, tmp, sett, reps=10):
+    """What one operator application costs inside the solve AS PRODUCTION RUNS IT: a fixed-iteration solve is one
+    hipGraph, replayed (api.hip) - no host launch latency between its kernels, which the event-bracketed plain
+    launches of `time_matvec_in_solve` pay (17 us for a 13 us kernel at 181 x 217 x 181).  Event records do not
+    survive stream capture on this runtime (tools/mb_graph_event.hip: the nodes are dropped), so the figure is a
+    difference: y-updates whose solves enqueue every A(p) twice (unires_plan_time_matvecs(plan, 2): idempotent, same
+    result, still one graph) against plain ones, one channel after the other, median of `reps` each, divided by the
+    number of operator applications added.  Returns (seconds per application, y-update plain, y-update doubled)."""
+    import statistics
+    import unires_amd as U
+    from unires_amd._project import _channel_plan
+    plans = [_channel_plan(x[c], y[c], sett.method, sett.do_proj) for c in range(len(x))]
+    keep = getattr(sett, 'channel_streams', 'auto')
+    sett.channel_streams = False
+
+    def run(mode):
+        for pl in plans:
+            pl.time_matvecs(mode)
+        ts = []
+        for rep in range(reps + 2):
+            for yc in y:
+                yc.dat.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            U._update_y(x, y, z, w, rho, tmp, sett)
+            e1.record()
+            torch.cuda.synchronize()
+            if rep >= 2:  # (the first replays capture / warm)
+                ts.append(e0.elapsed_time(e1) * 1e-3)
+        return statistics.median(ts)
+    try:
+        t1 = run(False)
+        t2 = run(2)
+    finally:
+        for pl in plans:
+            pl.time_matvecs(False)
+        sett.channel_streams = keep
+    return (t2 - t1) / (len(x) * sett.cgs_max_iter), t1, t2
 
 
 def host_cpu_model():
@@ -447,6 +489,24 @@ def main():
         # figure (kept as us_per_launch_cold) came out ~5 % above the kernel durations rocprofv3 reports
         # for this command.
         t_mv, n_mv = time_matvec_in_solve(x, y, z, w, rho, tmp, sett)
+        t_mv_ingraph, t_yu1, t_yu2 = time_matvec_in_graph(x, y, z, w, rho, tmp, sett)
+        streams_on = bool(U._update.channel_streams_on(sett, y[0].dat)) and C > 1
+        t_mv_shared = time_matvec_in_solve(x, y, z, w, rho, tmp, sett, serial=False)[0] if streams_on else None
+        # ... and the job the other way round: the same steps with one channel after the other
+        value_serial = None
+        if streams_on and world == 1:
+            keep_cs = sett.channel_streams
+            sett.channel_streams = False
+            try:
+                step()
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                value_serial = args.steps * iters_per_step / (time.perf_counter() - ts)
+            finally:
+                sett.channel_streams = keep_cs
         per_channel = [time_matvec(x, y, rho, sett, ring=4, channels=[c], graph=False) * 1e6 for c in range(len(x))]
         b_mv = alg_bytes_matvec(x[0], wl['dim_y'], sett.do_proj)
         achieved = b_mv / t_mv / 1e9
@@ -463,6 +523,8 @@ def main():
                        'channel_streams': bool(U._update.channel_streams_on(sett, y[0].dat)),
                        'channel_streams_setting': getattr(sett, 'channel_streams', 'auto'),
                        'parallelism': 'one subject per GPU, no data-path collective'},
+            # `value` with one channel after the other (settings.channel_streams = False), same steps
+            'value_channels_serial': value_serial,
             'subjects_per_sec': world / t_subject,
             'subjects_per_sec_note': 'subject = %d full ADMM iterations (y-update C x 20 CG, objective, z- and '
                                      'w-update) run on every rank between barriers, max over ranks: %.3f s '
@@ -485,11 +547,24 @@ def main():
                          'traffic': (traffic or {}).get('bytes_per_launch'), 'traffic_source': traffic,
                          'alg_bytes_per_launch': b_mv, 'us_per_launch': t_mv * 1e6,
                          'launches_timed': n_mv,
+                         # the same launches as the TIMED REGION runs them when the channels share the chip
+                         # (streams of their own, persistent grids sized for it): longer launches, a faster job
+                         'us_per_launch_channels_overlapped': None if t_mv_shared is None else t_mv_shared * 1e6,
+                         # ... and inside the replayed hipGraph that a fixed-iteration solve is in production (no host
+                         # launch latency): (y-update with every A(p) enqueued twice - plain y-update) / applications
+                         'us_per_launch_in_graph': t_mv_ingraph * 1e6,
+                         'frac_in_graph': b_mv / t_mv_ingraph / 1e9 / HBM_PEAK_GBS,
+                         'in_graph_y_update_ms': [t_yu1 * 1e3, t_yu2 * 1e3],
                          'us_per_launch_cold': t_mv_eager * 1e6, 'frac_cold': b_mv / t_mv_eager / 1e9 / HBM_PEAK_GBS,
                          'us_per_launch_graph': t_mv_graph * 1e6, 'us_per_launch_eager': t_mv_eager * 1e6,
                          'us_per_launch_by_channel': per_channel,
                          'timing': 'us_per_launch: HIP events recorded by the library around every A(p) of one '
-                                   "y-update's CG solves, on the stream they are launched on (plain launches); "
+                                   "y-update's CG solves, on the stream they are launched on (plain launches), one "
+                                   'channel after the other - the kernels alone on the chip; '
+                                   '_in_graph: marginal cost of an A(p) inside the hipGraph a tol = 0 solve is '
+                                   'replayed as (doubled-matvec solves minus plain ones, medians of 10); '
+                                   '_channels_overlapped: the same with the channels on streams of their own, as '
+                                   "`value`'s timed region runs them; "
                                    '_cold = _eager: stand-alone launches cycling through more p / q buffers than the '
                                    'Infinity Cache holds (the round-2 method), _graph: those replayed as one hipGraph, '
                                    '_by_channel: cold, one channel at a time'},

@@ -159,6 +159,11 @@ int unires_plan_create(unires_plan_t **plan, const int32_t dim_y[3], const float
 int unires_plan_destroy(unires_plan_t *plan);
 /* Replace repeat n's descriptor (after a rigid / scaling update; _update.py:576). */
 int unires_plan_set_repeat(unires_plan_t *plan, int32_t n, const unires_repeat_t *repeat);
+/* Hint: the caller keeps `n_concurrent` solves (this plan's and other plans') in flight on the device at once - the
+ * channels of one y-update, which do not couple (unires/_update.py:122-150), each on a stream of its own.  The
+ * plan then sizes the persistent kernels of its matvec so that other channels' kernels find room on the CUs (see
+ * api.hip; results are unchanged, reductions are summed in another - still fixed - order).  1 = the default. */
+int unires_plan_set_concurrency(unires_plan_t *plan, int32_t n_concurrent);
 /* Bytes of device workspace the plan owns. */
 int64_t unires_plan_workspace_bytes(const unires_plan_t *plan);
 /* Which kernels repeat n's operator runs on (no counterpart in the reference, whose _proj_apply
@@ -177,7 +182,11 @@ int unires_orient_of(const float M[12], int32_t perm[3], int32_t flip[3]);
 /* Measurement aid (no counterpart in the reference; bench.py's roofline leg).  While on,
  * unires_cg_solve launches its kernels one by one (no hipGraph replay) and brackets every operator
  * application A(p) of the solve with HIP events on the caller's stream.  Meaningful with tol == 0
- * only: launches enqueued after a solve has converged return at entry and are still counted. */
+ * only: launches enqueued after a solve has converged return at entry and are still counted.
+ * on == 2: no events; instead every A(p) of a solve is enqueued TWICE (it is idempotent: same result), the solve
+ * stays what it is in production - one hipGraph replayed.  The difference between a solve timed this way and a
+ * plain one, divided by its iterations, is what an operator application costs INSIDE the replayed graph
+ * (kernel + its dependent boundary, no host launch latency): bench.py's `us_per_launch_in_graph`. */
 int unires_plan_time_matvecs(unires_plan_t *plan, int32_t on);
 /* Waits for the recorded events; returns how many applications were recorded since the last call and
  * the sum of their durations (microseconds), and forgets them. */

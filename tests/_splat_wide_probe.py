@@ -1,7 +1,8 @@
 """Prints sha256 digests of At v and AtA p for thick slices along x, y and z on a 64 x 32 x 60 volume
-(128 splat tiles = 32 four-wave workgroups).  test_gpu_ops.py runs it as is and with
-UNIRES_SPLAT2_WIDE=2 (read once per process), which makes the launcher take the 16-wave form - on full-size
-volumes the choice of a conv-up table too long for four 4-wave workgroups per CU."""
+(128 splat tiles = 32 four-wave workgroups), and of the single-pass A^T A of the denoising regime.  test_gpu_ops.py
+runs it as is, with the persistent grids capped by the runtime's occupancy answer (UNIRES_SPLAT2_RESIDENT=1) and with
+the plans told about neighbours (PROBE_CONCURRENCY=3 -> unires_plan_set_concurrency; UNIRES_SHARE_S2 / _F1 = 1 make
+the caps that follow 16 workgroups, below this volume's grids): the same tiles, walked by fewer waves."""
 import hashlib
 import os
 import sys
@@ -28,8 +29,17 @@ for axis in range(3):
     v = (torch.rand(dim_x) + 0.5).to(dev)
     # plan-level operators: the schedule-driven splat of the hot path (U._proj_apply runs the op-level kernels)
     plan = ChannelPlan(dim_y, (1.0, 1.0, 1.0), [(po, 1.0)], 'super-resolution', True, device=dev)
+    plan.set_concurrency(int(os.environ.get('PROBE_CONCURRENCY', '1')))
     for op, arg in (('At', v), ('AtA', p)):
         out = plan.proj_apply(0, op, arg)
         print(op, axis, hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest())
     q = plan.matvec(p, 0.7, 0.05)
     print('AtA', 3 + axis, hashlib.sha256(q.cpu().numpy().tobytes()).hexdigest())
+
+# denoising regime: pull + push + stencil in one pass (k_ata1) on a rotated 1 mm observation of the same volume
+po = U._proj_info(dim_y, mat_y, dim_y, mat_y, rigid=rigid, device=dev)
+plan = ChannelPlan(dim_y, (1.0, 1.0, 1.0), [(po, 1.0)], 'denoising', True, device=dev)
+plan.set_concurrency(int(os.environ.get('PROBE_CONCURRENCY', '1')))
+torch.manual_seed(11)
+p = (torch.rand(dim_y) + 0.5).to(dev)
+print('AtA', 6, hashlib.sha256(plan.matvec(p, 0.7, 0.05).cpu().numpy().tobytes()).hexdigest())

@@ -99,3 +99,19 @@ def test_iteration_budget_beyond_the_old_graph_limit(dev):
     assert rel_err(yg[0].dat.cpu(), xr) < 1e-4
     with pytest.raises(ValueError, match='needs a tolerance'):
         plan.cg(b.to(dev), yg[0].dat, float(rho), float(yg[0].lam), max_iter=5000, tolerance=0.0)
+    # ... and under stream capture nothing runs until the graph is launched - the chunk feeder would wait for ever
+    # and its watchdog would query a capturing stream: refused up front, the capture survives
+    side = torch.cuda.Stream()
+    bg = b.to(dev)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        g.capture_begin()
+        try:
+            with pytest.raises(Exception, match='cannot join a stream capture'):
+                plan.cg(bg, yg[0].dat, float(rho), float(yg[0].lam), max_iter=5000, tolerance=1e-5, sync=False)
+            yg[0].dat.mul_(1.0)  # (something to capture)
+        finally:
+            g.capture_end()
+    g.replay()
+    torch.cuda.synchronize()

@@ -298,20 +298,22 @@ def test_isotropic_downsampling_under_large_rotations(dev, prof_ip, rot):
             assert err < 1e-5, '%s (%s kernels) differs from the oracle: %.3g' % (op, name, err)
 
 
-def test_sixteen_wave_splat_workgroups_give_the_same_bits(dev):
-    """k_splat2<AXIS, 16> (one 16-wave workgroup per CU sharing one conv-up table; taken when the table
-    leaves room for fewer 4-wave workgroups than the grid was sized for; UNIRES_SPLAT2_WIDE=2 forces it)
-    and a grid capped below its size (UNIRES_SPLAT2_RESIDENT=1 on a 32-workgroup grid... capped at 256)
-    walk the same tiles with the same per-tile arithmetic as the plain launch: At v and AtA p for thick
-    slices along x, y and z must not change by a bit."""
+def test_smaller_persistent_grids_give_the_same_bits(dev):
+    """k_splat2 / k_ata1 under a grid smaller than the one the schedule was laid out with - capped by the
+    runtime's occupancy answer (UNIRES_SPLAT2_RESIDENT=1), or by `unires_plan_set_concurrency` (channels of a
+    y-update on streams of their own: the plan leaves its neighbours room; UNIRES_SHARE_S2 / _F1 = 1 make that cap
+    16 workgroups, below the 32 this volume asks for) - walk the same tiles with the same per-tile arithmetic as
+    the plain launch: At v and AtA p for thick slices along x, y and z, and the denoising regime's one-pass AtA p,
+    must not change by a bit."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     outs = []
-    for env_extra in ({}, {'UNIRES_SPLAT2_WIDE': '2'}, {'UNIRES_SPLAT2_RESIDENT': '1', 'UNIRES_SPLAT2_WIDE': '0'}):
+    for env_extra in ({}, {'UNIRES_SPLAT2_RESIDENT': '1', 'UNIRES_F1_RESIDENT': '1'},
+                      {'PROBE_CONCURRENCY': '3', 'UNIRES_SHARE_S2': '1', 'UNIRES_SHARE_F1': '1'}):
         r = subprocess.run([sys.executable, os.path.join(here, '_splat_wide_probe.py')], env=dict(os.environ, **env_extra),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.split()[0] in ('At', 'AtA')])
-    assert len(outs[0]) == 9 and outs[0] == outs[1] == outs[2]
+    assert len(outs[0]) == 10 and outs[0] == outs[1] == outs[2]

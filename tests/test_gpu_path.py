@@ -704,12 +704,13 @@ def test_update_y_on_channel_streams_and_one_after_the_other(dev, case):
 def test_matvec_timing_hooks_count_the_solve_and_leave_it_unchanged(dev):
     """unires_plan_time_matvecs / unires_plan_matvec_time (bench.py's roofline leg): one event pair per
     A(p) of the solve - max_iter of them in fixed-iteration mode - and the solve, then run as plain
-    launches instead of a hipGraph, returns the same bits."""
+    launches instead of a hipGraph, returns the same bits.  Mode 2 (every A(p) enqueued twice inside the solve's
+    graph, bench.py's `us_per_launch_in_graph`): no events, the same bits again."""
     import unires_amd as U
     from unires_amd._project import _channel_plan
     prob = make_problem(**CASES['sr_3ch_axes'])
     outs = []
-    for timed in (False, True):
+    for timed in (False, True, 2):
         x, y, sett = gpu_structs(prob, dev)
         sett.cgs_max_iter, sett.cgs_tol = 7, 0.0
         z, w = prob['z'].to(dev), prob['w'].to(dev)
@@ -721,12 +722,13 @@ def test_matvec_timing_hooks_count_the_solve_and_leave_it_unchanged(dev):
         torch.cuda.synchronize()
         for pl in plans:
             n, us = pl.matvec_time()
-            assert n == (7 if timed else 0)
-            assert (us > 0.0) == timed
+            assert n == (7 if timed is True else 0)
+            assert (us > 0.0) == (timed is True)
             pl.time_matvecs(False)
         outs.append([yc.dat.clone() for yc in y])
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
 
 
 def test_one_kernel_conv_passes_are_bit_identical_to_the_separate_ones():

@@ -55,6 +55,7 @@ SIGNATURES = {
                                      C.c_int32, C.POINTER(Repeat), C.c_float]),
     'unires_plan_destroy': (C.c_int, [C.c_void_p]),
     'unires_plan_set_repeat': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Repeat)]),
+    'unires_plan_set_concurrency': (C.c_int, [C.c_void_p, C.c_int32]),
     'unires_plan_workspace_bytes': (C.c_int64, [C.c_void_p]),
     'unires_orient_of': (C.c_int, [c_f32x12, c_i32x3, c_i32x3]),
     'unires_plan_repeat_info': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32 * 8]),

@@ -73,6 +73,7 @@ class ChannelPlan:
         arr = (Repeat * len(repeats))(*[_repeat_desc(po, tau, method, self.regime, keep)
                                        for po, tau in repeats])
         self._h = C.c_void_p()
+        self._concurrency = 1
         check(self.lib.unires_plan_create(C.byref(self._h), i3(self.dim_y), f3(vx_y), self.regime,
                                           len(repeats), arr, fov_tol))
         self.dims_x = [self.dim_y if self.regime == REGIME_IDENTITY else tuple(po.dim_x)
@@ -115,8 +116,10 @@ class ChannelPlan:
     @on_device
     def time_matvecs(self, on=True):
         """Measurement aid: bracket every operator application of the following solves with HIP events
-        (the solves then run as plain launches, not as a hipGraph)."""
-        check(self.lib.unires_plan_time_matvecs(self._h, 1 if on else 0))
+        (the solves then run as plain launches, not as a hipGraph).  ``on=2``: no events - every A(p) is enqueued
+        twice instead, inside the solve's hipGraph (same result; the time difference to a plain solve is the cost of
+        the operator applications as production runs them)."""
+        check(self.lib.unires_plan_time_matvecs(self._h, 2 if on == 2 else (1 if on else 0)))
 
     @on_device
     def matvec_time(self):
@@ -130,6 +133,15 @@ class ChannelPlan:
         keep = []
         r = _repeat_desc(po, tau, self.method, self.regime, keep)
         check(self.lib.unires_plan_set_repeat(self._h, n, C.byref(r)))
+
+    def set_concurrency(self, n):
+        """Tell the plan that ``n`` solves run on the device at once (the channels of a y-update on streams of their
+        own): its persistent kernels then leave room for the others' (``unires_plan_set_concurrency``).  Free when
+        ``n`` is what the plan already has."""
+        n = max(1, int(n))
+        if n != self._concurrency:
+            check(self.lib.unires_plan_set_concurrency(self._h, n))
+            self._concurrency = n
 
     def _y(self, t, name):
         v, _ = _vol(t, name)

@@ -87,6 +87,7 @@ def _update_y(x, y, z, w, rho, tmp, sett, info=None):
     if not concurrent:
         for c in range(C):
             plan = _channel_plan(x[c], y[c], sett.method, sett.do_proj, vx_y)
+            plan.set_concurrency(1)
             lam = float(y[c].lam)
             if getattr(sett, 'cache_atx', True) and not sync:
                 plan.rhs_cached([xn.dat for xn in x[c]], w[c], z[c], rho, lam, out=tmp)
@@ -106,6 +107,7 @@ def _update_y(x, y, z, w, rho, tmp, sett, info=None):
     plans, bs = [], []
     for c in range(C):
         plan = _channel_plan(x[c], y[c], sett.method, sett.do_proj, vx_y)
+        plan.set_concurrency(C)  # (its persistent kernels leave the other channels' kernels room on the CUs)
         lam = float(y[c].lam)
         b = tmp if c == 0 else plan.rhs_buffer(tmp)
         with torch.cuda.stream(streams[c]):
@@ -127,16 +129,18 @@ def _update_y(x, y, z, w, rho, tmp, sett, info=None):
     return y
 
 
-# voxels of y below which the channels of a y-update go to separate HIP streams under 'auto'
-# (struct.settings.channel_streams): between 181 x 217 x 181 (7.1 M: streams +24 %) and 256^3 (16.8 M:
-# one channel after the other +6 %)
-CHANNEL_STREAMS_MAX_VOXELS = 10_000_000
+# struct.settings.channel_streams = 'auto': the channels of a y-update go to separate HIP streams whenever there is
+# more than one.  (Rounds 3 - 5 stopped at 10 M voxels: at 256^3 three streams bought nothing - every matvec kernel
+# fills the chip - and cost 6 % before the runtime's signal pool was raised.  Since round 6 a plan that is told about
+# its neighbours, `ChannelPlan.set_concurrency`, sizes its persistent kernels for them: profiles/r06_overlap_scan.txt,
+# +6 % CG it/s at 256^3 x 3, +5 % at 384^3 x 4, +24 % at 181 x 217 x 181 x 3.)  None: no upper bound.
+CHANNEL_STREAMS_MAX_VOXELS = None
 
 
 def channel_streams_on(sett, dat):
     cs = getattr(sett, 'channel_streams', 'auto')
     if cs == 'auto':
-        return dat.numel() < CHANNEL_STREAMS_MAX_VOXELS
+        return CHANNEL_STREAMS_MAX_VOXELS is None or dat.numel() < CHANNEL_STREAMS_MAX_VOXELS
     return bool(cs)
 
 

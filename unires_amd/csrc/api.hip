@@ -324,6 +324,7 @@ struct unires_plan {
   float *r = nullptr, *p = nullptr, *ap = nullptr, *ax = nullptr;  // N_y each
   // measurement aid (unires_plan_time_matvecs): event pairs around the operator applications of a solve
   bool timing = false;
+  bool twice = false;  // unires_plan_time_matvecs(plan, 2): every A(p) of a solve is enqueued twice (same result)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
   float *gbuf = nullptr;                                           // max N_g
   float *gbuf2 = nullptr;  // second grid-space scratch, only for many-tap profiles (separable passes)
@@ -363,6 +364,10 @@ struct unires_plan {
   hipEvent_t last_use = nullptr;
   std::vector<hipStream_t> use_streams;
   bool captured_use = false;
+  // unires_plan_set_concurrency: how many solves the caller keeps in flight on the device (channels of a y-update on
+  // streams of their own), and the caps on the persistent kernels' grids that follow from it (0: the whole chip)
+  int concurrency = 1;
+  int cap_s2 = 0, cap_f1 = 0;
 };
 
 // Drop the captured CG solve.  A launch of it may still be in flight (the ADMM loop never syncs):
@@ -397,8 +402,9 @@ static void mark_use(unires_plan *pl, hipStream_t st) {
 static void await_use(unires_plan *pl) {
   static const bool device_wide = getenv("UNIRES_SET_REPEAT_DEVICE_SYNC") != nullptr;  // (measurement: the r4 behaviour)
   if (pl->captured_use || device_wide) {
+    // (sticky: a graph the caller captured may be replayed at any time without an entry point being called - a plan
+    // that was ever used under capture is waited for device-wide from then on)
     (void)hipDeviceSynchronize();
-    pl->captured_use = false;
     pl->use_streams.clear();
     return;
   }
@@ -804,7 +810,10 @@ extern "C" int unires_plan_destroy(unires_plan_t *plan) {
 
 extern "C" int unires_plan_time_matvecs(unires_plan_t *plan, int32_t on) {
   if (!plan) return fail(UNIRES_ERR_NULL, "null argument");
-  plan->timing = on != 0;
+  const bool twice = on == 2;
+  if (twice != plan->twice) drop_cg_graph(plan);  // (a captured solve has its launches baked in)
+  plan->twice = twice;
+  plan->timing = on == 1;
   if (!plan->timing) drop_timing(plan);
   return UNIRES_OK;
 }
@@ -837,8 +846,9 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
     return fail(UNIRES_ERR_DIM, "new repeat needs the separable-conv scratch the plan was built without");
   // The tables rebuilt below (pull records, splat schedule, conv tables) are rewritten by kernels on
   // the NULL stream and synchronous copies; work queued on the caller's - possibly non-blocking -
-  // streams may still be reading them: wait for the plan's last launch (an event every entry point
-  // records - not the whole device: the other channels' streams keep running).
+  // streams may still be reading them: wait for the plan's last launches - every entry point REMEMBERS its stream
+  // before it enqueues anything (mark_use), await_use records an event on each remembered stream and waits for it;
+  // not the whole device: the other channels' streams keep running.
   await_use(plan);
   drop_cg_graph(plan);  // the captured solve has the old operator baked in
   plan->prec_ready = false;  // a preconditioner built for the old operator is stale
@@ -887,6 +897,33 @@ extern "C" int unires_plan_set_repeat(unires_plan_t *plan, int32_t n,
   if (!rc) rc = build_repeat_kernels(plan, plan->reps[n]);
   sched_set_thorough(true);
   return rc;
+}
+
+// How many solves of OTHER plans the caller keeps in flight next to this one's (the channels of a y-update, each
+// on a stream of its own: unires/_update.py:122-150 has no cross-channel term).  The matvec's persistent kernels
+// (k_splat2, k_ata1) normally take every wave slot / register the chip has - a channel's kernels then run one
+// after the other's whatever the streams say.  With room left for them, the bandwidth-bound CG vector kernels of
+// one channel run under the issue-bound splat of another: measured at 256^3 x 3 (profiles/r06_overlap_scan.txt)
+// 4 879 -> 5 190 CG it/s with 384 - 448 splat workgroups of 1 024; at 384^3 x 4 a smaller grid LOSES (the pull and
+// conv kernels between the splats leave room anyway): the cap applies below 2^25 output voxels.  A launch under a
+// cap takes longer and the job as a whole gets faster.  n <= 1: the whole chip (the default).
+extern "C" int unires_plan_set_concurrency(unires_plan_t *plan, int32_t n_concurrent) {
+  if (!plan) return fail(UNIRES_ERR_NULL, "null argument");
+  if (n_concurrent < 1 || n_concurrent > 64) return fail(UNIRES_ERR_ARG, "concurrency out of range (1 .. 64)");
+  if (n_concurrent == plan->concurrency) return UNIRES_OK;
+  int cap_s2 = 0, cap_f1 = 0;
+  if (n_concurrent > 1 && plan->dy.numel() <= (1ull << 25)) {
+    int dev = 0, ncu = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    static const int s2_16 = getenv("UNIRES_SHARE_S2") ? atoi(getenv("UNIRES_SHARE_S2")) : 28;  // workgroups per 16 CUs
+    static const int f1_16 = getenv("UNIRES_SHARE_F1") ? atoi(getenv("UNIRES_SHARE_F1")) : 48;
+    cap_s2 = std::max(8, ncu * s2_16 / 16 / 8 * 8);  // 448 of 1 024 on 256 CUs
+    cap_f1 = std::max(8, ncu * f1_16 / 16 / 8 * 8);  // 768 of 1 024
+  }
+  if (cap_s2 != plan->cap_s2 || cap_f1 != plan->cap_f1) drop_cg_graph(plan);  // (a captured solve has its grids baked in)
+  plan->concurrency = n_concurrent, plan->cap_s2 = cap_s2, plan->cap_f1 = cap_f1;
+  return UNIRES_OK;
 }
 
 extern "C" int64_t unires_plan_workspace_bytes(const unires_plan_t *plan) {
@@ -1040,14 +1077,14 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
     const float4 *tab = (const float4 *)R.ctab_dev[src.S.dim == 2 ? 1 : 0];
     if (!launch_splat2(R.sched, h, R.dim_h.numel(), tab, R.ctab_n, R.src_stride, R.ctab_step, R.src_stride,
                        R.ctab_step, A, alpha, ep, out, pl->dy, done, st))
-      return ep.partials ? splat2_blocks(pl->dy) : 0;
+      return ep.partials ? splat2_blocks(pl->dy, ep.grid_cap) : 0;
   }
   if (!use_tile && mode == nullptr && !R.hyb && R.sched.valid && (src.convup != 0) == (R.sched.axis >= 0)) {
     const float4 *tab = src.convup ? (const float4 *)R.ctab_dev[src.S.dim >= 0 ? 1 : 0] : nullptr;
     const size_t numel = src.convup ? src.xd.numel() : src.gd.numel();
     if (!launch_splat2(R.sched, src.data, numel, tab, R.ctab_n, R.src_stride, R.ctab_step, R.src_stride,
                        R.ctab_step, A, alpha, ep, out, pl->dy, done, st))
-      return ep.partials ? splat2_blocks(pl->dy) : 0;
+      return ep.partials ? splat2_blocks(pl->dy, ep.grid_cap) : 0;
   }
   if (!use_tile &&
       !launch_splat(src, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
@@ -1060,7 +1097,7 @@ static int push_any(unires_plan *pl, const PushSrc &src, const Repeat &R, float 
     if (mode == nullptr && R.sched.valid && R.sched.axis < 0 &&
         !launch_splat2(R.sched, d.data, d.gd.numel(), nullptr, 0, R.src_stride, 1, 0, 0, A, alpha, ep, out,
                        pl->dy, done, st))
-      return ep.partials ? splat2_blocks(pl->dy) : 0;
+      return ep.partials ? splat2_blocks(pl->dy, ep.grid_cap) : 0;
     if (!launch_splat(d, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st))
       return ep.partials ? splat_blocks(pl->dy, A) : 0;
     (void)launch_push_tile(d, A, R.Afinv, R.safe, alpha, pl->fov_tol, ep, out, pl->dy, done, st);
@@ -1089,6 +1126,7 @@ static void at_accumulate(unires_plan *pl, const Repeat &R, const float *x, floa
   }
   PushEpilogue ep;
   ep.accumulate = accumulate ? 1 : 0;
+  ep.grid_cap = pl->cap_s2;
   const bool sr = pl->regime == UNIRES_REGIME_SUPERRES;
   push_any(pl, push_src(R, x, sr, sr ? R.scl : 0.f), R, alpha, ep, out, nullptr, st);
 }
@@ -1101,6 +1139,7 @@ extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, con
     return fail(UNIRES_ERR_ARG, "Undefined operator");
   if (in == out) return fail(UNIRES_ERR_ARG, "proj_apply cannot run in place");
   hipStream_t st = (hipStream_t)stream;
+  mark_use(plan, st);  // (before anything is enqueued: an error return below is remembered too)
   const Repeat &R = plan->reps[n];
   const size_t ny = plan->dy.numel();
   if (plan->regime == UNIRES_REGIME_IDENTITY) {  // operator 'none': return dat
@@ -1139,7 +1178,6 @@ extern "C" int unires_proj_apply(unires_plan_t *plan, int32_t n, int32_t op, con
       push_any(plan, src, R, 1.f, PushEpilogue(), out, nullptr, st);
     }
   }
-  mark_use(plan, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -1202,11 +1240,13 @@ static int matvec(unires_plan *pl, float rho, float lam, const float *p, float *
     }
     if (n + 1 == nrep) ep.partials = part, ep.objb = objb;
     // denoising regime: pull, push, stencil and dot in ONE pass over p (ata1.hip)
+    ep.grid_cap = pl->cap_f1;
     if (pl->regime == UNIRES_REGIME_DENOISE && R.f1.valid &&
         !launch_ata1(R.f1, p, R.Af, R.tau, ep, q, pl->dy, done, st)) {
-      npart = ep.partials ? ata1_blocks(pl->dy) : 0;
+      npart = ep.partials ? ata1_blocks(pl->dy, ep.grid_cap) : 0;
       continue;
     }
+    ep.grid_cap = pl->cap_s2;
     const PushSrc src = ata_forward(pl, R, p, done, st);
     npart = push_any(pl, src, R, R.tau, ep, q, done, st);
   }
@@ -1218,9 +1258,9 @@ extern "C" int unires_ata_matvec(unires_plan_t *plan, float rho, float lam, cons
   if (!plan || !p || !q) return fail(UNIRES_ERR_NULL, "null argument");
   if (p == q) return fail(UNIRES_ERR_ARG, "matvec cannot run in place");
   hipStream_t st = (hipStream_t)stream;
+  mark_use(plan, st);  // (before anything is enqueued: an error return below is remembered too)
   const int g = matvec(plan, rho, lam, p, q, dot_dev ? plan->part0 : nullptr, nullptr, st);
   if (dot_dev) launch_sum_to(plan->part0, g, dot_dev, st);
-  mark_use(plan, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -1242,6 +1282,7 @@ extern "C" int unires_precond_build(unires_plan_t *plan, int32_t precond_mode, f
   if (precond_mode != UNIRES_PRECOND_JACOBI && precond_mode != UNIRES_PRECOND_FFT)
     return fail(UNIRES_ERR_UNSUPPORTED, "preconditioner modes: identity (0), Jacobi (1), FFT (2)");
   hipStream_t st = (hipStream_t)stream;
+  mark_use(plan, st);  // (before anything is enqueued: an error return below is remembered too)
   const size_t ny = plan->dy.numel();
   if (precond_mode == UNIRES_PRECOND_FFT) {
     if (int rc = fftpre_setup(plan->fft, plan->dy))
@@ -1291,7 +1332,6 @@ extern "C" int unires_precond_build(unires_plan_t *plan, int32_t precond_mode, f
   }
   if (m_out)
     HIP_TRY(hipMemcpyAsync(m_out, plan->precM, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
-  mark_use(plan, st);
   CHECK_LAUNCH();
   plan->prec_rho = rho, plan->prec_lam = lam, plan->prec_mode = precond_mode, plan->prec_ready = true;
   return UNIRES_OK;
@@ -1301,6 +1341,7 @@ extern "C" int unires_precond_apply(unires_plan_t *plan, const float *in, float 
   if (!plan || !in || !out) return fail(UNIRES_ERR_NULL, "null argument");
   if (in == out) return fail(UNIRES_ERR_ARG, "precond_apply cannot run in place");
   hipStream_t st = (hipStream_t)stream;
+  mark_use(plan, st);  // (before anything is enqueued: an error return below is remembered too)
   const size_t ny = plan->dy.numel();
   if (!plan->prec_ready || plan->prec_mode == UNIRES_PRECOND_IDENTITY) {
     HIP_TRY(hipMemcpyAsync(out, in, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1309,7 +1350,6 @@ extern "C" int unires_precond_apply(unires_plan_t *plan, const float *in, float 
   } else {
     launch_div(in, plan->precM, out, ny, st);
   }
-  mark_use(plan, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -1321,12 +1361,12 @@ extern "C" int unires_rhs_assemble(unires_plan_t *plan, const float *const *x_pt
   for (size_t n = 0; n < plan->reps.size(); ++n)
     if (!x_ptrs[n]) return fail(UNIRES_ERR_NULL, "null observation pointer");
   hipStream_t st = (hipStream_t)stream;
+  mark_use(plan, st);  // (before anything is enqueued: an error return below is remembered too)
   // b = -lam * Dt(w - rho z)   (unires/_update.py:131-133)
   launch_div(w_c, z_c, 1.f, -rho, plan->dy, plan->vx, -lam, nullptr, b, st);
   // b += tau_n At_n x_n         (unires/_update.py:125-128)
   for (size_t n = 0; n < plan->reps.size(); ++n)
     at_accumulate(plan, plan->reps[n], x_ptrs[n], b, plan->reps[n].tau, true, st);
-  mark_use(plan, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -1337,12 +1377,12 @@ extern "C" int unires_atx_assemble(unires_plan_t *plan, const float *const *x_pt
   for (size_t n = 0; n < plan->reps.size(); ++n)
     if (!x_ptrs[n]) return fail(UNIRES_ERR_NULL, "null observation pointer");
   hipStream_t st = (hipStream_t)stream;
+  mark_use(plan, st);  // (before anything is enqueued: an error return below is remembered too)
   if (plan->regime == UNIRES_REGIME_IDENTITY)
     HIP_TRY(hipMemsetAsync(atx, 0, plan->dy.numel() * sizeof(float), st));
   for (size_t n = 0; n < plan->reps.size(); ++n)
     at_accumulate(plan, plan->reps[n], x_ptrs[n], atx, plan->reps[n].tau,
                   n > 0 || plan->regime == UNIRES_REGIME_IDENTITY, st);
-  mark_use(plan, st);
   CHECK_LAUNCH();
   return UNIRES_OK;
 }
@@ -1408,6 +1448,7 @@ static int cg_enqueue_iters(unires_plan *pl, float rho, float lam, const float *
         ev0 = nullptr;
       }
     }
+    if (pl->twice) (void)matvec(pl, rho, lam, pl->p, pl->ap, pl->part0, done, st);  // (measurement: see the header)
     const int g = matvec(pl, rho, lam, pl->p, pl->ap, pl->part0, done, st);
     if (ev0 && ev1) {
       (void)hipEventRecord(ev1, st);
@@ -1738,10 +1779,14 @@ extern "C" int unires_cg_solve(unires_plan_t *plan, float rho, float lam, const 
   const bool fft = precond_mode == UNIRES_PRECOND_FFT;
   hipStream_t st = (hipStream_t)stream;
   unires_plan *pl = plan;
+  mark_use(pl, st);  // (before anything is enqueued: a failed start or drive below is remembered too)
 
   // (a stream under capture - e.g. the caller's torch.cuda.graph - runs nothing until the graph is launched: the
   // chunk feeder would wait for progress that never comes.  The whole solve then joins the capture, as in r3;
   // kernels after convergence return at entry.)
+  if (stream_capturing(st) && tol != 0.0 && max_iter > kMaxCgIter)
+    return fail(UNIRES_ERR_ARG, "a solve with a tolerance and more than 4096 iterations cannot join a stream capture "
+                                "(it is fed to the device chunk by chunk, following its progress)");
   if (cg_chunked(tol, max_iter) && !(stream_capturing(st) && max_iter <= kMaxCgIter)) {
     std::vector<CgRun> runs(1, cg_make_run(pl, rho, lam, b, x, max_iter, tol, stop_mode, precond_mode, st));
     if ((rc = cg_run_start(runs[0]))) return rc;
@@ -1801,6 +1846,10 @@ extern "C" int unires_cg_solve_many(int32_t n, unires_plan_t *const *plans, cons
   }
   bool capturing = false;
   for (int c = 0; c < n; ++c) capturing = capturing || stream_capturing((hipStream_t)streams[c]);
+  if (capturing && tol != 0.0 && max_iter > kMaxCgIter)
+    return fail(UNIRES_ERR_ARG, "a solve with a tolerance and more than 4096 iterations cannot join a stream capture "
+                                "(it is fed to the device chunk by chunk, following its progress)");
+  for (int c = 0; c < n; ++c) mark_use(plans[c], (hipStream_t)streams[c]);  // (before anything is enqueued)
   if (!cg_chunked(tol, max_iter) || (capturing && max_iter <= kMaxCgIter)) {  // nothing to steer: each solve is enqueued whole
     for (int c = 0; c < n; ++c) {
       const int rc = unires_cg_solve(plans[c], rho[c], lam[c], b[c], x[c], max_iter, tol, stop_mode, precond_mode,

@@ -247,7 +247,10 @@ __global__ void __launch_bounds__(kWave)
         float ax, ay, az, bx, by, bz;
         f1_point(B.A, ra.x, ra.y, ra.z, (float)((int)m.k0 + pl - (int)m.pos), ax, ay, az);
         f1_point(B.A, rq.x, rq.y, rq.z, (float)((int)q.k0 + pl - (int)q.pos), bx, by, bz);
-        if (fabsf(floorf(ax) - floorf(bx)) < 2.f && fabsf(floorf(ay) - floorf(by)) < 2.f) {
+        // (the kernel floors g - (tile0 - 1): for a tile on the volume's low faces the base is -1 and an accepted
+        // in-tolerance point with g in (-6e-8, 0) rounds g + 1 to 1.0 - its cell moves from -1 to 0; the test uses
+        // the kernel's local arithmetic, not the floor of the global coordinate)
+        if (fabsf(floorf(ax - flx) - floorf(bx - flx)) < 2.f && fabsf(floorf(ay - fly) - floorf(by - fly)) < 2.f) {
           free = false;
           break;
         }
@@ -835,17 +838,18 @@ __global__ void __launch_bounds__(kWave *NW) k_ata1(F1Args P, const int *__restr
   }
 }
 
-static int f1_grid(Dim3i dd, int tx, int ty) {
+static int f1_grid(Dim3i dd, int tx, int ty, int share_cap = 0) {
   const int nt = f1_ntiles(dd, tx, ty);
-  static const int cap = getenv("UNIRES_F1_BLOCKS") ? atoi(getenv("UNIRES_F1_BLOCKS")) : 1024;
+  static const int cap_env = getenv("UNIRES_F1_BLOCKS") ? atoi(getenv("UNIRES_F1_BLOCKS")) : 0;
+  const int cap = cap_env > 0 ? cap_env : (share_cap >= 8 ? share_cap : 1024);
   const int want = (nt + kF1Waves - 1) / kF1Waves;
   return want < cap ? want : cap;
 }
 
-int ata1_blocks(Dim3i dd) {
+int ata1_blocks(Dim3i dd, int grid_cap) {
   int tx, ty;
   f1_shape(tx, ty);
-  return f1_grid(dd, tx, ty) * kF1Waves;
+  return f1_grid(dd, tx, ty, grid_cap) * kF1Waves;
 }
 
 static const void *f1_fn(int tx) {
@@ -890,7 +894,7 @@ int launch_ata1(const F1Sched &S, const float *src, const Affine &A, float alpha
   P.a0 = ep.p ? ep.a0 : 0.f, P.cx = ep.p ? ep.cx : 0.f, P.cy = ep.p ? ep.cy : 0.f, P.cz = ep.p ? ep.cz : 0.f;
   P.dst = dst, P.dd = dd, P.accumulate = ep.accumulate, P.partials = ep.partials, P.objb = ep.partials ? ep.objb : nullptr;
   P.want_dot = ep.partials != nullptr;
-  const dim3 grid(f1_grid(dd, tx, ty)), block(kWave * kF1Waves);
+  const dim3 grid(f1_grid(dd, tx, ty, ep.grid_cap)), block(kWave * kF1Waves);
   if (grid.x >= 8) {
     for (int x = 0; x <= 8; ++x) P.xlo[x] = S.xcd_lo[x];
   } else {

@@ -39,7 +39,7 @@ int ata1_build(F1Sched &S, const Affine &A, const Affine &Ainv, Dim3i gd, Dim3i 
                const SplatSafety &safe);
 void ata1_free(F1Sched &S);
 
-int ata1_blocks(Dim3i dd);  // partials written by a launch
+int ata1_blocks(Dim3i dd, int grid_cap = 0);  // partials written by a launch (grid_cap: PushEpilogue::grid_cap)
 // dst = [dst +] alpha * push_A(pull_A(src)) [+ c DtD p] with ep as in the push kernels (ep.p, when
 // given, must be src).  Non-zero return: nothing launched.
 int launch_ata1(const F1Sched &S, const float *src, const Affine &A, float alpha, const PushEpilogue &ep,

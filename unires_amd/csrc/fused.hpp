@@ -19,6 +19,7 @@ struct PushEpilogue {
   int accumulate = 0;          // dst += instead of dst =
   double *partials = nullptr;  // push_tile_blocks(dd) doubles: pieces of sum(p * dst)
   const float *objb = nullptr; // objective mode: partials = sum (dst - 2 objb) * p, dst not stored
+  int grid_cap = 0;            // persistent kernels (k_splat2, k_ata1): at most this many workgroups; 0 = as many as the chip holds
 };
 
 // xs = S conv_down pull_A(src).  Returns non-zero if the tile does not fit LDS

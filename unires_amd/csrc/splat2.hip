@@ -78,9 +78,12 @@ static int s2_ntiles(Dim3i dd) {
   return ((dd.x + T::TX - 1) / T::TX) * ((dd.y + T::TY - 1) / T::TY) * ((dd.z + T::TZ - 1) / T::TZ);
 }
 
-static int s2_grid(Dim3i dd) {
+// workgroups of the persistent launch; `share_cap` > 0: the caller runs other work next to it (channels of a y-update
+// on streams of their own) and wants room left on the CUs - see unires_plan_set_concurrency (api.hip)
+static int s2_grid(Dim3i dd, int share_cap = 0) {
   const int nt = s2_ntiles(dd);
-  static const int cap = getenv("UNIRES_SPLAT2_BLOCKS") ? atoi(getenv("UNIRES_SPLAT2_BLOCKS")) : 1024;
+  static const int cap_env = getenv("UNIRES_SPLAT2_BLOCKS") ? atoi(getenv("UNIRES_SPLAT2_BLOCKS")) : 0;
+  const int cap = cap_env > 0 ? cap_env : (share_cap >= 8 ? share_cap : 1024);
   const int want = (nt + kS2Waves - 1) / kS2Waves;
   return want < cap ? want : cap;
 }
@@ -1265,7 +1268,7 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
   }
 }
 
-int splat2_blocks(Dim3i dd) { return s2_grid(dd) * kS2Waves; }  // partials written
+int splat2_blocks(Dim3i dd, int grid_cap) { return s2_grid(dd, grid_cap) * kS2Waves; }  // partials written
 
 // Workgroups of k_splat2<axis> that take tiles: as many of the grid as the device holds at once (asked of the
 // runtime once per kernel), rounded down to whole rounds over the 8 XCDs.  (All LDS is static since r6: four
@@ -1315,9 +1318,11 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
   P.dst = dst, P.dd = dd, P.accumulate = ep.accumulate, P.partials = ep.partials, P.objb = ep.objb;
   static const int dbg = getenv("UNIRES_S2_DBG") ? atoi(getenv("UNIRES_S2_DBG")) : 0;
   P.dbg = dbg;
-  const dim3 grid(s2_grid(dd)), block(kWave * kS2Waves);
+  const dim3 grid(s2_grid(dd, ep.grid_cap)), block(kWave * kS2Waves);
   P.active = s2_active(S.axis, (int)grid.x);
-  if (P.active != S.nwg) return 1;  // (the walk was laid out for another launch shape)
+  // (the walk's layout depends on the launch only through the number of partitions, min(8, workgroups): a smaller
+  // persistent grid - ep.grid_cap - walks the same records with fewer wave slots per partition)
+  if (std::min(8, P.active) != std::min(8, S.nwg) || (P.active >= 8 && P.active % 8)) return 1;
   for (int x = 0; x <= 8; ++x) P.xlo[x] = S.pos_lo[x];
   static const int prio_rot = getenv("UNIRES_S2_PRIO") ? atoi(getenv("UNIRES_S2_PRIO")) : 1;
   P.prio_rot = prio_rot;

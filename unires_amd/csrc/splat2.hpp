@@ -68,7 +68,7 @@ void splat2_free(SplatSched &S);
 void sched_set_thorough(bool on);
 bool sched_thorough();
 
-int splat2_blocks(Dim3i dd);
+int splat2_blocks(Dim3i dd, int grid_cap = 0);  // (grid_cap: PushEpilogue::grid_cap of the launch)
 // tab_dev: gn float4 {bits(koff), w0, w1, -} conv_up table along the schedule's axis (nullptr for
 // a direct source); row_stride: elements per source row (axis 2 / -1), per ui (axis 1) or per uj
 // (axis 0); tab_step: elements between the two x-space values of a grid voxel (axis 0 / 1).

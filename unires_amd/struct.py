@@ -91,11 +91,11 @@ class settings:
         # 'fft': build-side FFT-diagonal preconditioner (circulant a I + rho lam^2 DtD)
         self.cgs_precond = 'none'
         # build-side knob: enqueue the (independent) channels of the y-update on separate HIP streams
-        # (True / False), or 'auto': streams for volumes below 10 M voxels.  Measured in round 3, streams
-        # vs one channel after the other (CG iterations/s): 181 x 217 x 181 (config 2, the demo's shape)
-        # +20 .. +24 % - its kernels do not fill the chip alone; 256^3: config 3 -6 %, aligned -2.5 %,
-        # translated -5.6 %, thick axis x / y / z +1.6 % - three channels' vectors (800 MB) no longer
-        # share the 256 MB Infinity Cache; 384^3 (config 4): +-1 %, Gaussian profile +3 %
+        # (True / False), or 'auto': streams whenever there are several channels.  Each plan is then told about
+        # its neighbours (unires_plan_set_concurrency) and sizes its persistent kernels for them.  CG iterations/s,
+        # streams vs one channel after the other (profiles/r06_overlap_scan.txt): 181 x 217 x 181 +20 .. +24 %,
+        # 256^3 x 3 +6 %, thick axes x / y / z +8 %, 384^3 x 4 +5 %.  (Rounds 3 - 5 stopped at 10 M voxels: with
+        # every matvec kernel filling the chip three streams bought nothing at 256^3.)
         self.channel_streams = 'auto'
         # ADMM iterations the host may run ahead of its GPU before it sleeps (blocking-sync events; 0: never
         # waits - the runtime then spins in the launch calls once the hardware queue is full), _host.Pacer
