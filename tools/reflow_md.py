@@ -84,14 +84,28 @@ def reflow(lines):
                 out += rows
             i = j
             continue
-        if len(ln) <= WIDTH or ln.startswith('#') or ln.startswith('    ') and not re.match(r'^\s*([*+-]|\d+\.)\s', ln):
+        marker = re.match(r'^(\s*)((?:[*+-]|\d+\.)\s+|>\s*)?(.*)$', ln)
+        indent, mark, body = marker.group(1), marker.group(2) or '', marker.group(3)
+        if ln.startswith('#') or not ln.strip() or (ln.startswith('    ') and not mark):
             out.append(ln)
             i += 1
             continue
-        m = re.match(r'^(\s*)((?:[*+-]|\d+\.)\s+|>\s*)?(.*)$', ln)
-        indent, mark, body = m.group(1), m.group(2) or '', m.group(3)
-        out += wrap(body, indent + mark, indent + ' ' * len(mark))
-        i += 1
+        # a block: this line and the lines that continue it (non-blank, no marker / heading / table / fence of their own)
+        j = i + 1
+        while j < n:
+            nx = lines[j].rstrip('\n')
+            if (not nx.strip() or nx.startswith('#') or nx.lstrip().startswith('|') or nx.lstrip().startswith('```')
+                    or re.match(r'^\s*((?:[*+-]|\d+\.)\s+|>\s*)', nx) or nx.endswith('  ')
+                    or (len(nx) - len(nx.lstrip()) != len(indent) + len(mark) and len(nx) - len(nx.lstrip()) != len(indent))):
+                break
+            j += 1
+        block = [lines[k].rstrip('\n') for k in range(i, j)]
+        if max(len(b) for b in block) <= WIDTH:
+            out += block
+        else:
+            text = ' '.join([body] + [b.strip() for b in block[1:]])
+            out += wrap(text, indent + mark, indent + ' ' * len(mark))
+        i = j
     return out
 
 
