@@ -53,7 +53,7 @@ def pmc_traffic(workload):
     profile file and its git blob hash so that it can be checked against the tree.
     None if no profile of this workload is committed."""
     import hashlib
-    for name in ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic_aligned.json'):
+    for name in ('r06_traffic.json', 'r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic_aligned.json'):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             raw = open(path, 'rb').read()
@@ -63,7 +63,7 @@ def pmc_traffic(workload):
                 return {'bytes_per_launch': rec['bytes_per_launch'], 'static': True,
                         'source': 'profiles/' + name, 'git_blob': blob,
                         'note': 'PMC passes of the kernels as committed with that profile; re-run '
-                                'tools/refresh_profiles_r05.sh to refresh'}
+                                'tools/refresh_profiles_r06.sh to refresh'}
         except (OSError, ValueError, KeyError):
             pass
     return None

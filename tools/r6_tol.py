@@ -7,6 +7,8 @@ dev = torch.device('cuda:0')
 wl = bench.WORKLOADS[os.environ.get('WL', 'cfg3_256c3_thick6z')]
 x, y, z, w, rho, sett = bench.build_subject(wl, dev, seed=1234)
 sett.cgs_tol, sett.cgs_stop = 1e-3, os.environ.get('STOP', 'max_gain')
+if os.environ.get('CS', 'auto') == 'serial':
+    sett.channel_streams = False
 tmp = torch.zeros_like(y[0].dat)
 n = int(os.environ.get('NUP', '6'))
 import time

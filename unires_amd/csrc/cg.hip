@@ -475,8 +475,12 @@ __global__ void __launch_bounds__(kBlock)
 // decision: while the recurred gain is >= kGuardHi x tol the solve goes on without the second A(x).  Below that the
 // fresh objective is computed every iteration, so that by the time a decision is close BOTH values in the gain are
 // fresh ones - nitorch's own arithmetic; where the previous fresh value is missing (the gain fell through the band in
-// one step, short solves) the consistent recurred pair decides.  A solve's LAST iteration always costs the second A(x).
-constexpr double kGuardHi = 4.0;
+// one step, short solves) the consistent recurred pair decides.  And below the band: a recurred gain under
+// kGuardLo x tol stops the solve there and then - the fresh gain is below tol as well, by a margin (tol / 2) that
+// is ~500 x the drift (tests/test_gpu_guard.py bounds it at 1e-5 of the range, measured ~1e-7) - so a solve whose
+// gain falls through the band in one step pays no second A(x) at all (config 3, first ADMM iteration: gains / tol
+// of the three channels 1000 .. 3.03 1.56 0.827 | 1000 0.338 | 1000 1.14 0.129 - six fresh objectives become four).
+constexpr double kGuardHi = 4.0, kGuardLo = 0.5;
 __global__ void __launch_bounds__(kBlock)
     k_sc_beta_guarded(CgState *st, const double *part_rr, const double *part_obj, int g, int k, double tol,
                       unsigned long long *hostw) {
@@ -499,8 +503,10 @@ __global__ void __launch_bounds__(kBlock)
     st->gain_rec = gain;
     st->rec_prev = rec;
     const bool far = fabs(gain) >= kGuardHi * tol;  // (NaN: not far - the fresh objective decides, as in nitorch)
-    st->skip_fresh = far ? 1 : 0;
+    const bool under = fabs(gain) < kGuardLo * tol;  // (NaN: not under)
+    st->skip_fresh = (far || under) ? 1 : 0;
     if (far) st->fresh_prev_ok = 0;
+    if (under) st->done = 1;  // converged by a margin the drift cannot bridge
     if (!isfinite(rec)) st->done = 1, st->skip_fresh = 1;
     publish(st, hostw);
   }
