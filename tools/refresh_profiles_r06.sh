@@ -3,7 +3,7 @@
 # gpurun_out/r06, copy what is to be judged into profiles/).  STEPS="1 2 ..." selects parts.
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r06; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-STEPS=${STEPS:-"1 2 3 4 5 7"}
+STEPS=${STEPS:-"1 2 3 4 5 7 8"}
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 if has 1; then
 # 1. PMC traffic (first: the bench lines below carry the git blob hash of profiles/r06_traffic.json): FETCH_SIZE /
@@ -83,5 +83,22 @@ bash tools/r5_host.sh > $OUT/host.log 2>&1
   echo "== schedule build kernels (rocprofv3), thorough / quick"
   for ex in 1 0; do UNIRES_S2_EXACT=$ex UNIRES_F1_EXACT=$ex WL=cfg3_256c3_thick6z CH=1 bash tools/prof.sh tools/pmc5.py 2>&1 | grep "build"; UNIRES_S2_EXACT=$ex UNIRES_F1_EXACT=$ex WL=cfg2_181c3_1mm CH=1 bash tools/prof.sh tools/pmc5.py 2>&1 | grep "build"; done
 } > $OUT/r06_ata1_packing.txt 2>&1
+fi
+if has 8; then
+# 8. round 6: channels overlapped by default - throughput per cap on the persistent grids and its repeatability; phase
+#    ablations of the pair at HEAD (needs build/ab/abl.so: tools/r6_buildlib.sh abl -DUNIRES_ABLATE); L2 counters; the
+#    reference-default stopping rule's kernel account and the gains its guard band sees
+bash tools/r6_share_scan.sh > /dev/null 2>&1; cp gpurun_out/r6_share_scan.txt $OUT/r06_share_scan.txt
+{ echo "# cfg3_256c3_thick6z, three bench.py runs per cap (UNIRES_SHARE_S2 = splat workgroups per 16 CUs: 64 = no cap, 28 = 448 of 1024, the default)"
+  for s in 64 28; do for rep in 1 2 3; do UNIRES_SHARE_S2=$s python bench.py --no-cpu-baseline --no-variants --admm-iters 1 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{\"metric'):
+        d=json.loads(l); print('S2=$s it/s %6.0f (serial %.0f)' % (d['value'], d['value_channels_serial'] or 0))"; done; done; } > $OUT/r06_share_repeat.txt
+[ -f build/ab/abl.so ] || bash tools/r6_buildlib.sh abl -DUNIRES_ABLATE > /dev/null 2>&1
+bash tools/r6_ablate.sh > $OUT/r06_ablations.txt 2>&1
+for wl in cfg3_256c3_thick6z cfg4_384c4_iso2; do echo "== $wl"; WL=$wl CH=1 bash tools/pmc_tcc.sh; done > $OUT/r06_l2_counters.txt 2>&1
+bash tools/r6_tolprof.sh > $OUT/r06_tol_kernels.txt 2>&1
+python tools/r6_gains.py 2>&1 | grep -v amdgpu.ids > $OUT/r06_gains.txt
 fi
 ls -la $OUT
