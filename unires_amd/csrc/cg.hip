@@ -480,7 +480,14 @@ __global__ void __launch_bounds__(kBlock)
 // is ~500 x the drift (tests/test_gpu_guard.py bounds it at 1e-5 of the range, measured ~1e-7) - so a solve whose
 // gain falls through the band in one step pays no second A(x) at all (config 3, first ADMM iteration: gains / tol
 // of the three channels 1000 .. 3.03 1.56 0.827 | 1000 0.338 | 1000 1.14 0.129 - six fresh objectives become four).
-constexpr double kGuardHi = 4.0, kGuardLo = 0.5;
+// The band's upper edge follows the solve (r6): what it is for is that the iteration BEFORE a close decision has a
+// fresh objective, i.e. that a gain which may be followed by one near tol is inside the band.  Gains contract by a
+// factor rho from one iteration to the next - 0.1 .. 0.5 in the first y-updates of a reconstruction, 0.8 .. 0.95 in
+// the later, long solves (profiles/r06_gains.txt) - so the edge sits where the PREDICTED next gain, rho x gain, is
+// still kGuardNear x tol away from the threshold: hi = kGuardNear / rho, between kGuardNear and kGuardHi.  A long
+// solve creeping towards tol (gains / tol ... 3.2 3.0 2.6 2.2 1.85 1.47 1.30 1.26 1.16 1.07) pays 5 fresh objectives
+// where the fixed edge at 4 paid 11; a solve that falls through in two steps keeps the edge at 4.
+constexpr double kGuardHi = 4.0, kGuardLo = 0.5, kGuardNear = 1.5;
 __global__ void __launch_bounds__(kBlock)
     k_sc_beta_guarded(CgState *st, const double *part_rr, const double *part_obj, int g, int k, double tol,
                       unsigned long long *hostw) {
@@ -500,9 +507,15 @@ __global__ void __launch_bounds__(kBlock)
     st->obj_max = fmax(st->obj_max, rec);
     st->obj_min = fmin(st->obj_min, rec);
     const double gain = (st->rec_prev - rec) / (st->obj_max - st->obj_min);
+    const double gain_before = fabs(st->gain_rec);  // (0 in front of the first iteration)
     st->gain_rec = gain;
     st->rec_prev = rec;
-    const bool far = fabs(gain) >= kGuardHi * tol;  // (NaN: not far - the fresh objective decides, as in nitorch)
+    double hi = kGuardHi;
+    if (gain_before > 0.0 && isfinite(gain_before) && isfinite(gain)) {
+      const double rho = fabs(gain) / gain_before;  // (> 1 where the gains are not monotone: the edge stays at kGuardNear)
+      hi = fmin(kGuardHi, fmax(kGuardNear, kGuardNear / fmax(rho, 1e-6)));
+    }
+    const bool far = fabs(gain) >= hi * tol;  // (NaN: not far - the fresh objective decides, as in nitorch)
     const bool under = fabs(gain) < kGuardLo * tol;  // (NaN: not under)
     st->skip_fresh = (far || under) ? 1 : 0;
     if (far) st->fresh_prev_ok = 0;
