@@ -232,3 +232,39 @@ def test_max_gain_iteration_counts_at_128(dev, seed):
     assert r['it'] == r['it_ref'], (r['it'], r['it_ref'])
     assert torch.allclose(torch.tensor(r['obj'], dtype=torch.float64), r['obj_ref'].double(), rtol=1e-5, atol=0)
     assert rel_err(r['y'][r['keep']], r['y_ref'][r['keep']]) < GATE
+
+
+@pytest.mark.parametrize('wlname', ['cfg3_256c3_thick6z', 'dn_256c3_1mm'])
+def test_full_size_channels_side_by_side_equal_one_after_the_other(dev, wlname):
+    """Round 6: the channels of a y-update run on streams of their own at every size, and each plan, told about its
+    neighbours (`unires_plan_set_concurrency`), caps its persistent kernels - 448 of k_splat2's 1 024 workgroups, 768 of
+    k_ata1's at 256^3, where the caps DO bite (the small problems of tests/test_gpu_path.py never reach them).  The
+    operator application is the same, bit for bit (the schedule is not rebuilt, the same tiles are walked by fewer
+    waves); only the float64 partials of the CG's dots are summed in another fixed grouping, so a whole y-update agrees
+    to rounding and is bit-reproducible in either mode."""
+    import unires_amd as U
+    from unires_amd._project import _channel_plan
+    x, y, z, w, rho, sett = workloads.build_subject(workloads.WORKLOADS[wlname], dev, seed=1234)
+    sett.cgs_max_iter, sett.cgs_tol = 6, 0.0
+    tmp = torch.zeros_like(y[0].dat)
+    plans = [_channel_plan(x[c], y[c], sett.method, sett.do_proj) for c in range(len(x))]
+    # A^T A p under the cap and without it
+    p = torch.rand(tuple(y[0].dim), generator=torch.Generator().manual_seed(5)).to(dev)
+    q = {}
+    for n in (1, 3, 1):
+        plans[0].set_concurrency(n)
+        q.setdefault(n, []).append(plans[0].matvec(p, rho, y[0].lam).clone())
+    assert torch.equal(q[1][0], q[3][0]) and torch.equal(q[1][0], q[1][1])
+    outs = {}
+    for mode in (True, False, True):
+        sett.channel_streams = mode
+        for yc in y:
+            yc.dat.zero_()
+        U._update_y(x, y, z, w, rho, tmp, sett)
+        torch.cuda.synchronize()
+        assert all(pl._concurrency == (len(x) if mode else 1) for pl in plans)
+        outs.setdefault(mode, []).append([yc.dat.clone() for yc in y])
+    for a, b in zip(outs[True][0], outs[True][1]):
+        assert torch.equal(a, b)  # (bit-reproducible in the shared-chip mode)
+    for a, b in zip(outs[True][0], outs[False][0]):
+        assert rel_err(a.cpu(), b.cpu()) < 1e-6
