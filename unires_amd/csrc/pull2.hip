@@ -41,6 +41,15 @@
 
 namespace unires {
 
+// phase-ablation switches: compiled in only with -DUNIRES_ABLATE (then UNIRES_P2_DBG selects bits: 1 no staging,
+// 2 no sampling, 4 no conv / store); product builds carry none of it (r6: the run-time test cost every sample
+// two scalar and two vector instructions and a branch)
+#ifdef UNIRES_ABLATE
+#define P2_ABL(bit) ((P.dbg & (bit)) != 0)
+#else
+#define P2_ABL(bit) (false)
+#endif
+
 constexpr int kP2SZ = 72, kP2SZ4 = kP2SZ / 4;  // z planes of a window (64 + drift + 2 + alignment)
 constexpr int kP2Items = 10;                    // 16-byte window pieces staged per thread (at most)
 #ifndef UNIRES_P2_TI
@@ -152,7 +161,7 @@ __global__ void k_pull2_plan(P2Geom G, int nblk, float tol, int W, int H, int *_
 struct P2Args {
   const float *src;
   const int *rec;
-  const int *wtab;   // dispatch index -> position of the walk (pull2_build: equal COST per XCD); nullptr: by formula
+  const int4 *wtab;  // dispatch index -> {record, bi, bj, bc} (pull2_build: equal COST per XCD); nullptr: by formula
   const int2 *itab;  // per staging item: {4 * plane group, byte offset inside the window} ...
   const int *itab2;  // ... and cxl | cyl << 16 (column inside the window; read by workgroups at the volume's x / y faces)
   float inv_m;       // 1 / G.m
@@ -167,7 +176,7 @@ struct P2Args {
   int W;             // window extent along x (cells); along y it is the template parameter H
   int band;          // block rows walked together (see the kernel's block mapping)
   unsigned long long *prof;  // -DUNIRES_P2_PROF builds: per-workgroup timeline (100 MHz ticks)
-  int dbg;           // UNIRES_P2_DBG ablation bits (measurement only): 1 no staging, 2 no sampling, 4 no conv / store
+  int dbg;           // UNIRES_P2_DBG ablation bits (read only by -DUNIRES_ABLATE builds): 1 no staging, 2 no sampling, 4 no conv / store
 };
 
 // NK, SK > 0: compile-time slice profile (7 taps stride 6 is the 6 mm / 1 mm case); 0: run-time
@@ -202,15 +211,25 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   // 508 MB for a 226 MB volume there (profiles/r03_traffic_other_configs.jsonl), and HBM is what bounds
   // it at that size.  (Where one block row's windows DO fit - config 3: 3.2 MB - the plain order is kept:
   // bands cut by the XCD runs' ends fetched 79 MB instead of 72 there.)
-  const int blk0 = P.wtab ? ((const __attribute__((address_space(4))) int *)P.wtab)[blockIdx.x]
-                          : xcd_chunked_block((int)blockIdx.x, (int)gridDim.x);
-  const int bc = blk0 % G.nbc, pair = blk0 / G.nbc;
-  const int nbi = (int)gridDim.x / (G.nbc * G.nbj);
-  const int bandh = P.band;  // kP2Band, or nbi (= plain row-major order) where a block row's windows fit the L2
-  const int band = pair / (bandh * G.nbj), rem = pair - band * (bandh * G.nbj);
-  const int bh = min(bandh, nbi - band * bandh);  // height of this band (the last one may be short)
-  const int bj = rem / bh, bi = band * bandh + (rem - bj * bh);
-  const int blk = (bi * G.nbj + bj) * G.nbc + bc;  // index of the plan's record
+  // (r6) With the plan's dispatch table the workgroup reads {record, bi, bj, bc} in one 16-byte scalar load: the walk's
+  // arithmetic below is five integer divisions by run-time values - ~150 dependent scalar instructions between a
+  // workgroup's first cycle and the address of its record, at the head of 10 240 workgroups that live ~7 us each.
+  int bi, bj, bc, blk;
+  if (P.wtab) {
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    const i4v e = ((const __attribute__((address_space(4))) i4v *)P.wtab)[blockIdx.x];
+    blk = e.x, bi = e.y, bj = e.z, bc = e.w;
+  } else {
+    const int blk0 = xcd_chunked_block((int)blockIdx.x, (int)gridDim.x);
+    const int pair = blk0 / G.nbc;
+    bc = blk0 % G.nbc;
+    const int nbi = (int)gridDim.x / (G.nbc * G.nbj);
+    const int bandh = P.band;  // kP2Band, or nbi (= plain row-major order) where a block row's windows fit the L2
+    const int band = pair / (bandh * G.nbj), rem = pair - band * (bandh * G.nbj);
+    const int bh = min(bandh, nbi - band * bandh);  // height of this band (the last one may be short)
+    bj = rem / bh, bi = band * bandh + (rem - bj * bh);
+    blk = (bi * G.nbj + bj) * G.nbc + bc;  // index of the plan's record
+  }
   const int i0 = GEN ? bi * G.oi * G.si : bi * TI, j0 = GEN ? bj * G.oj * G.sj : bj * TJ;
   const int nrows = GEN ? G.pi * G.pj : ROWS;
   const int kk0 = bc * G.m, k0 = kk0 * G.sk;
@@ -270,7 +289,7 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   // ---- stage the window: one 16-byte piece (4 planes of one column) per item; item n of the
   // load order lands on bytes 16 n of the window.  Pieces outside the volume come from an
   // out-of-range buffer offset (zeros, no branch). ----
-  if (!(P.dbg & 1)) {
+  if (!P2_ABL(1)) {
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(P.src, sd.numel() * sizeof(float));
     // (all origin reads first, then the loads: one LDS round trip per wave instead of one per item)
     unsigned offs[kP2Items];
@@ -350,18 +369,24 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
   // one sample: the trilinear value of p at grid point (i, j, kfv), from the window (masked by the field
   // of view where the workgroup is not wholly inside)
   auto sample = [&](auto i, auto j, float kfv) {
-    const RowBase rb = affine_row(G.A, (float)i, (float)j);
-    const float gx = fmaf(c0, kfv, rb.x) + t0, gy = fmaf(c1, kfv, rb.y) + t1, gz = fmaf(c2, kfv, rb.z) + t2;
+    // affine_row / affine_along, bit for bit, with x and y as ONE packed pair (written out: the file is compiled without
+    // the SLP vectoriser, whose other pairings - the y and x lerps below - cost more moves than they save)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const float fi = (float)i, fj = (float)j;
+    const v2f ai = {G.A.m[0] * fi, G.A.m[4] * fi}, aj = {G.A.m[1], G.A.m[5]}, jj = {fj, fj};
+    const v2f cxy = {c0, c1}, txy = {t0, t1}, kk = {kfv, kfv};
+    const v2f gxy = __builtin_elementwise_fma(cxy, kk, __builtin_elementwise_fma(aj, jj, ai)) + txy;
+    const float gx = gxy.x, gy = gxy.y;
+    const float gz = fmaf(c2, kfv, fmaf(G.A.m[9], fj, G.A.m[8] * fi)) + t2;
     const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
     const float wx = gx - fx, wy = gy - fy, wz = gz - fz;
     const int zl = (int)(fz - fZ0);
     const int xy = (int)fmaf(fx, (float)(H * SZ), fy * (float)SZ);
     const int a0 = xy + zl + tab[zl >> 2], a1 = xy + zl + 1 + tab[(zl + 1) >> 2];
     float v = 0.f;
-    if (!(P.dbg & 2)) {
+    if (!P2_ABL(2)) {
       // the four ds_read2_b32 return (y, y + 1) pairs: the z interpolation runs on the pairs as they
       // come (v_pk_add_f32 / v_pk_fma_f32, no register shuffles), y and x on scalars
-      typedef float v2f __attribute__((ext_vector_type(2)));
       const v2f P0 = {win[a0], win[a0 + SZ]}, R0 = {win[a0 + H * SZ], win[a0 + (H + 1) * SZ]};
       const v2f P1 = {win[a1], win[a1 + SZ]}, R1 = {win[a1 + H * SZ], win[a1 + (H + 1) * SZ]};
       const v2f wz2 = {wz, wz};
@@ -406,7 +431,7 @@ __global__ void __launch_bounds__(kBlock) k_pull_conv2(P2Args P, const int *__re
     hx = xact ? v : 0.f;
   }
   float (*scr)[SCR] = reinterpret_cast<float (*)[SCR]>(win);
-  if (P.dbg & 4) {
+  if (P2_ABL(4)) {
     if (hvall[0] + hvall[RPW - 1] == 123.f) P.dst[0] = 1.f;
   } else if (GEN) {  // keep the rows for the workgroup-wide separable conv below
     __syncthreads();  // every wave is done with the window
@@ -630,10 +655,10 @@ int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd,
     if (Q.wtab) (void)hipFree(Q.wtab);
     Q.wtab = nullptr;
     // (the table, then one class byte per workgroup)
-    if (hipMalloc((void **)&Q.wtab, (size_t)nblk * (sizeof(int) + 1)) != hipSuccess) return 1;
+    if (hipMalloc((void **)&Q.wtab, (size_t)nblk * (4 * sizeof(int) + 1)) != hipSuccess) return 1;
     Q.wtab_cap = (size_t)nblk;
   }
-  unsigned char *cls_dev = reinterpret_cast<unsigned char *>(Q.wtab + Q.wtab_cap);
+  unsigned char *cls_dev = reinterpret_cast<unsigned char *>(Q.wtab + 4 * Q.wtab_cap);
   hipLaunchKernelGGL(k_pull2_plan, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, G, (int)nblk, tol, W, H,
                      Q.rec, cls_dev);
   Q.tol = tol;
@@ -653,11 +678,13 @@ int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd,
     const long long nbi = nblk / ((long long)G.nbc * G.nbj);
     if (!off_tab && nblk >= 64) {
       // the walk: position w -> workgroup record (the kernel's own mapping)
+      long long w_bi = 0, w_bj = 0, w_bc = 0;
       auto blk_of = [&](long long w) {
         const long long bc = w % G.nbc, pair = w / G.nbc;
         const long long band = pair / ((long long)bandh * G.nbj), rem = pair - band * ((long long)bandh * G.nbj);
         const long long bh = std::min<long long>(bandh, nbi - band * bandh);
         const long long bj = rem / bh, bi = band * bandh + (rem - bj * bh);
+        w_bi = bi, w_bj = bj, w_bc = bc;
         return (bi * G.nbj + bj) * G.nbc + bc;
       };
       std::vector<int> ne, em;
@@ -694,7 +721,14 @@ int pull2_build(PullPlan &Q, Dim3i sd, const Affine &A, const Taps &T, Dim3i xd,
         ok = i == cnt;
       }
       ok = ok && in == ne.size() && ie == em.size();
-      if (ok && hipMemcpy(Q.wtab, tab.data(), (size_t)nblk * sizeof(int), hipMemcpyHostToDevice) == hipSuccess)
+      // what the kernel reads: {record, bi, bj, bc} of the walk's position
+      std::vector<int> tab4((size_t)nblk * 4);
+      for (long long d = 0; d < nblk && ok; ++d) {
+        const long long b = blk_of(tab[(size_t)d]);
+        tab4[4 * (size_t)d] = (int)b, tab4[4 * (size_t)d + 1] = (int)w_bi, tab4[4 * (size_t)d + 2] = (int)w_bj,
+                         tab4[4 * (size_t)d + 3] = (int)w_bc;
+      }
+      if (ok && hipMemcpy(Q.wtab, tab4.data(), tab4.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess)
         Q.use_wtab = true;
     }
   }
@@ -759,7 +793,7 @@ int launch_pull_conv2(const PullPlan &Q, const float *src, Dim3i sd, const Affin
   const size_t lds = p2_lds(W, H, gen) + lds_pad;
   const dim3 grid((unsigned)p2_blocks(P.G, xd)), block(kBlock);
   P.band = p2_band(P.G, (long long)grid.x, p2_lds(W, H, gen));
-  P.wtab = Q.use_wtab ? Q.wtab : nullptr;
+  P.wtab = Q.use_wtab ? reinterpret_cast<const int4 *>(Q.wtab) : nullptr;
   P.prof = nullptr;
 #ifdef UNIRES_P2_PROF
   static unsigned long long *prof_dev = nullptr;

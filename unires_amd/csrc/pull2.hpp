@@ -12,7 +12,7 @@ struct PullPlan {
   size_t cap = 0;      // workgroup records allocated
   int *itab = nullptr; // device: per staging item {plane group * 4, byte offset inside the window, cxl | cyl << 16, 0}
   size_t itab_cap = 0; // items allocated
-  int *wtab = nullptr; // device: dispatch index -> position of the kernel's walk (equal cost per XCD), then a class byte per workgroup
+  int *wtab = nullptr; // device: dispatch index -> {record, bi, bj, bc} of the kernel's walk (equal cost per XCD), then a class byte per workgroup
   size_t wtab_cap = 0;
   bool use_wtab = false;
   bool valid = false;

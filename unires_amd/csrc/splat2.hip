@@ -802,7 +802,9 @@ struct S2Args {
   unsigned long long *prof;  // -DUNIRES_S2_PROF builds: per-wave timeline (100 MHz ticks)
 };
 
-template <int AXIS, int NW>
+// OBJK: the launch evaluates the CG objective (P.objb set: q is not stored) - a kernel of its own since r6, so that the
+// sixteen extra rows its epilogue holds do not decide the register allocation of the form every CG iteration runs
+template <int AXIS, int NW, bool OBJK>
 __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(4, 4))) k_splat2(S2Args P, const int *__restrict__ done) {
   if (done && *done) return;
   using T = S2Tile;
@@ -822,8 +824,19 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
   uint4 *ring2 = ring2_all[AXIS == 3 ? wave : 0];
   float4 *tabs = tabs_all[CONV ? wave : 0];
   const Dim3i dd = P.dd;
-  const float *__restrict__ pin = P.p;
-  float *__restrict__ dst = P.dst;
+  // (r6) What only a tile's header and epilogue want - pointers, buffer ranges, the stencil's coefficients - is NOT held
+  // in scalar registers through the instruction stream: held, it did not fit (96 scalar values parked in the lanes of
+  // two VGPRs, ~75 v_readlane + their hazard waits per tile - VALU issues, what this kernel runs out of).  It is read
+  // again from the kernel-argument segment, by scalar load, through a pointer laundered per tile (S2Args is the
+  // kernel's first parameter: offset 0 of the segment).
+  typedef const __attribute__((address_space(4))) S2Args *KArgs;
+  auto kargs = [&]() {
+    KArgs k = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+#ifndef UNIRES_S2_NO_KARG
+    asm volatile("" : "+s"(k));
+#endif
+    return k;
+  };
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(P.src, P.src_bytes);
   // XCD-aware persistent schedule: workgroup b sits on XCD b % 8; each XCD walks one contiguous
   // run of tiles so that neighbouring tiles (shared stencil halos, schedule lines) share an L2.
@@ -875,24 +888,25 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
   // the slice - no register carried through the epilogue); the masks' load is issued AFTER them, so that the wait
   // the compiler puts in front of the masks' first use covers both (loads return in order).
   ulonglong2 h_mk = make_ulonglong2(0ull, 0ull);
-  auto issue_header = [&](const u4v &rc, int ln) {
+  auto issue_header = [&](KArgs K, const u4v &rc, int ln) {
     const int ni = (int)(rc.w & 0xffu);
-    const __amdgpu_buffer_rsrc_t rs_ent = make_rsrc(P.entries, P.ent_bytes);
+    const int gn = K->gn;
+    const __amdgpu_buffer_rsrc_t rs_ent = make_rsrc(K->entries, K->ent_bytes);
     S2_FENCE();
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ent, (__attribute__((address_space(3))) void *)ring, 16,
                                              16u * (rc.y + (unsigned)ln), 0, 0, 0);
     if (CONV) {
-      const __amdgpu_buffer_rsrc_t rs_tab = make_rsrc(P.tab, (size_t)P.gn * sizeof(float4));
+      const __amdgpu_buffer_rsrc_t rs_tab = make_rsrc(K->tab, (size_t)gn * sizeof(float4));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_tab, (__attribute__((address_space(3))) void *)tabs, 16,
-                                               16u * (unsigned)min(max((int)(rc.w >> 8) + ln, 0), P.gn - 1), 0, 0, 0);
+                                               16u * (unsigned)min(max((int)(rc.w >> 8) + ln, 0), gn - 1), 0, 0, 0);
     }
     S2_FENCE();
     // (every lane loads - lanes past the tile's last instruction read the zero padding or a later tile's masks, never
     // used: an unconditional load is always issued, and the wait on it is what orders the DMA above)
-    h_mk = P.masks[rc.z + (unsigned)min(ln, max(ni - 1, 0))];
+    h_mk = K->masks[rc.z + (unsigned)min(ln, max(ni - 1, 0))];
     (void)ni;
   };
-  if (rec.x != 0xffffffffu) issue_header(rec, lane);
+  if (rec.x != 0xffffffffu) issue_header(kargs(), rec, lane);
   for (; rec.x != 0xffffffffu; ++round) {
     if (P.prio_rot) {
       switch ((hw_slot + round) & 3) {
@@ -907,7 +921,7 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
     const int ninstr = (int)(rec.w & 0xffu);
     const int tab_base = (int)(rec.w >> 8);
     const unsigned ent0 = rec.y;
-    const uint4 *E = reinterpret_cast<const uint4 *>(P.entries) + ent0;
+    const uint4 *E = reinterpret_cast<const uint4 *>(P.entries) + ent0;  // (used through the stream: stays in registers)
     const int t_next = t + slots;
     const u4v rec_next = t_next < t_hi ? recs[t_next] : rec_none;
     // lane l keeps the segment-start mask of instruction l (a tile has at most 64 of them)
@@ -922,12 +936,14 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
     uint4 pre = make_uint4(0u, 0u, 0u, 0u);
     if (lp < 32) pre = E[64 + lp];
     if (CONV) {
-      // (.w = the grid coordinate the entry belongs to, as a float: the z-profile kernels take k from the table
+      // (.x = the grid coordinate the entry belongs to, as a float: the z-profile kernels take k from the table
       // instead of converting it, and the 16-byte read costs the LDS 4 cycles where the 12-byte one costs 8)
       const unsigned step4 = (AXIS == 2 || AXIS == 3) ? 4u : P.tab_step4;  // the per-lane table runs along z
       const float4 raw = tabs[lp];
-      tabs[lp] = make_float4(__int_as_float((int)(step4 * (unsigned)__float_as_int(raw.x))), P.alpha * raw.y,
-                             P.alpha * raw.z, (float)(tab_base + lp));
+      // (as the stream reads it: {grid coordinate, byte offset, alpha w0, alpha w1} - the coordinate FIRST, in the even
+      // register of the 16-byte read, where the packed coordinate arithmetic takes it without a move)
+      tabs[lp] = make_float4((float)(tab_base + lp), __int_as_float((int)(step4 * (unsigned)__float_as_int(raw.x))),
+                             P.alpha * raw.y, P.alpha * raw.z);
     }
 #ifdef UNIRES_S2_PROF
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // per tile: {header here, stream end, p window here, end, instructions}
@@ -948,7 +964,12 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
       for (int i = lz; i < N / 4; i += kWave) reinterpret_cast<float4 *>(acc)[i] = make_float4(zr, zr, zr, zr);
     }
     // accumulator cell of global floor cell (fx, fy, fz): acc_t[(fx * SY + fy) * SZ + fz]
-    float *acc_t = acc - (((x0 - 1) * SY + (y0 - 1)) * SZ + (z0 - 1));
+    // (the offset is laundered: left to itself the compiler folds its constant part, XS + YS + 1, into the immediate
+    // offsets of the eight LDS accesses, which then no longer fit their 8 bits - two more address additions per
+    // splat instruction; opaque, the four cells sit at 0 / YS / XS / XS + YS (+ 1) <= 225 dwords from ONE address)
+    int acc_off = -(((x0 - 1) * SY + (y0 - 1)) * SZ + (z0 - 1));
+    asm volatile("" : "+s"(acc_off));
+    float *acc_t = acc + acc_off;
     int chunk_lo = 0;  // the ring holds chunks chunk_lo and chunk_lo + 1 (32 entries each)
     int eb = 0;        // first entry of the next instruction, relative to the tile
     S2_FENCE();
@@ -986,7 +1007,9 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
         if (lane < 32) ring[(chunk_lo & 1) * 32 + lane] = pre;
         if (AXIS == 3) ring2[(chunk_lo & 1) * 64 + lane] = pre2;
         ++chunk_lo;
-        if (lane < 32) pre = E[32 * (chunk_lo + 2) + lane];
+        int la = lane;  // (laundered: 16 * lane is not to be held through the tile loop - it ended up in scratch memory)
+        asm volatile("" : "+v"(la));
+        if (la < 32) pre = E[32 * (chunk_lo + 2) + la];
         if (AXIS == 3) pre2 = X[64 * (chunk_lo + 2) + lane];
         S2_FENCE();
       }
@@ -1009,39 +1032,50 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
           // conv_up along x, y and z: 2 x 2 x-space columns (per segment) x the z pair (per lane)
           const uint4 xa = ring2[2 * ((ebu[u] + sl) & 63)], xb = ring2[2 * ((ebu[u] + sl) & 63) + 1];
           const float4 tb = tabs[k & 63];
-          const unsigned a = xa.x + (unsigned)__float_as_int(tb.x);
+          const unsigned a = xa.x + (unsigned)__float_as_int(tb.y);
           const uint2 p00 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a, 0, 0));
           const uint2 p01 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a + P.xs_sy4, 0, 0));
           const uint2 p10 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a + P.xs_sx4, 0, 0));
           const uint2 p11 =
               __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a + P.xs_sx4 + P.xs_sy4, 0, 0));
-          const float z00 = tb.y * __uint_as_float(p00.x) + tb.z * __uint_as_float(p00.y);
-          const float z01 = tb.y * __uint_as_float(p01.x) + tb.z * __uint_as_float(p01.y);
-          const float z10 = tb.y * __uint_as_float(p10.x) + tb.z * __uint_as_float(p10.y);
-          const float z11 = tb.y * __uint_as_float(p11.x) + tb.z * __uint_as_float(p11.y);
+          const float z00 = tb.z * __uint_as_float(p00.x) + tb.w * __uint_as_float(p00.y);
+          const float z01 = tb.z * __uint_as_float(p01.x) + tb.w * __uint_as_float(p01.y);
+          const float z10 = tb.z * __uint_as_float(p10.x) + tb.w * __uint_as_float(p10.y);
+          const float z11 = tb.z * __uint_as_float(p11.x) + tb.w * __uint_as_float(p11.y);
           Bt.w0[u] = 1.f;
-          kf = tb.w;
+          kf = tb.x;
           Bt.s0[u] = __uint_as_float(xa.y) * z00 + __uint_as_float(xa.z) * z01 + __uint_as_float(xa.w) * z10 +
                      __uint_as_float(xb.x) * z11;
           (void)code;
         } else if (AXIS == 2) {
           const float4 tb = tabs[k & 63];
-          kf = tb.w;
-          const unsigned a = __umul24(code, P.row_stride4) + (unsigned)__float_as_int(tb.x);
+          kf = tb.x;
+          const unsigned a = __umul24(code, P.row_stride4) + (unsigned)__float_as_int(tb.y);
           const uint2 pr = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a, 0, 0));
-          Bt.w0[u] = tb.y, Bt.w1[u] = tb.z, Bt.s0[u] = __uint_as_float(pr.x), Bt.s1[u] = __uint_as_float(pr.y);
+          Bt.w0[u] = tb.z, Bt.w1[u] = tb.w, Bt.s0[u] = __uint_as_float(pr.x), Bt.s1[u] = __uint_as_float(pr.y);
         } else if (AXIS == 0 || AXIS == 1) {
           const unsigned ui = code >> 9, uj = code & 511u;
           const float4 tb = tabs[((int)(AXIS == 0 ? ui : uj) - tab_base) & 63];
-          const unsigned a = __umul24(AXIS == 0 ? uj : ui, P.row_stride4) + (unsigned)__float_as_int(tb.x) +
+          const unsigned a = __umul24(AXIS == 0 ? uj : ui, P.row_stride4) + (unsigned)__float_as_int(tb.y) +
                              4u * (unsigned)k;
-          Bt.w0[u] = tb.y, Bt.w1[u] = tb.z;
+          Bt.w0[u] = tb.z, Bt.w1[u] = tb.w;
           Bt.s0[u] = buf_load(rsrc, a, 0), Bt.s1[u] = buf_load(rsrc, a + P.tab_step4, 0);
         } else {
           Bt.s0[u] = buf_load(rsrc, __umul24(code, P.row_stride4) + 4u * (unsigned)k, 0);
         }
+#ifndef UNIRES_S2_NO_PKXY
+        {
+          // x and y as ONE packed pair per instruction (the entry's {rx, ry} arrive adjacent from the ring): left to
+          // itself the vectoriser pairs the same coordinate of two batch slots and pays eleven moves per batch for it
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          const v2f cxy = {c0, c1}, txy = {t0, t1}, rxy = {rx, ry}, kk = {kf, kf};
+          const v2f gxy = __builtin_elementwise_fma(cxy, kk, rxy) + txy;
+          Bt.gx[u] = gxy.x, Bt.gy[u] = gxy.y;
+        }
+#else
         Bt.gx[u] = fmaf(c0, kf, rx) + t0;
         Bt.gy[u] = fmaf(c1, kf, ry) + t1;
+#endif
         Bt.gz[u] = fmaf(c2, kf, rz) + t2;
       }
     };
@@ -1114,6 +1148,7 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
 #endif
     // ---- epilogue: q = [q +] acc + a0 p + c DtD p ; dot += p*q  (one row per lane group) ----
     // the next tile's per-lane header: requested now, it lands under this epilogue
+    const KArgs K = kargs();
     {
       // (the ring's chunk in flight may never have been used: let it land NOW, or the compiler waits for everything -
       // the header included - the first time the epilogue writes one of its registers)
@@ -1121,10 +1156,14 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
       if (AXIS == 3) asm volatile("" ::"v"(pre2.x), "v"(pre2.y), "v"(pre2.z), "v"(pre2.w));
       int lh = lane;
       asm volatile("" : "+v"(lh));
-      if (rec_next.x != 0xffffffffu) issue_header(rec_next, lh);
+      if (rec_next.x != 0xffffffffu) issue_header(K, rec_next, lh);
     }
+    const float *__restrict__ pin = K->p;
+    float *__restrict__ dst = K->dst;
+    const float *objb = OBJK ? K->objb : nullptr;
+    const int accumulate = K->accumulate;
     double dtile = 0.0;  // this tile's part of the dot
-    const bool fast_xy = !S2_ABL(2) && pin != nullptr && !P.accumulate && ex == TX && ey == TY && dd.numel() < (1ull << 29);
+    const bool fast_xy = !S2_ABL(2) && pin != nullptr && !accumulate && ex == TX && ey == TY && dd.numel() < (1ull << 29);
     if (fast_xy) {
       // Whole tiles, wherever they lie: x / y stencil neighbours outside the volume read as zeros
       // through an out-of-range buffer offset (the volume's first and last x slabs are a quarter of
@@ -1151,7 +1190,11 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
       const int gl = le & (L - 1), grp = le / L;
       const int kz = z0 - 1 + gl;
       const bool out_z = gl >= 1 && gl <= ez;
-      const unsigned sxb = 4u * (unsigned)(dd.y * dd.z), syb = 4u * (unsigned)dd.z;
+      // (the 24 row offsets below are scalar sums of these two: as loop invariants of the tile loop they were computed
+      // once, could not all be held through the stream and came back from VGPR lanes - 58 v_readlane + their hazard
+      // waits per epilogue; laundered per tile they are made here by the scalar unit)
+      unsigned sxb = 4u * (unsigned)(dd.y * dd.z), syb = 4u * (unsigned)dd.z;
+      asm volatile("" : "+s"(sxb), "+s"(syb));
       constexpr unsigned kOob = 0x80000000u;
       const int xg = x0 + 4 * grp;
       // byte offset of (first owned slab, first owned row, plane kz): plane -1 reads plane 0 (so that the backward
@@ -1163,7 +1206,7 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
       const unsigned est = out_z ? e0 : kOob;
       const __amdgpu_buffer_rsrc_t rp = make_rsrc(pin, dd.numel() * 4),
                                    rd = make_rsrc(dst, dd.numel() * 4),
-                                   rb = make_rsrc(P.objb ? P.objb : pin, dd.numel() * 4);
+                                   rb = make_rsrc(objb ? objb : pin, dd.numel() * 4);
       const float *arow = acc + ((4 * grp + 1) * SY + 1) * SZ + gl;
       float pv[6][6];  // pv[s + 1][ly + 1]: x slab s = -1 .. 4, row ly = -1 .. 4 (corners unused)
 #pragma unroll
@@ -1183,16 +1226,9 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (pw && lane == 0 && ptile < 5) pw[5 + 5 * ptile] = wall_clock64();
 #endif
+      const float kcx = K->cx, kcy = K->cy, kcz = K->cz, ka0 = K->a0;
       auto rows = [&](auto obj_tag) {
         constexpr bool OBJ = decltype(obj_tag)::value;
-        float ob[4][4];
-        if (OBJ) {
-#pragma unroll
-          for (int sa = 1; sa <= 4; ++sa)
-#pragma unroll
-            for (int la = 1; la <= 4; ++la)
-              ob[sa - 1][la - 1] = buf_load(rb, e1, (unsigned)(sa - 1) * sxb + (unsigned)(la - 1) * syb);
-        }
         // x and y differences, each once: p[s + 1][l] - p[s][l] is the forward term of slab s and the backward term of s + 1
         float dxp[4];
 #pragma unroll
@@ -1203,6 +1239,11 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
           float dy[5], av[4];  // (the slab's four accumulator reads issued together, ahead of its arithmetic)
 #pragma unroll
           for (int la = 1; la <= 4; ++la) av[la - 1] = arow[((sa - 1) * SY + (la - 1)) * SZ];
+          float ob[4];  // (objective form: b of the slab's rows, requested per slab - all sixteen up front did not fit the registers)
+          if (OBJ) {
+#pragma unroll
+            for (int la = 1; la <= 4; ++la) ob[la - 1] = buf_load(rb, e1, (unsigned)(sa - 1) * sxb + (unsigned)(la - 1) * syb);
+          }
 #pragma unroll
           for (int la = 0; la <= 4; ++la) dy[la] = pv[sa][la + 1] - pv[sa][la];
 #pragma unroll
@@ -1215,10 +1256,10 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
             const float xf = pv[sa + 1][la] - c, xbk = dxp[la - 1];
             dxp[la - 1] = xf;
             const float yf = dy[la], ybk = dy[la - 1];
-            const float st = P.cx * (xbk - xf) + P.cy * (ybk - yf) + P.cz * (zbk - zf);
-            const float q = av[la - 1] + (P.a0 * c + st);
+            const float st = kcx * (xbk - xf) + kcy * (ybk - yf) + kcz * (zbk - zf);
+            const float q = av[la - 1] + (ka0 * c + st);
             if (OBJ) {
-              dt += (double)obj_term(q, ob[sa - 1][la - 1], c);
+              dt += (double)obj_term(q, ob[la - 1], c);
             } else {
               buf_store(q, rd, est, (unsigned)(sa - 1) * sxb + (unsigned)(la - 1) * syb);
               dt += (double)__fmul_rn(c, q);
@@ -1227,15 +1268,12 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
         }
         dtile = out_z ? dt : 0.0;
       };
-      if (P.objb)
-        rows(std::true_type{});
-      else
-        rows(std::false_type{});
+      rows(std::integral_constant<bool, OBJK>{});
     } else if (!S2_ABL(2)) {
       int lg = lane;  // (laundered: see the fast form)
       asm volatile("" : "+v"(lg));
       const int gl = lg & (L - 1), grp = lg / L;
-#pragma unroll 4
+#pragma unroll 2
       for (int r = grp; r < TX * TY; r += G) {
         const int lx = r / TY, ly = r % TY, lz = gl;
         if (lx >= ex || ly >= ey || lz >= ez) continue;
@@ -1244,11 +1282,11 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
         float q = acc[((lx + 1) * SY + ly + 1) * SZ + lz + 1];
         float pc = 0.f;
         if (pin) {
-          const float st = dtd_at(pin, idx, i, j, k, dd, P.cx, P.cy, P.cz, pc);
-          q += P.a0 * pc + st;
+          const float st = dtd_at(pin, idx, i, j, k, dd, K->cx, K->cy, K->cz, pc);
+          q += K->a0 * pc + st;
         }
-        if (P.accumulate) q += dst[idx];
-        matvec_emit(dst, idx, q, pc, P.objb, P.partials != nullptr, dtile);
+        if (accumulate) q += dst[idx];
+        matvec_emit(dst, idx, q, pc, objb, P.partials != nullptr, dtile);
       }
     }
 #ifdef UNIRES_S2_PROF
@@ -1280,11 +1318,11 @@ static int s2_active(int axis, int grid) {
   auto it = cache.find(axis);
   if (it == cache.end()) {
     int per_cu = 0, dev = 0, ncu = 0;
-    const void *fn = axis == 0   ? (const void *)k_splat2<0, kS2Waves>
-                     : axis == 1 ? (const void *)k_splat2<1, kS2Waves>
-                     : axis == 2 ? (const void *)k_splat2<2, kS2Waves>
-                     : axis == 3 ? (const void *)k_splat2<3, kS2Waves>
-                                 : (const void *)k_splat2<-1, kS2Waves>;
+    const void *fn = axis == 0   ? (const void *)k_splat2<0, kS2Waves, false>
+                     : axis == 1 ? (const void *)k_splat2<1, kS2Waves, false>
+                     : axis == 2 ? (const void *)k_splat2<2, kS2Waves, false>
+                     : axis == 3 ? (const void *)k_splat2<3, kS2Waves, false>
+                                 : (const void *)k_splat2<-1, kS2Waves, false>;
     static const int force = getenv("UNIRES_SPLAT2_RESIDENT") ? atoi(getenv("UNIRES_SPLAT2_RESIDENT")) : 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave * kS2Waves, 0) != hipSuccess) per_cu = 0;
     if (force > 0) per_cu = force;
@@ -1334,13 +1372,21 @@ int launch_splat2(const SplatSched &S, const float *src, size_t src_numel, const
   (void)hipMemsetAsync(prof_dev, 0, nprof * sizeof(unsigned long long), st);
   P.prof = prof_dev;
 #endif
+#define S2_LAUNCH(AX)                                                                          \
+  do {                                                                                         \
+    if (P.objb)                                                                                \
+      hipLaunchKernelGGL((k_splat2<AX, kS2Waves, true>), grid, block, 0, st, P, done);         \
+    else                                                                                       \
+      hipLaunchKernelGGL((k_splat2<AX, kS2Waves, false>), grid, block, 0, st, P, done);        \
+  } while (0)
   switch (S.axis) {
-    case 0: hipLaunchKernelGGL((k_splat2<0, kS2Waves>), grid, block, 0, st, P, done); break;
-    case 1: hipLaunchKernelGGL((k_splat2<1, kS2Waves>), grid, block, 0, st, P, done); break;
-    case 2: hipLaunchKernelGGL((k_splat2<2, kS2Waves>), grid, block, 0, st, P, done); break;
-    case 3: hipLaunchKernelGGL((k_splat2<3, kS2Waves>), grid, block, 0, st, P, done); break;
-    default: hipLaunchKernelGGL((k_splat2<-1, kS2Waves>), grid, block, 0, st, P, done); break;
+    case 0: S2_LAUNCH(0); break;
+    case 1: S2_LAUNCH(1); break;
+    case 2: S2_LAUNCH(2); break;
+    case 3: S2_LAUNCH(3); break;
+    default: S2_LAUNCH(-1); break;
   }
+#undef S2_LAUNCH
 #ifdef UNIRES_S2_PROF
   {
     static int shots = 0;
