@@ -811,12 +811,23 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
   constexpr int TX = T::TX, TY = T::TY, L = T::L, G = kWave / L;
   constexpr int SY = T::SY, SZ = T::SZ, N = T::N, XS = T::XS, YS = T::YS;
   constexpr bool CONV = AXIS >= 0;
-  __shared__ __align__(16) float acc_all[NW][N];
-  __shared__ __align__(16) uint4 ring_all[NW][kWave];  // 2 chunks of 32 segment entries
-  __shared__ __align__(16) uint4 ring2_all[AXIS == 3 ? NW : 1][AXIS == 3 ? 2 * kWave : 1];  // their S2Ext
-  // CONV: the 64 entries of the conv_up table from the tile's base on, {byte offset, alpha w0, alpha w1, grid
-  // coordinate as a float}, one slice per wave, refilled per tile (r6; was the whole table per workgroup)
-  __shared__ __align__(16) float4 tabs_all[CONV ? NW : 1][CONV ? kWave : 1];
+  // (one struct, so that the layout is the one written: each wave's ring and table slice are 1 KB on a 1 KB boundary,
+  // and slot (i & 63) of either is  base | ((i << 4) & 0x3f0)  - an add-shift and an and-or where the indexed form costs
+  // an and, a shift-add and, for the ring, an add)
+  struct __align__(1024) Lds {
+    uint4 ring[NW][kWave];  // 2 chunks of 32 segment entries
+    // CONV: the 64 entries of the conv_up table from the tile's base on, {grid coordinate as a float, byte offset,
+    // alpha w0, alpha w1}, one slice per wave, refilled per tile (r6; was the whole table per workgroup)
+    float4 tabs[CONV ? NW : 1][kWave];
+    float acc[NW][N];
+    uint4 ring2[AXIS == 3 ? NW : 1][AXIS == 3 ? 2 * kWave : 1];  // AXIS 3: the entries' S2Ext
+  };
+  __shared__ Lds lds;
+  static_assert(sizeof(uint4) * kWave == 1024, "ring / table slices are addressed as 1 KB blocks");
+  auto &acc_all = lds.acc;
+  auto &ring_all = lds.ring;
+  auto &ring2_all = lds.ring2;
+  auto &tabs_all = lds.tabs;
   const int lane = threadIdx.x & (kWave - 1), grp = lane / L, gl = lane & (L - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *acc = acc_all[wave];
@@ -859,6 +870,13 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
   const float c0 = P.A.m[2], c1 = P.A.m[6], c2 = P.A.m[10];
   const float t0 = P.A.m[3], t1 = P.A.m[7], t2 = P.A.m[11];
   const int lane_m64 = lane - 64;
+  typedef unsigned u4r __attribute__((ext_vector_type(4)));
+  typedef float f4r __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(3))) u4r *LdsU4;
+  typedef const __attribute__((address_space(3))) f4r *LdsF4;
+  const unsigned ring_b = (unsigned)(__UINTPTR_TYPE__)(LdsU4)(const void *)ring, tabs_b = (unsigned)(__UINTPTR_TYPE__)(LdsF4)(const void *)tabs;
+  unsigned m3f0 = 0x3f0u;  // (in a register: with the base in a scalar register the literal would be a second constant)
+  asm volatile("" : "+v"(m3f0));
   double dot = 0.0;
 #ifdef UNIRES_S2_PROF
   unsigned long long *pw = P.prof ? P.prof + (size_t)(blockIdx.x * NW + wave) * 32 : nullptr;
@@ -1017,7 +1035,7 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const int sl = (int)__builtin_amdgcn_mbcnt_hi(mhi[u], __builtin_amdgcn_mbcnt_lo(mlo[u], 0u));
-        const uint4 e = ring[(ebu[u] + sl) & 63];
+        const u4r e = *(LdsU4)(__UINTPTR_TYPE__)((((unsigned)(ebu[u] + sl) << 4) & m3f0) | ring_b);
         const float rx = __uint_as_float(e.x), ry = __uint_as_float(e.y), rz = __uint_as_float(e.z);
         float kf;
         const unsigned code = e.w & kS2RowIdle;
@@ -1031,7 +1049,7 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
         } else if (AXIS == 3) {
           // conv_up along x, y and z: 2 x 2 x-space columns (per segment) x the z pair (per lane)
           const uint4 xa = ring2[2 * ((ebu[u] + sl) & 63)], xb = ring2[2 * ((ebu[u] + sl) & 63) + 1];
-          const float4 tb = tabs[k & 63];
+          const f4r tb = *(LdsF4)(__UINTPTR_TYPE__)((((unsigned)k << 4) & m3f0) | tabs_b);
           const unsigned a = xa.x + (unsigned)__float_as_int(tb.y);
           const uint2 p00 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a, 0, 0));
           const uint2 p01 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a + P.xs_sy4, 0, 0));
@@ -1048,7 +1066,7 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
                      __uint_as_float(xb.x) * z11;
           (void)code;
         } else if (AXIS == 2) {
-          const float4 tb = tabs[k & 63];
+          const f4r tb = *(LdsF4)(__UINTPTR_TYPE__)((((unsigned)k << 4) & m3f0) | tabs_b);
           kf = tb.x;
           const unsigned a = __umul24(code, P.row_stride4) + (unsigned)__float_as_int(tb.y);
           const uint2 pr = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, a, 0, 0));
