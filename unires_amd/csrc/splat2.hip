@@ -906,25 +906,33 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
   // the slice - no register carried through the epilogue); the masks' load is issued AFTER them, so that the wait
   // the compiler puts in front of the masks' first use covers both (loads return in order).
   ulonglong2 h_mk = make_ulonglong2(0ull, 0ull);
-  auto issue_header = [&](KArgs K, const u4v &rc, int ln) {
+  struct Hdr {  // what a header request wants of the kernel arguments
+    const S2Entry *entries;
+    size_t ent_bytes;
+    const float4 *tab;
+    int gn;
+    const ulonglong2 *masks;
+  };
+  auto load_hdr = [&](KArgs K) { return Hdr{K->entries, K->ent_bytes, K->tab, K->gn, K->masks}; };
+  auto issue_header = [&](const Hdr &H, const u4v &rc, int ln) {
     const int ni = (int)(rc.w & 0xffu);
-    const int gn = K->gn;
-    const __amdgpu_buffer_rsrc_t rs_ent = make_rsrc(K->entries, K->ent_bytes);
+    const int gn = H.gn;
+    const __amdgpu_buffer_rsrc_t rs_ent = make_rsrc(H.entries, H.ent_bytes);
     S2_FENCE();
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ent, (__attribute__((address_space(3))) void *)ring, 16,
                                              16u * (rc.y + (unsigned)ln), 0, 0, 0);
     if (CONV) {
-      const __amdgpu_buffer_rsrc_t rs_tab = make_rsrc(K->tab, (size_t)gn * sizeof(float4));
+      const __amdgpu_buffer_rsrc_t rs_tab = make_rsrc(H.tab, (size_t)gn * sizeof(float4));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_tab, (__attribute__((address_space(3))) void *)tabs, 16,
                                                16u * (unsigned)min(max((int)(rc.w >> 8) + ln, 0), gn - 1), 0, 0, 0);
     }
     S2_FENCE();
     // (every lane loads - lanes past the tile's last instruction read the zero padding or a later tile's masks, never
     // used: an unconditional load is always issued, and the wait on it is what orders the DMA above)
-    h_mk = K->masks[rc.z + (unsigned)min(ln, max(ni - 1, 0))];
+    h_mk = H.masks[rc.z + (unsigned)min(ln, max(ni - 1, 0))];
     (void)ni;
   };
-  if (rec.x != 0xffffffffu) issue_header(kargs(), rec, lane);
+  if (rec.x != 0xffffffffu) issue_header(load_hdr(kargs()), rec, lane);
   for (; rec.x != 0xffffffffu; ++round) {
     if (P.prio_rot) {
       switch ((hw_slot + round) & 3) {
@@ -985,9 +993,10 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
     // (the offset is laundered: left to itself the compiler folds its constant part, XS + YS + 1, into the immediate
     // offsets of the eight LDS accesses, which then no longer fit their 8 bits - two more address additions per
     // splat instruction; opaque, the four cells sit at 0 / YS / XS / XS + YS (+ 1) <= 225 dwords from ONE address)
-    int acc_off = -(((x0 - 1) * SY + (y0 - 1)) * SZ + (z0 - 1));
-    asm volatile("" : "+s"(acc_off));
-    float *acc_t = acc + acc_off;
+    // (... and the accumulator's own LDS address goes in with it: one scalar byte address per tile)
+    typedef __attribute__((address_space(3))) float *LdsF1;
+    unsigned acc_addr = (unsigned)(__UINTPTR_TYPE__)(LdsF1)(void *)acc - 4u * (unsigned)(((x0 - 1) * SY + (y0 - 1)) * SZ + (z0 - 1));
+    asm volatile("" : "+s"(acc_addr));
     int chunk_lo = 0;  // the ring holds chunks chunk_lo and chunk_lo + 1 (32 entries each)
     int eb = 0;        // first entry of the next instruction, relative to the tile
     S2_FENCE();
@@ -1120,7 +1129,7 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
         S2_FENCE();
         if (S2_ABL(4)) dot += (double)(a00 + a01 + a10 + a11 + (float)cell);
         if (__builtin_amdgcn_inverse_ballot_w64(Bt.amask[u]) && !S2_ABL(4)) {
-          float *q = acc_t + cell;
+          const LdsF1 q = (LdsF1)(__UINTPTR_TYPE__)(acc_addr + 4u * (unsigned)cell);
           {
             const float o00 = q[0], o01 = q[YS], o10 = q[XS], o11 = q[XS + YS];
             q[0] = o00 + a00 * wz0, q[YS] = o01 + a01 * wz0, q[XS] = o10 + a10 * wz0,
@@ -1166,7 +1175,17 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
 #endif
     // ---- epilogue: q = [q +] acc + a0 p + c DtD p ; dot += p*q  (one row per lane group) ----
     // the next tile's per-lane header: requested now, it lands under this epilogue
+    // (ALL of the epilogue's scalars are requested here, ahead of the branch around the header request, and pinned: one
+    // trip to the scalar cache per tile - they came in two, the second one behind the header's loads)
     const KArgs K = kargs();
+    const Hdr H = load_hdr(K);
+    const float *__restrict__ pin = K->p;
+    float *__restrict__ dst = K->dst;
+    const float *objb = OBJK ? K->objb : nullptr;
+    const int accumulate = K->accumulate;
+    const float kcx = K->cx, kcy = K->cy, kcz = K->cz, ka0 = K->a0;
+    asm volatile("" ::"s"(H.entries), "s"(H.ent_bytes), "s"(H.tab), "s"(H.gn), "s"(H.masks), "s"(pin), "s"(dst), "s"(objb),
+                 "s"(accumulate), "s"(kcx), "s"(kcy), "s"(kcz), "s"(ka0));
     {
       // (the ring's chunk in flight may never have been used: let it land NOW, or the compiler waits for everything -
       // the header included - the first time the epilogue writes one of its registers)
@@ -1174,12 +1193,8 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
       if (AXIS == 3) asm volatile("" ::"v"(pre2.x), "v"(pre2.y), "v"(pre2.z), "v"(pre2.w));
       int lh = lane;
       asm volatile("" : "+v"(lh));
-      if (rec_next.x != 0xffffffffu) issue_header(K, rec_next, lh);
+      if (rec_next.x != 0xffffffffu) issue_header(H, rec_next, lh);
     }
-    const float *__restrict__ pin = K->p;
-    float *__restrict__ dst = K->dst;
-    const float *objb = OBJK ? K->objb : nullptr;
-    const int accumulate = K->accumulate;
     double dtile = 0.0;  // this tile's part of the dot
     const bool fast_xy = !S2_ABL(2) && pin != nullptr && !accumulate && ex == TX && ey == TY && dd.numel() < (1ull << 29);
     if (fast_xy) {
@@ -1244,7 +1259,6 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (pw && lane == 0 && ptile < 5) pw[5 + 5 * ptile] = wall_clock64();
 #endif
-      const float kcx = K->cx, kcy = K->cy, kcz = K->cz, ka0 = K->a0;
       auto rows = [&](auto obj_tag) {
         constexpr bool OBJ = decltype(obj_tag)::value;
         // x and y differences, each once: p[s + 1][l] - p[s][l] is the forward term of slab s and the backward term of s + 1
@@ -1300,8 +1314,8 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
         float q = acc[((lx + 1) * SY + ly + 1) * SZ + lz + 1];
         float pc = 0.f;
         if (pin) {
-          const float st = dtd_at(pin, idx, i, j, k, dd, K->cx, K->cy, K->cz, pc);
-          q += K->a0 * pc + st;
+          const float st = dtd_at(pin, idx, i, j, k, dd, kcx, kcy, kcz, pc);
+          q += ka0 * pc + st;
         }
         if (accumulate) q += dst[idx];
         matvec_emit(dst, idx, q, pc, objb, P.partials != nullptr, dtile);
