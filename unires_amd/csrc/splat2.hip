@@ -877,6 +877,9 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
   const unsigned ring_b = (unsigned)(__UINTPTR_TYPE__)(LdsU4)(const void *)ring, tabs_b = (unsigned)(__UINTPTR_TYPE__)(LdsF4)(const void *)tabs;
   unsigned m3f0 = 0x3f0u;  // (in a register: with the base in a scalar register the literal would be a second constant)
   asm volatile("" : "+v"(m3f0));
+  typedef float v2k __attribute__((ext_vector_type(2)));
+  v2k k_one0 = {1.f, 0.f};  // (likewise: the packed weight pairs' second constant, else re-made in front of every use)
+  asm volatile("" : "+v"(k_one0));
   double dot = 0.0;
 #ifdef UNIRES_S2_PROF
   unsigned long long *pw = P.prof ? P.prof + (size_t)(blockIdx.x * NW + wave) * 32 : nullptr;
@@ -1117,6 +1120,44 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
         // collision tests floor the same global coordinate); the tile's base enters once, as an integer offset of
         // the accumulator pointer (r6: was a subtraction per coordinate in front of v_fract - three instructions
         // more, and exact only for tiles off the volume's low faces)
+#ifndef UNIRES_S2_NO_PKW
+        // (r6, with the registers the build without the SLP vectoriser left free - packed, this form needed 129 of 128 in
+        // round 3.)  The weights as PAIRS: {wx0, wx1} and {wy0, wy1} come out of one packed fma each ({-1, 1} w + {1, 0}: the
+        // same single rounding as 1 - w, and w itself), v {wx0, wx1}, then {a00, a01} = vx0 {wy0, wy1} and {a10, a11} = vx1
+        // {wy0, wy1} are packed multiplies, and the accumulator's (y, y + 1) pairs arrive from ds_read2_b32 as register
+        // pairs: one packed fma per pair where there were two.  21 vector instructions per splat instruction instead of 29,
+        // every product and sum rounded exactly as before.
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+        const v2f gxy = {gx, gy}, fxy = {fx, fy};
+        const v2f w1 = gxy - fxy;  // {wx1, wy1}
+        const float wz1 = gz - fz, wz0 = 1.f - wz1;
+        const v2f m11 = {-1.f, 1.f}, one0 = k_one0;
+        const v2f wx = __builtin_elementwise_fma(m11, (v2f){w1.x, w1.x}, one0);  // {wx0, wx1}
+        const v2f wy = __builtin_elementwise_fma(m11, (v2f){w1.y, w1.y}, one0);  // {wy0, wy1}
+        // cell index in float (exact: integers below 2^24), one conversion
+        const float cf = fmaf(fx, (float)XS, fmaf(fy, (float)YS, fz));
+        const int cell = (int)cf;
+        const float v = Bt.w0[u] * Bt.s0[u] + Bt.w1[u] * Bt.s1[u];
+        const v2f vx = (v2f){v, v} * wx;                 // {vx0, vx1}
+        const v2f a0 = (v2f){vx.x, vx.x} * wy, a1 = (v2f){vx.y, vx.y} * wy;  // {a00, a01}, {a10, a11}
+        S2_FENCE();
+        if (S2_ABL(4)) dot += (double)(a0.x + a0.y + a1.x + a1.y + (float)cell);
+        if (__builtin_amdgcn_inverse_ballot_w64(Bt.amask[u]) && !S2_ABL(4)) {
+          const LdsF1 q = (LdsF1)(__UINTPTR_TYPE__)(acc_addr + 4u * (unsigned)cell);
+          {
+            const v2f o0 = {q[0], q[YS]}, o1 = {q[XS], q[XS + YS]};
+            const v2f r0 = __builtin_elementwise_fma(a0, (v2f){wz0, wz0}, o0), r1 = __builtin_elementwise_fma(a1, (v2f){wz0, wz0}, o1);
+            q[0] = r0.x, q[YS] = r0.y, q[XS] = r1.x, q[XS + YS] = r1.y;
+          }
+          S2_FENCE();
+          {
+            const v2f o0 = {q[1], q[YS + 1]}, o1 = {q[XS + 1], q[XS + YS + 1]};
+            const v2f r0 = __builtin_elementwise_fma(a0, (v2f){wz1, wz1}, o0), r1 = __builtin_elementwise_fma(a1, (v2f){wz1, wz1}, o1);
+            q[1] = r0.x, q[YS + 1] = r0.y, q[XS + 1] = r1.x, q[XS + YS + 1] = r1.y;
+          }
+        }
+#else
         const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
         const float wx1 = gx - fx, wy1 = gy - fy, wz1 = gz - fz;
         const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
@@ -1145,6 +1186,7 @@ __global__ void __launch_bounds__(kWave *NW) __attribute__((amdgpu_waves_per_eu(
             q[XS + YS + 1] = o11 + a11 * wz1;
           }
         }
+#endif
         S2_FENCE();
       }
     };
